@@ -1,0 +1,173 @@
+// ref_harness.cpp -- thin C entry points onto the REFERENCE's own code, compiled from the
+// sources where they lie under /root/reference (see oracle/Makefile).  TEST INFRASTRUCTURE:
+// it validates oracle/hm_oracle.c and generates tests/golden/*.  Nothing under
+// hm-opencl_amd/ links it.  Output goes to oracle/_ref/ only (git-ignored, travels with gpurun).
+//
+// The reference keeps the functions we need protected/private; the harness opens them with
+// the usual test-only macro trick (the reference sources themselves are untouched).
+#define protected public
+#define private public
+#include "TLibCommon/TComRom.h"
+#include "TLibCommon/TComRdCost.h"
+#include "TLibCommon/TComPattern.h"
+#include "TLibCommon/TComDataCU.h"
+#include "TLibCommon/TComSlice.h"
+#include "TLibEncoder/TEncCfg.h"
+#include "TLibEncoder/TEncSearch.h"
+#undef protected
+#undef private
+
+#include <stdint.h>
+#include <string.h>
+#include <new>
+
+namespace {
+
+struct Rig {
+  TEncSearch* search;
+  TEncCfg* cfg;
+  TComRdCost* rd;
+  TComDataCU* cu;
+  TComSlice* slice;
+  TComSPS* sps;
+  Rig() {
+    initROM();
+    // heap objects, never destroyed: ~TEncSearch dereferences members init() would have set
+    search = new TEncSearch;
+    cfg = new TEncCfg;
+    rd = new TComRdCost;
+    cu = new TComDataCU;
+    slice = new TComSlice;
+    sps = new TComSPS;
+    rd->init();
+    search->m_pcEncCfg = cfg;
+    search->m_pcRdCost = rd;
+    slice->setSPS(sps);
+    cu->m_pcSlice = slice;
+    cu->m_pePartSize = new Char[4]();
+    cu->m_puhDepth = new UChar[4]();
+    cu->m_puhWidth = new UChar[4]();
+    cu->m_puhHeight = new UChar[4]();
+  }
+};
+
+Rig& rig() {
+  static Rig* r = new Rig;
+  return *r;
+}
+
+void setup_cost(double lambda, int pred_x, int pred_y, int bit_depth) {
+  Rig& r = rig();
+  BitDepths bd;
+  for (int i = 0; i < MAX_NUM_CHANNEL_TYPE; ++i) bd.recon[i] = bit_depth;
+  r.rd->setLambda(lambda, bd);
+  r.rd->getMotionCost(true, 0, false);  // TEncSearch.cpp:3735
+  TComMv pred((Short)pred_x, (Short)pred_y);
+  r.rd->setPredictor(pred);             // :3737
+  r.rd->setCostScale(2);                // :3738
+}
+
+void setup_cu(int cu_x, int cu_y, int pic_w, int pic_h, int max_cu) {
+  Rig& r = rig();
+  r.sps->setPicWidthInLumaSamples(pic_w);
+  r.sps->setPicHeightInLumaSamples(pic_h);
+  r.sps->setMaxCUWidth(max_cu);
+  r.sps->setMaxCUHeight(max_cu);
+  r.cu->m_uiCUPelX = cu_x;
+  r.cu->m_uiCUPelY = cu_y;
+}
+
+}  // namespace
+
+extern "C" {
+
+// TComRdCost::xGetComponentBits
+uint32_t ref_component_bits(int v) { return rig().rd->xGetComponentBits(v); }
+
+// m_uiLambdaMotionSAD[0] after TComRdCost::setLambda
+uint32_t ref_lambda_q16(double lambda) {
+  setup_cost(lambda, 0, 0, 8);
+  return rig().rd->m_uiCost;
+}
+
+// TComRdCost::getCost(x, y) with cost scale 2
+uint32_t ref_mv_cost(double lambda, int x, int y, int pred_x, int pred_y) {
+  setup_cost(lambda, pred_x, pred_y, 8);
+  return rig().rd->getCost(x, y);
+}
+
+// the SAD function TComRdCost::setDistParam(pattern, ...) selects for this width
+uint32_t ref_sad(int16_t* org, int org_stride, int16_t* cur, int cur_stride, int w, int h, int sub_shift,
+                 int bit_depth) {
+  Rig& r = rig();
+  TComPattern pat;
+  pat.initPattern(org, w, h, org_stride, bit_depth);
+  DistParam dp;
+  dp.bApplyWeight = false;
+  r.rd->setDistParam(&pat, cur, cur_stride, dp);
+  dp.iSubShift = sub_shift;
+  dp.bitDepth = bit_depth;
+  return dp.DistFunc(&dp);
+}
+
+// TComDataCU::getIndexBlock
+int ref_index_block(int part_size, int depth, int part_idx, int abs_z_idx, int cu_h, int cu_w) {
+  Rig& r = rig();
+  r.cu->m_pePartSize[0] = (Char)part_size;
+  r.cu->m_puhDepth[0] = (UChar)depth;
+  r.cu->m_absZIdxInCtu = abs_z_idx;
+  r.cu->m_puhHeight[0] = (UChar)cu_h;
+  r.cu->m_puhWidth[0] = (UChar)cu_w;
+  return r.cu->getIndexBlock(part_idx);
+}
+
+// TEncSearch::xSetSearchRange (+ TComDataCU::clipMv)
+void ref_set_search_range(int pred_x_q, int pred_y_q, int sr, int cu_x, int cu_y, int pic_w, int pic_h,
+                          int max_cu, int* lt_x, int* lt_y, int* rb_x, int* rb_y) {
+  Rig& r = rig();
+  setup_cu(cu_x, cu_y, pic_w, pic_h, max_cu);
+  TComMv pred((Short)pred_x_q, (Short)pred_y_q), lt, rb;
+  r.search->xSetSearchRange(r.cu, pred, sr, lt, rb);
+  *lt_x = lt.getHor(); *lt_y = lt.getVer(); *rb_x = rb.getHor(); *rb_y = rb.getVer();
+}
+
+// TEncSearch::xPatternSearch for one PU.  `ref_at_pu` = reference plane at the PU origin.
+void ref_pattern_search(int16_t* org, int org_stride, int w, int h, int16_t* ref_at_pu, int ref_stride, int lt_x,
+                        int lt_y, int rb_x, int rb_y, int pred_x, int pred_y, double lambda, int fen,
+                        int bit_depth, int* mvx, int* mvy, uint32_t* sad) {
+  Rig& r = rig();
+  setup_cost(lambda, pred_x, pred_y, bit_depth);
+  r.cfg->setUseFastEnc(fen != 0);
+  r.cfg->setFastSearch(0);
+  TComPattern pat;
+  pat.initPattern(org, w, h, org_stride, bit_depth);
+  TComMv lt((Short)lt_x, (Short)lt_y), rb((Short)rb_x, (Short)rb_y), mv;
+  Distortion d = 0;
+  r.search->xPatternSearch(&pat, ref_at_pu, ref_stride, &lt, &rb, mv, d);
+  *mvx = mv.getHor(); *mvy = mv.getVer(); *sad = d;
+}
+
+// TEncSearch::xTZSearch for one PU (FastSearch=1).  start_q = *pcMvPred (TEncSearch.cpp:3778).
+// has_int_mv: pass pIntegerMv2Nx2NPred.  Window LT/RB as computed by the caller.
+void ref_tz_search(int16_t* org, int org_stride, int w, int h, int16_t* ref_at_pu, int ref_stride, int lt_x,
+                   int lt_y, int rb_x, int rb_y, int pred_x, int pred_y, double lambda, int fen, int bit_depth,
+                   int sr, int cu_x, int cu_y, int pic_w, int pic_h, int max_cu, int has_int_mv, int int_mv_x,
+                   int int_mv_y, int* mvx, int* mvy, uint32_t* sad) {
+  Rig& r = rig();
+  setup_cost(lambda, pred_x, pred_y, bit_depth);
+  setup_cu(cu_x, cu_y, pic_w, pic_h, max_cu);
+  r.cfg->setUseFastEnc(fen != 0);
+  r.cfg->setFastSearch(1);
+  r.search->m_iSearchRange = sr;
+  r.search->m_iFastSearch = 1;
+  TComPattern pat;
+  pat.initPattern(org, w, h, org_stride, bit_depth);
+  TComMv lt((Short)lt_x, (Short)lt_y), rb((Short)rb_x, (Short)rb_y);
+  TComMv mv((Short)pred_x, (Short)pred_y);
+  TComMv imv((Short)int_mv_x, (Short)int_mv_y);
+  Distortion d = 0;
+  r.search->xTZSearch(r.cu, &pat, ref_at_pu, ref_stride, &lt, &rb, mv, d, has_int_mv ? &imv : 0);
+  *mvx = mv.getHor(); *mvy = mv.getVer(); *sad = d;
+}
+
+}  // extern "C"

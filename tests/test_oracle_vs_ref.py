@@ -1,0 +1,50 @@
+"""Live cross-check of the oracle against the reference's own compiled code
+(oracle/_ref/libhmref.so).  Skipped where the library was never built (it is prebuilt here
+and travels with the gpurun snapshot; /root/reference itself never does)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_py
+
+pytestmark = pytest.mark.skipif(not oracle_py.ref_available(), reason="oracle/_ref/libhmref.so not built")
+
+
+def test_random_pu_searches_match_reference(oracle_lib):
+    R = oracle_lib.ref()
+    rng = np.random.default_rng(2024)
+    table = oracle_lib.slot_table()
+    for it in range(40):
+        bd = int(rng.choice([8, 10]))
+        sr = int(rng.choice([3, 8, 12]))
+        side = 64 + 2 * sr + 8
+        cur = rng.integers(0, 1 << bd, size=(64, 64)).astype(np.int16)
+        ref = rng.integers(0, 1 << bd, size=(side, side)).astype(np.int16)
+        o = sr + 4
+        lam = float(rng.choice([0.0, 3.3, 57.9, 900.0, 5.0e6]))
+        pred = (int(rng.integers(-60, 61)), int(rng.integers(-60, 61)))
+        lt = (-int(rng.integers(0, sr + 1)), -int(rng.integers(0, sr + 1)))
+        rb = (int(rng.integers(0, sr + 1)), int(rng.integers(0, sr + 1)))
+        fen = int(rng.integers(0, 2))
+        lq = R.ref_lambda_q16(lam)
+        p = oracle_lib.make_params(lt, rb, pred, lq, fen, bd)
+        ox, oy, osad = oracle_lib.search_ctu(cur, (0, 0), ref, (o, o), p)
+        for s in rng.choice(593, size=25, replace=False):
+            x, y, w, h = (int(v) for v in table[s])
+            want = oracle_lib.pattern_search(cur, (x, y), ref, (o + x, o + y), w, h, p, use_ref=True, lam=lam)
+            assert (int(ox[s]), int(oy[s]), int(osad[s])) == want, (it, s)
+            assert oracle_lib.pattern_search(cur, (x, y), ref, (o + x, o + y), w, h, p) == want
+
+
+def test_cost_and_bits_match_reference(oracle_lib):
+    L, R = oracle_lib.oracle(), oracle_lib.ref()
+    rng = np.random.default_rng(5)
+    for v in rng.integers(-40000, 40001, size=500):
+        assert L.hmo_component_bits(int(v)) == R.ref_component_bits(int(v))
+    for lam in (0.1, 33.0, 2.0e5, 9.9e6):
+        lq = R.ref_lambda_q16(lam)
+        assert lq == L.hmo_lambda_q16(lam)
+        for _ in range(100):
+            x, y, px, py = (int(v) for v in rng.integers(-300, 301, size=4))
+            assert L.hmo_mv_cost(lq, x, y, px, py, 2) == R.ref_mv_cost(lam, x, y, px, py)
