@@ -1,0 +1,413 @@
+// hmme.hip -- host side of the C ABI declared in include/hmme.h (see that header for the
+// reference interface each entry point replaces).  Plain HIP runtime; no OpenCL, no fallback path.
+#include "../../include/hmme.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "me_kernels.hpp"
+
+using hmme::MeJob;
+
+namespace {
+constexpr int kMarginX = 128;  // >= 72 needed by clipMv's bounds (+3 for dword staging); 128 keeps CTU rows 64B-aligned
+constexpr int kMarginY = 80;   // TComPicYuv: maxCUHeight + 16 (reference TComPicYuv.cpp:91-92)
+std::string g_create_error;
+}  // namespace
+
+struct hmme_ctx {
+  int device = 0;
+  int sr_max = 64;
+  uint32_t lambda_q16 = 0;
+  std::string err;
+  std::string info;
+  hipStream_t stream = nullptr;   // private stream of the synchronous entry points
+  // per-CTU path scratch
+  uint8_t* d_ctu = nullptr;       // 64 x 64
+  uint8_t* d_win = nullptr;       // window copy, pitch kWinPitch
+  uint8_t* h_stage = nullptr;     // pinned: ctu + window
+  int16_t* h_mv = nullptr;        // pinned results
+  uint32_t* h_sad = nullptr;
+  int16_t* d_mv1 = nullptr;
+  uint32_t* d_sad1 = nullptr;
+  MeJob* d_job1 = nullptr;
+  // frame path scratch (grown on demand)
+  MeJob* d_jobs = nullptr;
+  int jobs_cap = 0;
+  int16_t* d_pred = nullptr;
+  int16_t* d_mv = nullptr;
+  uint32_t* d_sad = nullptr;
+  int out_cap = 0;
+  int* d_flag = nullptr;
+};
+
+struct hmme_plane {
+  hmme_ctx* ctx = nullptr;
+  int width = 0, height = 0;
+  int pitch = 0;          // bytes per row, multiple of 256
+  int rows = 0;           // height + 2 * kMarginY
+  uint8_t* d_data = nullptr;
+  void* d_stage = nullptr;  // device staging for uploads (int16 or u8 picture area)
+  size_t stage_bytes = 0;
+  const uint8_t* origin() const { return d_data + (size_t)kMarginY * pitch + kMarginX; }
+};
+
+namespace {
+
+constexpr int kWinPitch = 256;   // per-CTU path: window rows are packed at this pitch
+
+int fail(hmme_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf; else g_create_error = buf;
+  fprintf(stderr, "hmme: ERROR: %s\n", buf);   // TEncOpenCL::checkError prints too (TEncOpenCL.h:93-101)
+  return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                              \
+  do {                                                                                                  \
+    hipError_t e_ = (call);                                                                             \
+    if (e_ != hipSuccess) return fail(ctx, HMME_ERR_DEVICE, "%s -> %s", #call, hipGetErrorString(e_));   \
+  } while (0)
+
+int launch_search(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const uint8_t* ref, int ref_pitch, const MeJob* d_jobs,
+                  int n_jobs, int fen, int16_t* d_mv, uint32_t* d_sad, hipStream_t stream) {
+  if (n_jobs <= 0) return HMME_OK;
+  if (fen)
+    hipLaunchKernelGGL(hmme::me_search_kernel<1>, dim3(n_jobs), dim3(hmme::kThreads), 0, stream, cur, cur_pitch, ref,
+                       ref_pitch, d_jobs, ctx->lambda_q16, d_mv, d_sad);
+  else
+    hipLaunchKernelGGL(hmme::me_search_kernel<0>, dim3(n_jobs), dim3(hmme::kThreads), 0, stream, cur, cur_pitch, ref,
+                       ref_pitch, d_jobs, ctx->lambda_q16, d_mv, d_sad);
+  HIP_TRY(ctx, hipGetLastError());
+  return HMME_OK;
+}
+
+int check_frame_args(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp, int* first,
+                     int* count) {
+  if (!ctx) return HMME_ERR_ARG;
+  if (!cur || !ref || !fp) return fail(ctx, HMME_ERR_ARG, "null plane / params");
+  if (cur->width != ref->width || cur->height != ref->height) return fail(ctx, HMME_ERR_ARG, "cur/ref size mismatch");
+  if (fp->bit_depth != 8) return fail(ctx, HMME_ERR_UNSUPPORTED, "bit depth %d: only the 8-bit path exists in this build", fp->bit_depth);
+  if (fp->search_range < 1 || fp->search_range > ctx->sr_max)
+    return fail(ctx, HMME_ERR_ARG, "search range %d outside [1, %d]", fp->search_range, ctx->sr_max);
+  const int n = hmme_num_ctus(cur->width, cur->height);
+  *first = fp->ctu_first;
+  *count = fp->ctu_count < 0 ? n - fp->ctu_first : fp->ctu_count;
+  if (*first < 0 || *count < 0 || *first + *count > n) return fail(ctx, HMME_ERR_ARG, "CTU range [%d, +%d) outside 0..%d", *first, *count, n);
+  return HMME_OK;
+}
+
+int ensure_jobs(hmme_ctx* ctx, int n) {
+  if (n <= ctx->jobs_cap) return HMME_OK;
+  if (ctx->d_jobs) hipFree(ctx->d_jobs);
+  ctx->d_jobs = nullptr; ctx->jobs_cap = 0;
+  HIP_TRY(ctx, hipMalloc(&ctx->d_jobs, sizeof(MeJob) * (size_t)n));
+  ctx->jobs_cap = n;
+  return HMME_OK;
+}
+
+}  // namespace
+
+namespace {
+template <typename T>
+int plane_fill(hmme_plane* pl, const T* d_src, int src_pitch_elems, hipStream_t s, bool check) {
+  hmme_ctx* ctx = pl->ctx;
+  dim3 grid((pl->pitch / 4 + 255) / 256, pl->rows);
+  hipLaunchKernelGGL(hmme::me_fill_plane_kernel<T>, grid, dim3(256), 0, s, pl->d_data, pl->pitch, kMarginX, kMarginY,
+                     pl->width, pl->height, d_src, src_pitch_elems, ctx->d_flag);
+  HIP_TRY(ctx, hipGetLastError());
+  if (check) {
+    int flag = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&flag, ctx->d_flag, sizeof flag, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (flag) {
+      HIP_TRY(ctx, hipMemset(ctx->d_flag, 0, sizeof(int)));
+      return fail(ctx, HMME_ERR_RANGE, "plane upload: sample outside [0,255] in the 8-bit path");
+    }
+  }
+  return HMME_OK;
+}
+
+template <typename T>
+int plane_upload(hmme_plane* pl, const T* origin, int stride) {
+  if (!pl) return HMME_ERR_ARG;
+  hmme_ctx* ctx = pl->ctx;
+  if (!origin || stride < pl->width) return fail(ctx, HMME_ERR_ARG, "plane upload: bad origin/stride");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = sizeof(T) * (size_t)pl->width * pl->height;
+  if (pl->stage_bytes < bytes) {
+    hipFree(pl->d_stage); pl->d_stage = nullptr; pl->stage_bytes = 0;
+    HIP_TRY(ctx, hipMalloc(&pl->d_stage, bytes));
+    pl->stage_bytes = bytes;
+  }
+  HIP_TRY(ctx, hipMemcpy2DAsync(pl->d_stage, sizeof(T) * pl->width, origin, sizeof(T) * (size_t)stride, sizeof(T) * pl->width,
+                                pl->height, hipMemcpyHostToDevice, ctx->stream));
+  return plane_fill<T>(pl, (const T*)pl->d_stage, pl->width, ctx->stream, true);
+}
+}  // namespace
+
+extern "C" {
+
+int hmme_num_ctus(int width, int height) { return ((width + 63) / 64) * ((height + 63) / 64); }
+
+int hmme_create(int device, int sr_max, unsigned flags, hmme_ctx** out) {
+  (void)flags;
+  if (!out) return fail(nullptr, HMME_ERR_ARG, "hmme_create: out == NULL");
+  *out = nullptr;
+  if (sr_max < 1 || sr_max > HMME_MAX_SEARCH_RANGE)
+    return fail(nullptr, HMME_ERR_UNSUPPORTED, "hmme_create: sr_max %d outside [1, %d]", sr_max, HMME_MAX_SEARCH_RANGE);
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return fail(nullptr, HMME_ERR_DEVICE, "hmme_create: no HIP device (this engine has no CPU fallback)");
+  if (device < 0 || device >= n_dev) return fail(nullptr, HMME_ERR_ARG, "hmme_create: device %d of %d", device, n_dev);
+  hipDeviceProp_t prop;
+  if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess)
+    return fail(nullptr, HMME_ERR_DEVICE, "hmme_create: cannot open device %d", device);
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, HMME_ERR_DEVICE, "hmme_create: device %d is %s; the kernels are built for gfx950 only", device, prop.gcnArchName);
+  hmme_ctx* ctx = new hmme_ctx;
+  ctx->device = device;
+  ctx->sr_max = sr_max;
+  char info[256];
+  snprintf(info, sizeof info, "%s (%s), %d CUs, %.0f GiB", prop.name, prop.gcnArchName, prop.multiProcessorCount,
+           (double)prop.totalGlobalMem / (1 << 30));
+  ctx->info = info;
+  const size_t win_bytes = (size_t)hmme::kWinRowsMax * kWinPitch + 64;
+#define CREATE_TRY(call)                                                                                           \
+  do {                                                                                                             \
+    hipError_t e_ = (call);                                                                                        \
+    if (e_ != hipSuccess) { int rc = fail(nullptr, HMME_ERR_NOMEM, "hmme_create: %s -> %s", #call, hipGetErrorString(e_)); hmme_destroy(ctx); return rc; } \
+  } while (0)
+  CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  CREATE_TRY(hipMalloc(&ctx->d_ctu, 64 * 64));
+  CREATE_TRY(hipMalloc(&ctx->d_win, win_bytes));
+  CREATE_TRY(hipHostMalloc(&ctx->h_stage, 64 * 64 + win_bytes));
+  CREATE_TRY(hipHostMalloc(&ctx->h_mv, sizeof(int16_t) * 2 * HMME_NUM_CTU_PARTS));
+  CREATE_TRY(hipHostMalloc(&ctx->h_sad, sizeof(uint32_t) * HMME_NUM_CTU_PARTS));
+  CREATE_TRY(hipMalloc(&ctx->d_mv1, sizeof(int16_t) * 2 * HMME_NUM_CTU_PARTS));
+  CREATE_TRY(hipMalloc(&ctx->d_sad1, sizeof(uint32_t) * HMME_NUM_CTU_PARTS));
+  CREATE_TRY(hipMalloc(&ctx->d_job1, sizeof(MeJob)));
+  CREATE_TRY(hipMalloc(&ctx->d_flag, sizeof(int)));
+  CREATE_TRY(hipMemset(ctx->d_flag, 0, sizeof(int)));
+#undef CREATE_TRY
+  *out = ctx;
+  return HMME_OK;
+}
+
+void hmme_destroy(hmme_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  if (ctx->stream) { hipStreamSynchronize(ctx->stream); hipStreamDestroy(ctx->stream); }
+  hipFree(ctx->d_ctu); hipFree(ctx->d_win); hipFree(ctx->d_mv1); hipFree(ctx->d_sad1); hipFree(ctx->d_job1);
+  hipFree(ctx->d_jobs); hipFree(ctx->d_pred); hipFree(ctx->d_mv); hipFree(ctx->d_sad); hipFree(ctx->d_flag);
+  if (ctx->h_stage) hipHostFree(ctx->h_stage);
+  if (ctx->h_mv) hipHostFree(ctx->h_mv);
+  if (ctx->h_sad) hipHostFree(ctx->h_sad);
+  delete ctx;
+}
+
+const char* hmme_last_error(const hmme_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+const char* hmme_device_info(const hmme_ctx* ctx) { return ctx ? ctx->info.c_str() : ""; }
+
+int hmme_set_lambda(hmme_ctx* ctx, double lambda) {
+  if (!ctx) return HMME_ERR_ARG;
+  if (!(lambda >= 0.0)) return fail(ctx, HMME_ERR_ARG, "lambda %g", lambda);
+  ctx->lambda_q16 = (uint32_t)std::floor(65536.0 * std::sqrt(lambda));   // TEncOpenCL.h:121 == TComRdCost.cpp:209
+  return HMME_OK;
+}
+int hmme_set_lambda_q16(hmme_ctx* ctx, uint32_t q) {
+  if (!ctx) return HMME_ERR_ARG;
+  ctx->lambda_q16 = q;
+  return HMME_OK;
+}
+uint32_t hmme_get_lambda_q16(const hmme_ctx* ctx) { return ctx ? ctx->lambda_q16 : 0; }
+
+void hmme_params_ocl_compat(hmme_search_params* p, int lt_x, int lt_y, int sr) {
+  // TEncOpenCL.cpp:312-313 scans [0, 2*SR] from LT and never reads RB; cl/sad.cl:374-398 prices the MV
+  // against (0,0); no row sub-sampling, no bit-depth shift
+  p->lt_x = lt_x; p->lt_y = lt_y; p->rb_x = lt_x + 2 * sr; p->rb_y = lt_y + 2 * sr;
+  p->pred_x = 0; p->pred_y = 0; p->fen = 0; p->bit_depth = 8;
+}
+
+void hmme_set_search_range(int pred_x_q, int pred_y_q, int sr, int cu_x, int cu_y, int pic_w, int pic_h, int* lt_x,
+                           int* lt_y, int* rb_x, int* rb_y) {
+  hmme::set_search_range(pred_x_q, pred_y_q, sr, cu_x, cu_y, pic_w, pic_h, *lt_x, *lt_y, *rb_x, *rb_y);
+}
+
+// ---- per-CTU drop-in ---------------------------------------------------------------------------------
+int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref0, int ref_stride,
+                    const hmme_search_params* p, int16_t* out_mv, uint32_t* out_sad) {
+  if (!ctx) return HMME_ERR_ARG;
+  if (!ctu || !ref0 || !p || !out_mv || !out_sad) return fail(ctx, HMME_ERR_ARG, "hmme_search_ctu: null argument");
+  if (p->bit_depth != 8) return fail(ctx, HMME_ERR_UNSUPPORTED, "bit depth %d: only the 8-bit path exists in this build", p->bit_depth);
+  const int wx = p->rb_x - p->lt_x + 1, wy = p->rb_y - p->lt_y + 1;
+  if (wx < 1 || wy < 1 || wx > 2 * ctx->sr_max + 1 || wy > 2 * ctx->sr_max + 1)
+    return fail(ctx, HMME_ERR_ARG, "window %dx%d outside 1..%d", wx, wy, 2 * ctx->sr_max + 1);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // pack CTU and window to bytes in pinned memory (the reference copies the same window with a scalar
+  // CPU loop, TEncOpenCL.cpp:275-277)
+  uint8_t* h_ctu = ctx->h_stage;
+  uint8_t* h_win = ctx->h_stage + 64 * 64;
+  unsigned bad = 0;
+  for (int y = 0; y < 64; ++y)
+    for (int x = 0; x < 64; ++x) {
+      const int v = ctu[y * ctu_stride + x];
+      bad |= (unsigned)v;
+      h_ctu[y * 64 + x] = (uint8_t)v;
+    }
+  const int rows = wy + 63, cols = wx + 63;
+  const int16_t* src = ref0 + (long)p->lt_y * ref_stride + p->lt_x;
+  for (int y = 0; y < rows; ++y) {
+    for (int x = 0; x < cols; ++x) {
+      const int v = src[(long)y * ref_stride + x];
+      bad |= (unsigned)v;
+      h_win[y * kWinPitch + x] = (uint8_t)v;
+    }
+    std::memset(h_win + y * kWinPitch + cols, 0, kWinPitch - cols);
+  }
+  if (bad & ~0xffu) return fail(ctx, HMME_ERR_RANGE, "hmme_search_ctu: sample outside [0,255] in the 8-bit path");
+  MeJob job;
+  job.ctu_x = 0; job.ctu_y = 0;
+  job.lt_x = (int16_t)p->lt_x; job.lt_y = (int16_t)p->lt_y; job.rb_x = (int16_t)p->rb_x; job.rb_y = (int16_t)p->rb_y;
+  job.pred_x = (int16_t)p->pred_x; job.pred_y = (int16_t)p->pred_y;
+  hipStream_t s = ctx->stream;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ctu, h_ctu, 64 * 64, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_win, h_win, (size_t)rows * kWinPitch + 64, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_job1, &job, sizeof job, hipMemcpyHostToDevice, s));
+  // the kernel addresses ref(ctu + lt): bias the base so that (lt_x, lt_y) lands on the window copy's first byte
+  const uint8_t* ref_base = ctx->d_win - (long)p->lt_y * kWinPitch - p->lt_x;
+  int rc = launch_search(ctx, ctx->d_ctu, 64, ref_base, kWinPitch, ctx->d_job1, 1, p->fen, ctx->d_mv1, ctx->d_sad1, s);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mv, ctx->d_mv1, sizeof(int16_t) * 2 * HMME_NUM_CTU_PARTS, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_sad, ctx->d_sad1, sizeof(uint32_t) * HMME_NUM_CTU_PARTS, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  std::memcpy(out_mv, ctx->h_mv, sizeof(int16_t) * 2 * HMME_NUM_CTU_PARTS);
+  std::memcpy(out_sad, ctx->h_sad, sizeof(uint32_t) * HMME_NUM_CTU_PARTS);
+  return HMME_OK;
+}
+
+// ---- planes ----------------------------------------------------------------------------------------------
+int hmme_plane_create(hmme_ctx* ctx, int width, int height, hmme_plane** out) {
+  if (!ctx) return HMME_ERR_ARG;
+  if (!out || width < 8 || height < 8 || width > 16384 || height > 16384) return fail(ctx, HMME_ERR_ARG, "hmme_plane_create(%d, %d)", width, height);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hmme_plane* pl = new hmme_plane;
+  pl->ctx = ctx; pl->width = width; pl->height = height;
+  pl->pitch = (width + 2 * kMarginX + 255) & ~255;
+  pl->rows = height + 2 * kMarginY;
+  hipError_t e = hipMalloc(&pl->d_data, (size_t)pl->pitch * (pl->rows + 1));
+  if (e != hipSuccess) { delete pl; return fail(ctx, HMME_ERR_NOMEM, "hipMalloc plane: %s", hipGetErrorString(e)); }
+  *out = pl;
+  return HMME_OK;
+}
+
+void hmme_plane_destroy(hmme_plane* pl) {
+  if (!pl) return;
+  hipSetDevice(pl->ctx->device);
+  hipFree(pl->d_data);
+  hipFree(pl->d_stage);
+  delete pl;
+}
+
+int hmme_plane_width(const hmme_plane* pl) { return pl ? pl->width : 0; }
+int hmme_plane_height(const hmme_plane* pl) { return pl ? pl->height : 0; }
+
+
+int hmme_plane_upload_pel(hmme_plane* pl, const int16_t* origin, int stride) { return plane_upload<int16_t>(pl, origin, stride); }
+int hmme_plane_upload_u8(hmme_plane* pl, const uint8_t* origin, int stride) { return plane_upload<uint8_t>(pl, origin, stride); }
+
+int hmme_plane_set_device_u8(hmme_plane* pl, const void* d_src, int src_pitch, void* stream) {
+  if (!pl) return HMME_ERR_ARG;
+  if (!d_src || src_pitch < pl->width) return fail(pl->ctx, HMME_ERR_ARG, "hmme_plane_set_device_u8: bad source");
+  HIP_TRY(pl->ctx, hipSetDevice(pl->ctx->device));
+  return plane_fill<uint8_t>(pl, (const uint8_t*)d_src, src_pitch, (hipStream_t)stream, false);
+}
+
+// ---- frame search --------------------------------------------------------------------------------------------
+int hmme_search_frame_device(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp,
+                             const void* d_pred_q, void* d_out_mv, void* d_out_sad, void* stream) {
+  int first, count;
+  int rc = check_frame_args(ctx, cur, ref, fp, &first, &count);
+  if (rc) return rc;
+  if (!d_out_mv || !d_out_sad) return fail(ctx, HMME_ERR_ARG, "null output buffer");
+  if (count == 0) return HMME_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  rc = ensure_jobs(ctx, count);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, dim3((count + 255) / 256), dim3(256), 0, s, ctx->d_jobs,
+                     (const int16_t*)d_pred_q, first, count, cur->width, cur->height, fp->search_range);
+  HIP_TRY(ctx, hipGetLastError());
+  return launch_search(ctx, cur->origin(), cur->pitch, ref->origin(), ref->pitch, ctx->d_jobs, count, fp->fen,
+                       (int16_t*)d_out_mv, (uint32_t*)d_out_sad, s);
+}
+
+int hmme_search_frame(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp,
+                      const int16_t* pred_q, int16_t* out_mv, uint32_t* out_sad) {
+  int first, count;
+  int rc = check_frame_args(ctx, cur, ref, fp, &first, &count);
+  if (rc) return rc;
+  if (!out_mv || !out_sad) return fail(ctx, HMME_ERR_ARG, "null output buffer");
+  if (count == 0) return HMME_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int n_ctu = hmme_num_ctus(cur->width, cur->height);
+  if (ctx->out_cap < n_ctu) {
+    hipFree(ctx->d_mv); hipFree(ctx->d_sad); hipFree(ctx->d_pred);
+    ctx->d_mv = nullptr; ctx->d_sad = nullptr; ctx->d_pred = nullptr; ctx->out_cap = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_mv, sizeof(int16_t) * 2 * HMME_NUM_CTU_PARTS * (size_t)n_ctu));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_sad, sizeof(uint32_t) * HMME_NUM_CTU_PARTS * (size_t)n_ctu));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_pred, sizeof(int16_t) * 2 * (size_t)n_ctu));
+    ctx->out_cap = n_ctu;
+  }
+  hipStream_t s = ctx->stream;
+  if (pred_q) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pred, pred_q, sizeof(int16_t) * 2 * (size_t)n_ctu, hipMemcpyHostToDevice, s));
+  rc = hmme_search_frame_device(ctx, cur, ref, fp, pred_q ? ctx->d_pred : nullptr, ctx->d_mv, ctx->d_sad, s);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(out_mv, ctx->d_mv, sizeof(int16_t) * 2 * HMME_NUM_CTU_PARTS * (size_t)count, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipMemcpyAsync(out_sad, ctx->d_sad, sizeof(uint32_t) * HMME_NUM_CTU_PARTS * (size_t)count, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  return HMME_OK;
+}
+
+int hmme_time_search_kernel(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp,
+                            const void* d_pred_q, void* d_out_mv, void* d_out_sad, void* stream, int reps, float* avg_ms) {
+  int first, count;
+  int rc = check_frame_args(ctx, cur, ref, fp, &first, &count);
+  if (rc) return rc;
+  if (!avg_ms || reps < 1) return fail(ctx, HMME_ERR_ARG, "hmme_time_search_kernel: bad reps/avg_ms");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = (hipStream_t)stream;
+  // job table once (it is not part of the timed kernel), then `reps` launches of the search kernel alone
+  rc = ensure_jobs(ctx, count);
+  if (rc) return rc;
+  hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, dim3((count + 255) / 256), dim3(256), 0, s, ctx->d_jobs,
+                     (const int16_t*)d_pred_q, first, count, cur->width, cur->height, fp->search_range);
+  hipEvent_t e0, e1;
+  HIP_TRY(ctx, hipEventCreate(&e0));
+  HIP_TRY(ctx, hipEventCreate(&e1));
+  HIP_TRY(ctx, hipEventRecord(e0, s));
+  for (int i = 0; i < reps; ++i) {
+    rc = launch_search(ctx, cur->origin(), cur->pitch, ref->origin(), ref->pitch, ctx->d_jobs, count, fp->fen,
+                       (int16_t*)d_out_mv, (uint32_t*)d_out_sad, s);
+    if (rc) return rc;
+  }
+  HIP_TRY(ctx, hipEventRecord(e1, s));
+  HIP_TRY(ctx, hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  *avg_ms = ms / reps;
+  return HMME_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,312 @@
+// me_kernels.hpp -- hand-written HIP kernels (gfx950 / CDNA4) of the hmme engine.
+//
+// Hot kernel: me_search_kernel<FEN>.  One workgroup (256 threads = 4 waves) searches one CTU
+// against one reference picture:
+//   1. the (Wy+63) x (Wx+63) byte reference window is staged into LDS (coalesced dword loads,
+//      re-aligned with v_alignbyte so that window column 0 sits at LDS byte 0 of each row);
+//   2. waves pull *tasks* (a strip of candidate MVs) from an LDS counter.  In a task every lane
+//      owns four horizontally adjacent candidates per iteration and walks the whole 64x64 CTU:
+//      v_qsad_pk_u16_u8 leaves (current-block dwords arrive through scalar loads, i.e. as SGPR
+//      operands), packed-u16 / linear-key reduction tree, per-lane min, wave butterfly --
+//      generated straight-line code, see tools/gen_me_tree.py;
+//   3. each wave folds its ten running-minimum registers into a per-CTU LDS table with 64-bit
+//      (cost, y, x) keys (ds_min_u64) so that ties resolve in raster order like
+//      TEncSearch::xPatternSearch's strict '<' (reference TEncSearch.cpp:3866-3889);
+//   4. 593 (mv, sad) results are written out coalesced.
+//
+// No MFMA: this is integer absolute-difference work.  The kernel is VALU-bound.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hmme {
+
+constexpr int kParts = 593;            // NUM_CTU_PARTS, reference TLibCommon/TypeDef.h:263
+constexpr int kPDW = 49;               // LDS window pitch in dwords (196 B >= 129 + 63 + 3)
+constexpr int kWinRowsMax = 192;       // (2*64+1) + 63
+constexpr int kIdxBits = 10;           // key = cost << 10 | iter(2) | lane(6) | j(2)
+constexpr uint32_t kInvCost = 3146751u;  // > any valid cost (<= 1047552 + 65535); + max SAD stays < 2^22
+constexpr int kGroups = 10;
+constexpr int kIterPerTask = 2;        // <= 4 (2 iteration bits in the key)
+constexpr int kThreads = 256;
+
+// one CTU search: everything in integer pels except the quarter-pel predictor
+struct MeJob {
+  int16_t ctu_x, ctu_y;   // CTU origin in the picture
+  int16_t lt_x, lt_y;     // window top-left   (xSetSearchRange, reference TEncSearch.cpp:3814-3830)
+  int16_t rb_x, rb_y;     // window bottom-right, inclusive
+  int16_t pred_x, pred_y; // AMVP predictor, quarter pels
+};
+static_assert(sizeof(MeJob) == 16, "MeJob layout");
+
+#include "me_slotmap.inc"
+
+// ---- helpers used by the generated tree ------------------------------------------------------
+typedef uint16_t u16x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+// LDS reads of the generated tree are volatile: they are issued exactly where the generator put
+// them (one 8x8 CU ahead of their use) instead of being hoisted and spilled by the scheduler
+typedef volatile __attribute__((address_space(3))) uint32_t lds_vu32_t;
+typedef volatile __attribute__((address_space(3))) uint64_t lds_vu64_t;
+
+__device__ __forceinline__ uint64_t me_pkadd(uint64_t a, uint64_t b) {
+  return __builtin_bit_cast(uint64_t, __builtin_bit_cast(u16x4_t, a) + __builtin_bit_cast(u16x4_t, b));
+}
+__device__ __forceinline__ uint64_t me_pksub(uint64_t a, uint64_t b) {
+  return __builtin_bit_cast(uint64_t, __builtin_bit_cast(u16x4_t, a) - __builtin_bit_cast(u16x4_t, b));
+}
+
+#define ME_MAXKEY 0xFFFFFFFFu
+#define ME_QSAD(lo, hi, cur, acc) __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)(hi) << 32) | (uint64_t)(lo), (cur), (acc))
+// key_j = sad_j * mult + c_j : one v_mad_u32_u16 per candidate (op_sel picks the packed half)
+#define ME_KEYS(v, p, mult)                                                                                    \
+  uint32_t v##_0, v##_1, v##_2, v##_3;                                                                         \
+  asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(v##_0) : "v"((uint32_t)(p)), "s"(mult), "v"(c0));                   \
+  asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(v##_1) : "v"((uint32_t)(p)), "s"(mult), "v"(c1));   \
+  asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(v##_2) : "v"((uint32_t)((p) >> 32)), "s"(mult), "v"(c2));           \
+  asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(v##_3) : "v"((uint32_t)((p) >> 32)), "s"(mult), "v"(c3))
+// keys are linear in the SAD:  K(a U b) = K(a) + K(b) - c ;  K(a \ b) = K(a) - K(b) + c
+#define ME_LIN(v, a, b)                                                                                         \
+  uint32_t v##_0, v##_1, v##_2, v##_3;                                                                          \
+  asm("v_add3_u32 %0, %1, %2, %3" : "=v"(v##_0) : "v"(a##_0), "v"(b##_0), "v"(nc0));                              \
+  asm("v_add3_u32 %0, %1, %2, %3" : "=v"(v##_1) : "v"(a##_1), "v"(b##_1), "v"(nc1));                              \
+  asm("v_add3_u32 %0, %1, %2, %3" : "=v"(v##_2) : "v"(a##_2), "v"(b##_2), "v"(nc2));                              \
+  asm("v_add3_u32 %0, %1, %2, %3" : "=v"(v##_3) : "v"(a##_3), "v"(b##_3), "v"(nc3))
+// K(a) >= K(b) whenever b's rectangle is inside a's, so |K(a) - K(b)| + c is exact: one v_sad_u32
+#define ME_SUB(v, a, b)                                                                                         \
+  uint32_t v##_0, v##_1, v##_2, v##_3;                                                                          \
+  asm("v_sad_u32 %0, %1, %2, %3" : "=v"(v##_0) : "v"(a##_0), "v"(b##_0), "v"(c0));                                \
+  asm("v_sad_u32 %0, %1, %2, %3" : "=v"(v##_1) : "v"(a##_1), "v"(b##_1), "v"(c1));                                \
+  asm("v_sad_u32 %0, %1, %2, %3" : "=v"(v##_2) : "v"(a##_2), "v"(b##_2), "v"(c2));                                \
+  asm("v_sad_u32 %0, %1, %2, %3" : "=v"(v##_3) : "v"(a##_3), "v"(b##_3), "v"(c3))
+#define ME_MIN4(k) min(min(k##_0, k##_1), min(k##_2, k##_3))
+
+// butterfly transpose-reduce: merge two slot registers into one; lanes whose role bit is 0 keep
+// slot a (min over the lane pair), lanes whose role bit is 1 keep slot b.
+__device__ __forceinline__ uint32_t me_merge0(uint32_t a, uint32_t b) {   // role = lane bit 5
+  u32x2_t r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  return min(r.x, r.y);
+}
+__device__ __forceinline__ uint32_t me_merge1(uint32_t a, uint32_t b) {   // role = lane bit 4
+  u32x2_t r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  return min(r.x, r.y);
+}
+template <int DPP_CTRL>
+__device__ __forceinline__ uint32_t me_merge_dpp(uint32_t a, uint32_t b, bool role) {
+  const uint32_t keep = role ? b : a;
+  const uint32_t give = role ? a : b;
+  return min(keep, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give, DPP_CTRL, 0xf, 0xf, false));
+}
+#define me_merge2(a, b, role) me_merge_dpp<0x128>(a, b, role)   // row_ror:8           role = lane bit 3
+#define me_merge3(a, b, role) me_merge_dpp<0x141>(a, b, role)   // row_half_mirror     role = lane bit 2
+#define me_merge4(a, b, role) me_merge_dpp<0x4E>(a, b, role)    // quad_perm [2,3,0,1] role = lane bit 1
+#define me_merge5(a, b, role) me_merge_dpp<0xB1>(a, b, role)    // quad_perm [1,0,3,2] role = lane bit 0
+
+// TComRdCost::xGetComponentBits (reference TComRdCost.cpp:278-292) in closed form
+__device__ __forceinline__ uint32_t me_component_bits(int v) {
+  const uint32_t t = (v <= 0) ? ((uint32_t)(-v) << 1) + 1u : ((uint32_t)v << 1);
+  return 2u * (31u - (uint32_t)__builtin_clz(t)) + 1u;
+}
+// TComRdCost::getCost(x, y) with cost scale 2 (reference TComRdCost.h:172-189): uint32 wrap, >> 16
+__device__ __forceinline__ uint32_t me_mv_cost(uint32_t lambda_q16, int x, int y, int pred_x, int pred_y) {
+  return (lambda_q16 * (me_component_bits((x << 2) - pred_x) + me_component_bits((y << 2) - pred_y))) >> 16;
+}
+
+// ---- the search kernel --------------------------------------------------------------------------
+template <int FEN>
+__global__ void __launch_bounds__(kThreads, 2)
+me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const uint8_t* __restrict__ ref_base,
+                 int ref_pitch, const MeJob* __restrict__ jobs, uint32_t lambda_q16, int16_t* __restrict__ out_mv,
+                 uint32_t* __restrict__ out_sad) {
+  __shared__ uint32_t win[kWinRowsMax * kPDW];
+  __shared__ unsigned long long best64[kParts];
+  __shared__ uint2 curl[64 * 8];   // the 64x64 current block; read wave-uniformly by the leaves
+  __shared__ int task_ctr;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const MeJob job = jobs[blockIdx.x];
+  const int wx = job.rb_x - job.lt_x + 1, wy = job.rb_y - job.lt_y + 1;   // candidates per row / rows
+
+  for (int s = tid; s < kParts; s += kThreads) best64[s] = ~0ull;
+  if (tid == 0) task_ctr = 0;
+
+  // -- 0. current block -> LDS (one 16-byte load per thread)
+  {
+    const int r = tid >> 2, q = tid & 3;
+    const uint4 v = *(const uint4*)(cur_base + (long)(job.ctu_y + r) * cur_pitch + job.ctu_x + 16 * q);
+    *(uint4*)&curl[r * 8 + 2 * q] = v;
+  }
+  // -- 1. stage the reference window: LDS row r, byte b  <->  ref(ctu_x + lt_x + b, ctu_y + lt_y + r)
+  {
+    const uint8_t* src = ref_base + (long)(job.ctu_y + job.lt_y) * ref_pitch + (job.ctu_x + job.lt_x);
+    const uint32_t mis = (uint32_t)(uintptr_t)src & 3u;
+    const uint32_t* src_al = (const uint32_t*)(src - mis);
+    const int pitch_dw = ref_pitch >> 2;
+    const int n = (wy + 63) * kPDW;
+    for (int i = tid; i < n; i += kThreads) {
+      const int r = i / kPDW, k = i - r * kPDW;
+      const uint32_t lo = src_al[(long)r * pitch_dw + k], hi = src_al[(long)r * pitch_dw + k + 1];
+      win[i] = __builtin_amdgcn_alignbyte(hi, lo, mis);
+    }
+  }
+  __syncthreads();
+
+  // -- 2. task list: the ceil(wx/4) candidate quads of a row are split into power-of-two parts
+  //       (129 -> 32 + 1); part k lays a wave out as 2^k quads x (64 >> k) rows per iteration.
+  const int quads = (wx + 3) >> 2;
+  int n_tasks = 0;
+  for (int k = 5; k >= 0; --k)
+    if (quads & (1 << k)) n_tasks += ((wy + (64 >> k) - 1) / (64 >> k) + kIterPerTask - 1) / kIterPerTask;
+
+  const uint32_t mult_a = 1u << kIdxBits;
+  const uint32_t mult_e = FEN ? (2u << kIdxBits) : (1u << kIdxBits);
+  const bool rb3 = lane & 8, rb2 = lane & 4, rb1 = lane & 2, rb0 = lane & 1;
+
+  while (true) {
+    int t = 0;
+    if (lane == 0) t = atomicAdd(&task_ctr, 1);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t >= n_tasks) break;
+    // decode task t -> (x0, k, first iteration)
+    int x0 = 0, k = 0, it0 = 0, n_it = 0;
+    {
+      int xq = 0, rem = t;
+      for (int kk = 5; kk >= 0; --kk) {
+        if (!(quads & (1 << kk))) continue;
+        const int iters = (wy + (64 >> kk) - 1) / (64 >> kk);
+        const int nt = (iters + kIterPerTask - 1) / kIterPerTask;
+        if (rem < nt) { x0 = xq * 4; k = kk; it0 = rem * kIterPerTask; n_it = min(kIterPerTask, iters - it0); break; }
+        rem -= nt;
+        xq += 1 << kk;
+      }
+    }
+    const int ty = 64 >> k;
+    const int lx = lane & ((1 << k) - 1), ly = lane >> k;
+    const int cx = x0 + 4 * lx;
+
+    // running minima of the task: register g, lane l <-> slot ME_SLOT_OF[g][l]
+    uint32_t b0 = ME_MAXKEY, b1 = ME_MAXKEY, b2 = ME_MAXKEY, b3 = ME_MAXKEY, b4 = ME_MAXKEY, b5 = ME_MAXKEY,
+             b6 = ME_MAXKEY, b7 = ME_MAXKEY, b8 = ME_MAXKEY, b9 = ME_MAXKEY;
+
+    for (int it = 0; it < n_it; ++it) {
+      const int cy = (it0 + it) * ty + ly;
+      const bool vy = cy < wy;
+      // per-candidate constants: (mv cost | invalid marker) << 10 | iteration | lane | j
+      const int mvy = job.lt_y + cy, mvx = job.lt_x + cx;
+      const uint32_t by = me_component_bits((mvy << 2) - job.pred_y);
+      const uint32_t tag = ((uint32_t)it << 8) | ((uint32_t)lane << 2);
+      uint32_t cc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t cost = (lambda_q16 * (me_component_bits(((mvx + j) << 2) - job.pred_x) + by)) >> 16;
+        cc[j] = (((vy && (cx + j) < wx) ? cost : kInvCost) << kIdxBits) | tag | (uint32_t)j;
+      }
+      const uint32_t c0 = cc[0], c1 = cc[1], c2 = cc[2], c3 = cc[3];
+      const uint32_t nc0 = 0u - c0, nc1 = 0u - c1, nc2 = 0u - c2, nc3 = 0u - c3;
+      // lanes outside the window still run (wave-uniform code) on clamped, in-bounds addresses
+      const lds_vu32_t* lpv = (const lds_vu32_t*)(win + min(cy, wy - 1) * kPDW + (min(cx, wx - 1) >> 2));
+      const lds_vu64_t* curv = (const lds_vu64_t*)curl;
+      if constexpr (FEN) {
+#include "me_tree_fen1.inc"
+      } else {
+#include "me_tree_fen0.inc"
+      }
+    }
+
+    // -- 3. fold the wave's running minima into the CTU table; (cost, y, x) keys give raster-order ties
+#define ME_FLUSH(g, key_)                                                                                          \
+    {                                                                                                              \
+      const int slot = ME_SLOT_OF[g][lane];                                                                        \
+      const uint32_t key = (key_);                                                                                 \
+      const uint32_t cost = key >> kIdxBits;                                                                       \
+      if (slot >= 0 && cost < kInvCost) {                                                                          \
+        const int kit = (key >> 8) & 3, kl = (key >> 2) & 63, kj = key & 3;                                        \
+        const int bx = x0 + 4 * (kl & ((1 << k) - 1)) + kj;                                                        \
+        const int byy = (it0 + kit) * ty + (kl >> k);                                                              \
+        atomicMin(&best64[slot],                                                                                   \
+                  ((unsigned long long)cost << 32) | ((unsigned long long)byy << 16) | (unsigned long long)bx);    \
+      }                                                                                                            \
+    }
+    ME_FLUSH(0, b0) ME_FLUSH(1, b1) ME_FLUSH(2, b2) ME_FLUSH(3, b3) ME_FLUSH(4, b4)
+    ME_FLUSH(5, b5) ME_FLUSH(6, b6) ME_FLUSH(7, b7) ME_FLUSH(8, b8) ME_FLUSH(9, b9)
+#undef ME_FLUSH
+  }
+  __syncthreads();
+
+  // -- 4. results: integer MV (TComMv layout) and the pure SAD at the arg-min (ruiSAD, reference
+  //       TEncSearch.cpp:3895: best - getCost(best))
+  for (int s = tid; s < kParts; s += kThreads) {
+    const unsigned long long v = best64[s];
+    const int mvx = job.lt_x + (int)(v & 0xffff), mvy = job.lt_y + (int)((v >> 16) & 0xffff);
+    const uint32_t cost = (uint32_t)(v >> 32);
+    const long o = (long)blockIdx.x * kParts + s;
+    out_mv[2 * o] = (int16_t)mvx;
+    out_mv[2 * o + 1] = (int16_t)mvy;
+    out_sad[o] = cost - me_mv_cost(lambda_q16, mvx, mvy, job.pred_x, job.pred_y);
+  }
+}
+
+// ---- frame helpers ---------------------------------------------------------------------------------
+
+// TComDataCU::clipMv (reference TComDataCU.cpp:2907-2920), quarter pels, maxCU = 64
+__host__ __device__ inline void clip_mv_q(int& x, int& y, int cu_x, int cu_y, int pic_w, int pic_h) {
+  const int hor_max = (pic_w + 8 - cu_x - 1) << 2, hor_min = (-64 - 8 - cu_x + 1) << 2;
+  const int ver_max = (pic_h + 8 - cu_y - 1) << 2, ver_min = (-64 - 8 - cu_y + 1) << 2;
+  x = (int16_t)(x > hor_max ? hor_max : (x < hor_min ? hor_min : x));
+  y = (int16_t)(y > ver_max ? ver_max : (y < ver_min ? ver_min : y));
+}
+// TEncSearch::xSetSearchRange (reference TEncSearch.cpp:3814-3830)
+__host__ __device__ inline void set_search_range(int pred_x, int pred_y, int sr, int cu_x, int cu_y, int pic_w,
+                                                 int pic_h, int& lt_x, int& lt_y, int& rb_x, int& rb_y) {
+  int px = pred_x, py = pred_y;
+  clip_mv_q(px, py, cu_x, cu_y, pic_w, pic_h);
+  int ltx = (int16_t)(px - (sr << 2)), lty = (int16_t)(py - (sr << 2));
+  int rbx = (int16_t)(px + (sr << 2)), rby = (int16_t)(py + (sr << 2));
+  clip_mv_q(ltx, lty, cu_x, cu_y, pic_w, pic_h);
+  clip_mv_q(rbx, rby, cu_x, cu_y, pic_w, pic_h);
+  lt_x = ltx >> 2; lt_y = lty >> 2; rb_x = rbx >> 2; rb_y = rby >> 2;
+}
+
+// one job per CTU of the picture from the per-CTU predictors
+__global__ void me_prep_jobs_kernel(MeJob* jobs, const int16_t* __restrict__ pred_q, int ctu_first, int ctu_count,
+                                    int pic_w, int pic_h, int sr) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ctu_count) return;
+  const int ctu = ctu_first + i, ctus_x = (pic_w + 63) >> 6;
+  const int cu_x = (ctu % ctus_x) * 64, cu_y = (ctu / ctus_x) * 64;
+  const int px = pred_q ? pred_q[2 * ctu] : 0, py = pred_q ? pred_q[2 * ctu + 1] : 0;
+  int ltx, lty, rbx, rby;
+  set_search_range(px, py, sr, cu_x, cu_y, pic_w, pic_h, ltx, lty, rbx, rby);
+  MeJob j;
+  j.ctu_x = (int16_t)cu_x; j.ctu_y = (int16_t)cu_y;
+  j.lt_x = (int16_t)ltx; j.lt_y = (int16_t)lty; j.rb_x = (int16_t)rbx; j.rb_y = (int16_t)rby;
+  j.pred_x = (int16_t)px; j.pred_y = (int16_t)py;
+  jobs[i] = j;
+}
+
+// picture area (int16 Pel or u8, pitch in elements) -> padded u8 plane, borders edge-replicated like
+// TComPicYuv::extendPicBorder (reference TComPicYuv.cpp:214-262).  One thread per 4 output bytes.
+// flag[0] is set when a sample lies outside [0,255].
+template <typename SrcT>
+__global__ void me_fill_plane_kernel(uint8_t* __restrict__ dst, int dst_pitch, int margin_x, int margin_y, int w, int h,
+                                     const SrcT* __restrict__ src, int src_pitch, int* __restrict__ flag) {
+  const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;   // plane column of the first byte
+  const int y = blockIdx.y;                                       // plane row
+  if (x4 >= dst_pitch) return;
+  const int sy = min(max(y - margin_y, 0), h - 1);
+  uint32_t packed = 0;
+  bool bad = false;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int sx = min(max(x4 + i - margin_x, 0), w - 1);
+    const int v = (int)src[(long)sy * src_pitch + sx];
+    bad |= (v < 0) | (v > 255);
+    packed |= (uint32_t)(v & 0xff) << (8 * i);
+  }
+  *(uint32_t*)(dst + (long)y * dst_pitch + x4) = packed;
+  if (bad) atomicOr(flag, 1);
+}
+
+}  // namespace hmme

@@ -1,0 +1,200 @@
+"""ctypes bindings onto the C ABI (include/hmme.h) of libhmme.so -- the HIP engine.
+
+There is no CPU fallback: `load()` raises if the library is missing, and every call that needs
+the GPU raises HmmeError carrying the engine's own error text.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(HERE), "csrc")
+LIB_PATH = os.path.join(CSRC, "libhmme.so")
+NUM_PARTS = 593
+
+# every symbol include/hmme.h declares (tests check the library exports all of them)
+SYMBOLS = ["hmme_create", "hmme_destroy", "hmme_last_error", "hmme_device_info", "hmme_set_lambda",
+           "hmme_set_lambda_q16", "hmme_get_lambda_q16", "hmme_params_ocl_compat", "hmme_set_search_range",
+           "hmme_search_ctu", "hmme_plane_create", "hmme_plane_destroy", "hmme_plane_upload_pel",
+           "hmme_plane_upload_u8", "hmme_plane_set_device_u8", "hmme_plane_width", "hmme_plane_height",
+           "hmme_num_ctus", "hmme_search_frame", "hmme_search_frame_device", "hmme_time_search_kernel"]
+
+
+class HmmeError(RuntimeError):
+    pass
+
+
+class SearchParams(C.Structure):
+    _fields_ = [("lt_x", C.c_int), ("lt_y", C.c_int), ("rb_x", C.c_int), ("rb_y", C.c_int),
+                ("pred_x", C.c_int), ("pred_y", C.c_int), ("fen", C.c_int), ("bit_depth", C.c_int)]
+
+
+class FrameParams(C.Structure):
+    _fields_ = [("search_range", C.c_int), ("fen", C.c_int), ("bit_depth", C.c_int),
+                ("ctu_first", C.c_int), ("ctu_count", C.c_int)]
+
+
+def build():
+    """compile libhmme.so for gfx950 (hipcc cross-compiles without a GPU)"""
+    subprocess.run(["make", "-s", "-C", CSRC], check=True)
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HmmeError(f"{LIB_PATH} is missing: build it with `make -C {CSRC}` (python __graft_entry__.py). "
+                        "The engine has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i = C.c_void_p, C.c_int
+    L.hmme_create.argtypes = [i, i, C.c_uint, C.POINTER(vp)]
+    L.hmme_destroy.argtypes = [vp]
+    L.hmme_destroy.restype = None
+    L.hmme_last_error.argtypes = [vp]
+    L.hmme_last_error.restype = C.c_char_p
+    L.hmme_device_info.argtypes = [vp]
+    L.hmme_device_info.restype = C.c_char_p
+    L.hmme_set_lambda.argtypes = [vp, C.c_double]
+    L.hmme_set_lambda_q16.argtypes = [vp, C.c_uint32]
+    L.hmme_get_lambda_q16.argtypes = [vp]
+    L.hmme_get_lambda_q16.restype = C.c_uint32
+    L.hmme_params_ocl_compat.argtypes = [C.POINTER(SearchParams), i, i, i]
+    L.hmme_params_ocl_compat.restype = None
+    L.hmme_set_search_range.argtypes = [i] * 7 + [C.POINTER(i)] * 4
+    L.hmme_set_search_range.restype = None
+    L.hmme_search_ctu.argtypes = [vp, vp, i, vp, i, C.POINTER(SearchParams), vp, vp]
+    L.hmme_plane_create.argtypes = [vp, i, i, C.POINTER(vp)]
+    L.hmme_plane_destroy.argtypes = [vp]
+    L.hmme_plane_destroy.restype = None
+    L.hmme_plane_upload_pel.argtypes = [vp, vp, i]
+    L.hmme_plane_upload_u8.argtypes = [vp, vp, i]
+    L.hmme_plane_set_device_u8.argtypes = [vp, vp, i, vp]
+    L.hmme_plane_width.argtypes = [vp]
+    L.hmme_plane_height.argtypes = [vp]
+    L.hmme_num_ctus.argtypes = [i, i]
+    L.hmme_search_frame.argtypes = [vp, vp, vp, C.POINTER(FrameParams), vp, vp, vp]
+    L.hmme_search_frame_device.argtypes = [vp, vp, vp, C.POINTER(FrameParams), vp, vp, vp, vp]
+    L.hmme_time_search_kernel.argtypes = [vp, vp, vp, C.POINTER(FrameParams), vp, vp, vp, vp, i, C.POINTER(C.c_float)]
+    _lib = L
+    return L
+
+
+class Plane:
+    def __init__(self, engine, width, height):
+        self.engine = engine
+        self.width, self.height = width, height
+        h = C.c_void_p()
+        engine._check(engine.L.hmme_plane_create(engine.h, width, height, C.byref(h)))
+        self.h = h
+
+    def upload_pel(self, padded, origin):
+        """padded: 2-D int16 HM plane, origin = (x, y) of sample (0,0) inside it"""
+        a = np.ascontiguousarray(padded, dtype=np.int16)
+        ptr = a.ctypes.data + 2 * (origin[1] * a.shape[1] + origin[0])
+        self.engine._check(self.engine.L.hmme_plane_upload_pel(self.h, ptr, a.shape[1]))
+
+    def upload_u8(self, img):
+        a = np.ascontiguousarray(img, dtype=np.uint8)
+        assert a.shape == (self.height, self.width)
+        self.engine._check(self.engine.L.hmme_plane_upload_u8(self.h, a.ctypes.data, a.shape[1]))
+
+    def set_device_u8(self, dptr, pitch, stream=0):
+        self.engine._check(self.engine.L.hmme_plane_set_device_u8(self.h, dptr, pitch, stream))
+
+    def close(self):
+        if self.h:
+            self.engine.L.hmme_plane_destroy(self.h)
+            self.h = None
+
+
+class Engine:
+    """one context = one GPU (reference: one TEncOpenCL object, TEncTop.h:82)"""
+
+    def __init__(self, device=0, sr_max=64):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.hmme_create(device, sr_max, 0, C.byref(h))
+        if rc != 0:
+            raise HmmeError(f"hmme_create failed ({rc}): {self.L.hmme_last_error(None).decode()}")
+        self.h = h
+
+    def _check(self, rc):
+        if rc != 0:
+            raise HmmeError(f"hmme error {rc}: {self.L.hmme_last_error(self.h).decode()}")
+
+    def close(self):
+        if self.h:
+            self.L.hmme_destroy(self.h)
+            self.h = None
+
+    @property
+    def device_info(self):
+        return self.L.hmme_device_info(self.h).decode()
+
+    def set_lambda(self, lam):
+        self._check(self.L.hmme_set_lambda(self.h, float(lam)))
+
+    def set_lambda_q16(self, q):
+        self._check(self.L.hmme_set_lambda_q16(self.h, int(q)))
+
+    @property
+    def lambda_q16(self):
+        return int(self.L.hmme_get_lambda_q16(self.h))
+
+    def plane(self, width, height):
+        return Plane(self, width, height)
+
+    def search_ctu(self, cur_plane, cur_xy, ref_plane, ref_xy, params):
+        """per-CTU drop-in (calcMotionVectors).  planes: 2-D int16; *_xy = CTU origin inside them.
+        -> (mv int16[593,2], sad uint32[593])"""
+        cur = np.ascontiguousarray(cur_plane, dtype=np.int16)
+        ref = np.ascontiguousarray(ref_plane, dtype=np.int16)
+        mv = np.zeros((NUM_PARTS, 2), np.int16)
+        sad = np.zeros(NUM_PARTS, np.uint32)
+        cp = cur.ctypes.data + 2 * (cur_xy[1] * cur.shape[1] + cur_xy[0])
+        rp = ref.ctypes.data + 2 * (ref_xy[1] * ref.shape[1] + ref_xy[0])
+        self._check(self.L.hmme_search_ctu(self.h, cp, cur.shape[1], rp, ref.shape[1], C.byref(params),
+                                           mv.ctypes.data, sad.ctypes.data))
+        return mv, sad
+
+    def search_frame(self, cur, ref, sr, pred_q=None, fen=1, bit_depth=8, ctu_first=0, ctu_count=-1):
+        """-> (mv int16[count,593,2], sad uint32[count,593])"""
+        n = self.L.hmme_num_ctus(cur.width, cur.height)
+        count = n - ctu_first if ctu_count < 0 else ctu_count
+        fp = FrameParams(sr, int(fen), bit_depth, ctu_first, count)
+        mv = np.zeros((count, NUM_PARTS, 2), np.int16)
+        sad = np.zeros((count, NUM_PARTS), np.uint32)
+        pq = None
+        if pred_q is not None:
+            pred_q = np.ascontiguousarray(pred_q, dtype=np.int16)
+            assert pred_q.shape == (n, 2)
+            pq = pred_q.ctypes.data
+        self._check(self.L.hmme_search_frame(self.h, cur.h, ref.h, C.byref(fp), pq, mv.ctypes.data, sad.ctypes.data))
+        return mv, sad
+
+    def search_frame_device(self, cur, ref, fp, d_pred, d_mv, d_sad, stream=0):
+        self._check(self.L.hmme_search_frame_device(self.h, cur.h, ref.h, C.byref(fp), d_pred, d_mv, d_sad, stream))
+
+    def time_search_kernel(self, cur, ref, fp, d_pred, d_mv, d_sad, stream=0, reps=3):
+        ms = C.c_float()
+        self._check(self.L.hmme_time_search_kernel(self.h, cur.h, ref.h, C.byref(fp), d_pred, d_mv, d_sad, stream, reps,
+                                                   C.byref(ms)))
+        return float(ms.value)
+
+
+def ocl_compat_params(lt_x, lt_y, sr):
+    p = SearchParams()
+    load().hmme_params_ocl_compat(C.byref(p), lt_x, lt_y, sr)
+    return p
+
+
+def set_search_range(pred_x_q, pred_y_q, sr, cu_x, cu_y, pic_w, pic_h):
+    out = [C.c_int() for _ in range(4)]
+    load().hmme_set_search_range(pred_x_q, pred_y_q, sr, cu_x, cu_y, pic_w, pic_h, *[C.byref(o) for o in out])
+    return tuple(o.value for o in out)

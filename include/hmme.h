@@ -1,0 +1,139 @@
+/*
+ * hmme.h -- C ABI of the MI355X-native integer motion-estimation engine for HM 16.4.
+ *
+ * This is the drop-in boundary: plain C types, no exceptions, no torch/HIP types in the
+ * signatures (streams and device buffers travel as void*).  It replaces what the reference's
+ * OpenCL add-on does behind TEncOpenCL (all citations relative to /root/reference/):
+ *
+ *   hmme_create            <- TEncOpenCL::findDevice + compileKernelSource + createBuffers
+ *                             (source/Lib/TLibEncoder/TEncOpenCL.cpp:69, :139, :195; called from
+ *                             TEncTop::xInitOpenCL, TEncTop.cpp:1116-1162)
+ *   hmme_set_lambda*       <- TEncOpenCL::setLambda (TEncOpenCL.h:121; TEncSlice.cpp:150)
+ *   hmme_search_ctu        <- TEncOpenCL::calcMotionVectors + getX/getY/getRuiCost
+ *                             (TEncOpenCL.cpp:240-362, TEncOpenCL.h:117-119; caller
+ *                             TEncSearch::xMotionEstimation, TEncSearch.cpp:3743-3765)
+ *   hmme_search_frame*     <- the same search batched over every CTU of a picture (the
+ *                             reference has no batched form: it launches 2*(2SR+1)^2 kernels per
+ *                             CTU from the host, TEncOpenCL.cpp:312-333)
+ *   hmme_plane_*           <- the padded reference plane calcMotionVectors reads
+ *                             (TComPicYuv, TLibCommon/TComPicYuv.cpp:91-92, 214-262)
+ *   hmme_last_error        <- TEncOpenCL::checkError (TEncOpenCL.h:93-101)
+ *   hmme_destroy           <- TEncOpenCL::~TEncOpenCL (TEncOpenCL.cpp:38-66)
+ *
+ * Results use the reference's slot order (TComDataCU::getIndexBlock, TComDataCU.cpp:3379-3391):
+ * out_mv is laid out exactly like TComMv[NUM_CTU_PARTS] ({Short hor, Short ver}, integer pels)
+ * and out_sad like Distortion[NUM_CTU_PARTS], so one memcpy fills
+ * TEncSearch::allMotionVectors[list][refIdx] / allRuiCost[list][refIdx] (TEncSearch.h:114-115).
+ *
+ * Arithmetic is HM's CPU arithmetic (TEncSearch::xPatternSearch, TEncSearch.cpp:3835-3897):
+ * predictor-relative MV cost, window LT..RB, strict '<' in raster order, optional FEN row
+ * sub-sampling.  hmme_params_ocl_compat() selects what cl/sad.cl does instead (pred (0,0),
+ * window LT..LT+2*SR, all rows).
+ *
+ * Threading: a context is not thread-safe; use one per host thread / per GPU.
+ * Every function returns HMME_OK (0) or a negative HMME_ERR_* code; nothing ever falls back
+ * to a CPU implementation.
+ */
+#ifndef HMME_H
+#define HMME_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HMME_NUM_CTU_PARTS 593 /* TLibCommon/TypeDef.h:263 */
+#define HMME_CTU_SIZE 64
+#define HMME_MAX_SEARCH_RANGE 64 /* window side (2*SR+1) <= 129 in this build */
+
+enum {
+  HMME_OK = 0,
+  HMME_ERR_ARG = -1,     /* invalid argument (null pointer, window larger than sr_max, ...) */
+  HMME_ERR_DEVICE = -2,  /* no usable gfx950 device / HIP runtime error */
+  HMME_ERR_RANGE = -3,   /* sample outside [0,255] handed to the 8-bit path */
+  HMME_ERR_NOMEM = -4,
+  HMME_ERR_UNSUPPORTED = -5
+};
+
+typedef struct hmme_ctx hmme_ctx;
+typedef struct hmme_plane hmme_plane;
+
+/* one (CTU, reference picture) search; integer-pel window, quarter-pel predictor */
+typedef struct hmme_search_params {
+  int lt_x, lt_y;      /* cMvSrchRngLT after xSetSearchRange (TEncSearch.cpp:3814-3830) */
+  int rb_x, rb_y;      /* cMvSrchRngRB, inclusive */
+  int pred_x, pred_y;  /* m_pcRdCost->setPredictor(*pcMvPred), quarter pels (TEncSearch.cpp:3737) */
+  int fen;             /* m_pcEncCfg->getUseFastEnc() (TEncSearch.cpp:3853-3859) */
+  int bit_depth;       /* 8 in this build */
+} hmme_search_params;
+
+/* one whole-picture search: window derived per CTU from the predictor exactly like
+ * xSetSearchRange + TComDataCU::clipMv (TComDataCU.cpp:2907-2920) */
+typedef struct hmme_frame_params {
+  int search_range;  /* SearchRange (cfg/encoder_lowdelay_P_main.cfg:33) */
+  int fen;           /* FEN (cfg/encoder_lowdelay_P_main.cfg:34) */
+  int bit_depth;
+  int ctu_first;     /* first CTU (raster order) and number of CTUs to search; count < 0 = to the end */
+  int ctu_count;
+} hmme_frame_params;
+
+/* ---- context ------------------------------------------------------------------------- */
+int hmme_create(int device, int sr_max, unsigned flags, hmme_ctx** out);
+void hmme_destroy(hmme_ctx* ctx);
+const char* hmme_last_error(const hmme_ctx* ctx); /* ctx may be NULL: error of the last failed hmme_create */
+const char* hmme_device_info(const hmme_ctx* ctx);
+int hmme_set_lambda(hmme_ctx* ctx, double lambda);         /* m_lambda = floor(65536*sqrt(lambda)) */
+int hmme_set_lambda_q16(hmme_ctx* ctx, uint32_t lambda_q16);
+uint32_t hmme_get_lambda_q16(const hmme_ctx* ctx);
+
+/* the parameter set that reproduces the reference GPU path's choices */
+void hmme_params_ocl_compat(hmme_search_params* p, int lt_x, int lt_y, int search_range);
+/* xSetSearchRange + clipMv on the host (exported so callers and tests can derive LT/RB) */
+void hmme_set_search_range(int pred_x_q, int pred_y_q, int search_range, int cu_x, int cu_y, int pic_w,
+                           int pic_h, int* lt_x, int* lt_y, int* rb_x, int* rb_y);
+
+/* ---- per-CTU drop-in (host buffers, HM `Pel` = int16) --------------------------------- */
+/* ctu: 64x64 current block (TEncSearch.cpp:3747); ref_at_ctu_origin: reference plane at the CTU
+ * origin inside its padded buffer, as handed to calcMotionVectors.  Synchronous.
+ * out_mv: int16[593][2] (hor, ver), out_sad: uint32[593] (pure SAD at the arg-min = ruiCost). */
+int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref_at_ctu_origin,
+                    int ref_stride, const hmme_search_params* p, int16_t* out_mv, uint32_t* out_sad);
+
+/* ---- frame path ------------------------------------------------------------------------ */
+/* device-resident 8-bit luma plane with edge-replicated margins */
+int hmme_plane_create(hmme_ctx* ctx, int width, int height, hmme_plane** out);
+void hmme_plane_destroy(hmme_plane* plane);
+/* upload the width x height picture area of an HM plane (origin = sample (0,0)); borders are
+ * re-extended on the device like TComPicYuv::extendPicBorder */
+int hmme_plane_upload_pel(hmme_plane* plane, const int16_t* origin, int stride);
+int hmme_plane_upload_u8(hmme_plane* plane, const uint8_t* origin, int stride);
+/* device-side producers (e.g. a torch tensor): copy a width x height u8 image that already
+ * lives in device memory, then extend borders; asynchronous on `stream` (hipStream_t) */
+int hmme_plane_set_device_u8(hmme_plane* plane, const void* d_src, int src_pitch, void* stream);
+int hmme_plane_width(const hmme_plane* plane);
+int hmme_plane_height(const hmme_plane* plane);
+
+/* number of CTUs (partial edge CTUs included) of a width x height picture */
+int hmme_num_ctus(int width, int height);
+
+/* synchronous, host results.  pred_q: int16[n_ctu][2] quarter-pel predictors indexed by CTU
+ * raster address, or NULL for (0,0).  out_mv: int16[count][593][2], out_sad: uint32[count][593] */
+int hmme_search_frame(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp,
+                      const int16_t* pred_q, int16_t* out_mv, uint32_t* out_sad);
+/* asynchronous on `stream`, everything device-resident (d_pred_q may be NULL) */
+int hmme_search_frame_device(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref,
+                             const hmme_frame_params* fp, const void* d_pred_q, void* d_out_mv, void* d_out_sad,
+                             void* stream);
+
+/* ---- measurement helpers (bench.py) ------------------------------------------------------ */
+/* average device time in ms of the search kernel over `reps` back-to-back launches on `stream`,
+ * measured with hipEvents recorded on that stream */
+int hmme_time_search_kernel(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp,
+                            const void* d_pred_q, void* d_out_mv, void* d_out_sad, void* stream, int reps,
+                            float* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -78,6 +78,8 @@ def oracle():
         L.hmo_search_ctu.restype = None
         L.hmo_search_ctu.argtypes = [C.POINTER(C.c_int16), C.c_int, C.POINTER(C.c_int16), C.c_int,
                                      C.POINTER(Params), _i32p, _i32p, _u32p, C.c_void_p]
+        L.hmo_ocl_compat_params.restype = None
+        L.hmo_ocl_compat_params.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.c_uint32]
         L.hmo_tz_search.restype = C.c_long
         L.hmo_tz_search.argtypes = [C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int16), C.c_int,
                                     C.POINTER(Params), C.POINTER(TzCtx), C.POINTER(C.c_int), C.c_int, C.c_int,

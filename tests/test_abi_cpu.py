@@ -1,0 +1,52 @@
+"""CPU-side checks of the drop-in boundary: the HIP library builds, loads and exports every
+symbol include/hmme.h declares; host-side helpers that need no GPU agree with the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+from conftest import GOLDEN, ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    from hmme import api
+    api.build()
+    L = api.load()
+    header = open(os.path.join(ROOT, "include", "hmme.h")).read()
+    declared = sorted(set(re.findall(r"\b(hmme_[a-z0-9_]+)\s*\(", header)))
+    assert declared == sorted(api.SYMBOLS)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_host_search_range_matches_reference_goldens():
+    # reference: TEncSearch::xSetSearchRange + TComDataCU::clipMv (golden rows from the compiled reference)
+    from hmme import api
+    api.build()
+    for r in np.load(os.path.join(GOLDEN, "range.npz"))["rows"]:
+        px, py, sr, cu_x, cu_y, pw, ph, max_cu = (int(v) for v in r[:8])
+        assert max_cu == 64
+        assert api.set_search_range(px, py, sr, cu_x, cu_y, pw, ph) == tuple(int(v) for v in r[8:12])
+
+
+def test_ocl_compat_preset():
+    # reference: TEncOpenCL.cpp:312-313 (x,y in [0,2*SR]), cl/sad.cl:374-398 (pred 0, all rows)
+    from hmme import api
+    api.build()
+    p = api.ocl_compat_params(-13, 5, 8)
+    assert (p.lt_x, p.lt_y, p.rb_x, p.rb_y, p.pred_x, p.pred_y, p.fen, p.bit_depth) == (-13, 5, 3, 21, 0, 0, 0, 8)
+
+
+def test_create_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        return
+    from hmme import api
+    api.build()
+    try:
+        api.Engine(0)
+    except api.HmmeError as e:
+        assert "no HIP device" in str(e) or "hmme_create failed" in str(e)
+    else:
+        raise AssertionError("Engine() must not succeed without a GPU")

@@ -1,0 +1,199 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP engine, called through the C ABI,
+against (a) the golden vectors generated from the compiled reference and (b) the CPU oracle on the
+same seeded inputs.  Bit-exact: MVs and SADs are integers."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from hmme import api
+    e = api.Engine(0, 64)
+    yield e
+    e.close()
+
+
+def _golden_cases(fname):
+    d = np.load(os.path.join(GOLDEN, fname))
+    for i in range(len(d["cur"])):
+        m = dict(zip(d["meta_columns"].tolist(), (int(v) for v in d["meta"][i])))
+        yield i, m, d["cur"][i], d["ref"][i], d["out"][i]
+
+
+@pytest.mark.parametrize("fname", ["search_sr8.npz", "search_sr64.npz"])
+def test_search_ctu_matches_reference_goldens(engine, fname):
+    """hmme_search_ctu == TEncSearch::xPatternSearch on all 593 PU rectangles (goldens from the compiled reference)"""
+    from hmme import api
+    n = 0
+    for i, m, cur, ref, want in _golden_cases(fname):
+        if m["bit_depth"] != 8:
+            continue
+        engine.set_lambda_q16(m["lambda_q16"])
+        p = api.SearchParams(m["lt_x"], m["lt_y"], m["rb_x"], m["rb_y"], m["pred_x"], m["pred_y"], m["fen"], 8)
+        mv, sad = engine.search_ctu(cur, (0, 0), ref, (m["origin_x"], m["origin_y"]), p)
+        assert np.array_equal(mv.astype(np.int64), want[:, :2]), f"{fname} case {i}: MV mismatch"
+        assert np.array_equal(sad.astype(np.int64), want[:, 2]), f"{fname} case {i}: SAD mismatch"
+        n += 1
+    assert n >= 2
+
+
+def test_search_ctu_random_windows_vs_oracle(engine, oracle_lib):
+    """ragged / clipped windows, all parameter mixes, against the oracle"""
+    from hmme import api
+    rng = np.random.default_rng(77)
+    for it in range(24):
+        sr = int(rng.choice([1, 5, 8, 21, 40, 64]))
+        side = 64 + 2 * sr + 8
+        kind = it % 4
+        if kind == 3:   # motion-like content: ref = shifted cur + noise
+            base = rng.integers(0, 256, size=(side + 16, side + 16))
+            ref = base[8:8 + side, 8:8 + side].astype(np.int16)
+            dx, dy = int(rng.integers(-min(sr, 7), min(sr, 7) + 1)), int(rng.integers(-min(sr, 7), min(sr, 7) + 1))
+            o = sr + 4
+            cur = base[8 + o + dy:8 + o + dy + 64, 8 + o + dx:8 + o + dx + 64].astype(np.int16)
+        else:
+            cur = rng.integers(0, 256, size=(64, 64)).astype(np.int16)
+            ref = rng.integers(0, 256, size=(side, side)).astype(np.int16)
+        o = sr + 4
+        lt = (-int(rng.integers(0, sr + 1)), -int(rng.integers(0, sr + 1)))
+        rb = (int(rng.integers(0, sr + 1)), int(rng.integers(0, sr + 1)))
+        if it % 5 == 0:
+            lt, rb = (-sr, -sr), (sr, sr)
+        pred = (int(rng.integers(-80, 81)), int(rng.integers(-80, 81)))
+        fen = int(rng.integers(0, 2))
+        lam = float(rng.choice([0.0, 4.7, 57.9, 2000.0, 6.0e6]))
+        lq = oracle_lib.oracle().hmo_lambda_q16(lam)
+        engine.set_lambda(lam)
+        assert engine.lambda_q16 == lq
+        p = api.SearchParams(lt[0], lt[1], rb[0], rb[1], pred[0], pred[1], fen, 8)
+        mv, sad = engine.search_ctu(cur, (0, 0), ref, (o, o), p)
+        op = oracle_lib.make_params(lt, rb, pred, lq, fen, 8)
+        ox, oy, osad = oracle_lib.search_ctu(cur, (0, 0), ref, (o, o), op)
+        assert np.array_equal(mv[:, 0], ox) and np.array_equal(mv[:, 1], oy), f"iter {it}: MV mismatch"
+        assert np.array_equal(sad, osad), f"iter {it}: SAD mismatch"
+        if kind == 3 and lt[0] <= dx <= rb[0] and lt[1] <= dy <= rb[1] and lam < 100:
+            assert tuple(mv[592]) == (dx, dy) and sad[592] == 0
+
+
+def test_ocl_compat_mode_vs_oracle(engine, oracle_lib):
+    """the reference GPU path's choices (pred (0,0), window LT..LT+2SR, all rows): cl/sad.cl:374-408"""
+    from hmme import api
+    rng = np.random.default_rng(5)
+    sr = 8
+    cur = rng.integers(0, 256, size=(64, 64)).astype(np.int16)
+    ref = rng.integers(0, 256, size=(64 + 4 * sr + 8, 64 + 4 * sr + 8)).astype(np.int16)
+    o = 2 * sr + 2
+    lq = oracle_lib.oracle().hmo_lambda_q16(57.9)
+    engine.set_lambda(57.9)
+    p = api.ocl_compat_params(-sr - 3, -sr + 2, sr)
+    mv, sad = engine.search_ctu(cur, (0, 0), ref, (o, o), p)
+    import ctypes as C
+    op = oracle_lib.Params()
+    oracle_lib.oracle().hmo_ocl_compat_params(C.byref(op), -sr - 3, -sr + 2, sr, C.c_uint32(lq))
+    ox, oy, osad = oracle_lib.search_ctu(cur, (0, 0), ref, (o, o), op)
+    assert np.array_equal(mv[:, 0], ox) and np.array_equal(mv[:, 1], oy) and np.array_equal(sad, osad)
+
+
+@pytest.mark.parametrize("w,h,sr,fen,use_pred", [(200, 136, 16, 1, True), (320, 192, 64, 1, False), (192, 128, 8, 0, True)])
+def test_search_frame_vs_oracle(engine, oracle_lib, w, h, sr, fen, use_pred):
+    """whole-picture path incl. partial edge CTUs and clipped windows == oracle frame search"""
+    from hmme import synth
+    cur, ref, _ = synth.make_pair(w, h, seed=w + sr, max_mv=min(sr, 12), region=64)
+    n_ctu = ((w + 63) // 64) * ((h + 63) // 64)
+    pred = synth.random_predictors(n_ctu, seed=3, max_pel=sr) if use_pred else None
+    lq = oracle_lib.oracle().hmo_lambda_q16(57.9)
+    engine.set_lambda(57.9)
+    pc, pr = engine.plane(w, h), engine.plane(w, h)
+    pc.upload_pel(cur, (synth.MARGIN, synth.MARGIN))
+    pr.upload_pel(ref, (synth.MARGIN, synth.MARGIN))
+    mv, sad = engine.search_frame(pc, pr, sr, pred, fen=fen)
+    ox, oy, osad = oracle_lib.search_frame(cur, ref, (synth.MARGIN, synth.MARGIN), w, h, sr, pred, lq, fen, 8, n_threads=8)
+    pc.close(); pr.close()
+    assert np.array_equal(mv[:, :, 0], ox) and np.array_equal(mv[:, :, 1], oy)
+    assert np.array_equal(sad, osad)
+
+
+def test_frame_ctu_subrange_and_u8_upload(engine, oracle_lib):
+    from hmme import synth
+    w, h, sr = 256, 128, 8
+    cur, ref, _ = synth.make_pair(w, h, seed=9, max_mv=6, region=64)
+    m = synth.MARGIN
+    pc, pr = engine.plane(w, h), engine.plane(w, h)
+    pc.upload_u8(cur[m:m + h, m:m + w].astype(np.uint8))
+    pr.upload_u8(ref[m:m + h, m:m + w].astype(np.uint8))
+    engine.set_lambda(57.9)
+    full_mv, full_sad = engine.search_frame(pc, pr, sr)
+    part_mv, part_sad = engine.search_frame(pc, pr, sr, ctu_first=3, ctu_count=4)
+    pc.close(); pr.close()
+    assert np.array_equal(part_mv, full_mv[3:7]) and np.array_equal(part_sad, full_sad[3:7])
+    lq = oracle_lib.oracle().hmo_lambda_q16(57.9)
+    ox, oy, osad = oracle_lib.search_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, 8, n_threads=4)
+    assert np.array_equal(full_mv[:, :, 0], ox) and np.array_equal(full_sad, osad)
+
+
+def test_error_behaviour(engine):
+    """errors come back as status codes with a message; nothing falls back to the CPU"""
+    from hmme import api
+    cur = np.zeros((64, 64), np.int16)
+    ref = np.zeros((100, 100), np.int16)
+    engine.set_lambda(1.0)
+    bad = api.SearchParams(-70, -8, 70, 8, 0, 0, 1, 8)           # window wider than sr_max
+    with pytest.raises(api.HmmeError, match="window"):
+        engine.search_ctu(cur, (0, 0), ref, (18, 18), bad)
+    p10 = api.SearchParams(-8, -8, 8, 8, 0, 0, 1, 10)
+    with pytest.raises(api.HmmeError, match="bit depth"):
+        engine.search_ctu(cur, (0, 0), ref, (18, 18), p10)
+    cur2 = cur.copy(); cur2[5, 5] = 300                             # bi-pred style origin outside [0,255]
+    p = api.SearchParams(-8, -8, 8, 8, 0, 0, 1, 8)
+    with pytest.raises(api.HmmeError, match="outside"):
+        engine.search_ctu(cur2, (0, 0), ref, (18, 18), p)
+    pl = engine.plane(64, 64)
+    with pytest.raises(api.HmmeError, match="outside"):
+        pl.upload_pel(np.full((64, 64), 700, np.int16), (0, 0))
+    pl.close()
+    with pytest.raises(api.HmmeError):
+        api.Engine(0, 4096)
+
+
+def test_1080p_planted_motion_and_oracle_spot_check(engine, oracle_lib):
+    """BASELINE config 2 shape (1920x1080, SR 64, FEN 1): size-independent properties over the whole
+    frame + bit-exact oracle comparison on a CTU sample"""
+    from hmme import synth
+    w, h, sr = 1920, 1080, 64
+    cur, ref, true_mv = synth.make_pair(w, h, seed=1234, max_mv=12, region=128, noise_sigma=0.0)
+    m = synth.MARGIN
+    engine.set_lambda(57.9)
+    pc, pr = engine.plane(w, h), engine.plane(w, h)
+    pc.upload_pel(cur, (m, m)); pr.upload_pel(ref, (m, m))
+    mv, sad = engine.search_frame(pc, pr, sr)
+    pc.close(); pr.close()
+    ctus_x = 30
+    assert mv.shape == (510, 593, 2)
+    # (1) noise-free translated texture: interior CTUs that lie inside one 128x128 region find it exactly
+    hits = 0
+    for cy in range(0, 16, 2):
+        for cx in range(0, 30, 2):
+            # CTU (cx,cy) and its right/bottom neighbour share a region; take the region-aligned one
+            ctu = cy * ctus_x + cx
+            dx, dy = true_mv[cy // 2, cx // 2]
+            if cx in (0, 28) or cy in (0, 14):
+                continue
+            assert tuple(mv[ctu, 592]) == (dx, dy) and sad[ctu, 592] == 0, (cx, cy)
+            hits += 1
+    assert hits > 50
+    # (2) hierarchy consistency: a PU's best cost can never beat the sum of ... (SAD additivity at the
+    # winning MV of the 64x64 PU): SAD(64x64 @ mv592) == sum of the four 32x32 SADs at that MV >= sum of
+    # the 32x32 minima's SADs is NOT guaranteed with MV costs, so only check range sanity here
+    assert sad.max() < 1044481
+    # (3) oracle spot check on 12 CTUs incl. partial bottom-row CTUs and picture corners
+    lq = oracle_lib.oracle().hmo_lambda_q16(57.9)
+    for ctu in (0, 29, 31, 200, 255, 340, 479, 480, 495, 509, 123, 77):
+        ox, oy, osad = oracle_lib.search_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, 8, ctu_first=ctu, ctu_count=1)
+        assert np.array_equal(mv[ctu, :, 0], ox[0]) and np.array_equal(mv[ctu, :, 1], oy[0]), ctu
+        assert np.array_equal(sad[ctu], osad[0]), ctu

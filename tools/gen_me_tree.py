@@ -1,0 +1,486 @@
+#!/usr/bin/env python3
+"""Generator for the per-lane reduction tree of the MI355X full-search ME kernel.
+
+One *lane-iteration* of the kernel evaluates FOUR horizontally adjacent candidate MVs
+(x, x+1, x+2, x+3 at one y) against the whole 64x64 CTU:
+
+  leaves   256 4x4 blocks x 4 rows of v_qsad_pk_u16_u8 (4 candidates per instruction, packed
+           u16 accumulators); per block an "even rows" sum E (rows 0,2 -- what HM's FEN
+           sub-sampled SAD reads) and an "all rows" sum A (E chained through rows 1,3)
+  tree     packed-u16 sums (v_pk_add_u16) up to 16x16, then 32-bit *keys*
+           K = sad * MULT + C_j,  C_j = (mvcost_j << 10) | candidate index   (one v_mad_u32_u16)
+           Keys are linear:  K(a U b) = K(a) + K(b) - C  (v_add3_u32),  K(a \\ b) = K(a) - K(b) + C,
+           so everything above 16x16 is one VALU op per candidate and slot.
+  arg-min  per slot: min over the lane's 4 candidates (v_min3_u32 + v_min_u32), then a
+           64-register -> 1-register *butterfly transpose-reduce* across the wave
+           (v_permlane32_swap, v_permlane16_swap, DPP row_ror:8 / row_half_mirror / quad_perm):
+           afterwards lane l of group register g holds the wave-wide minimum of slot
+           SLOT_OF[g][l]; ten running-minimum registers persist across iterations.
+
+The slot numbering is the reference's (TComDataCU::getIndexBlock, TComDataCU.cpp:3379-3391 and
+:4676-6461; same offsets in cl/sad.cl:200-365); FEN semantics are TEncSearch.cpp:3853-3859 +
+TComRdCost.cpp:509-521 (rows > 8 -> every 2nd row, sum << 1).
+
+The same op list is (a) emitted as straight-line HIP C++ (csrc/me_tree_fen{0,1}.inc) and
+(b) interpreted with numpy (`simulate`) so the tree can be checked against the oracle on
+the CPU (tests/test_tree_sim.py) before it ever runs on a GPU.
+
+usage: python tools/gen_me_tree.py            (writes the .inc files)
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT_DIR = os.path.join(ROOT, "hm-opencl_amd", "csrc")
+
+IDX_BITS = 10          # key = cost << 10 | iter(2) | lane(6) | j(2)
+MULT_A = 1 << IDX_BITS
+N_GROUPS = 10          # ceil(593 / 64)
+PDW = 49               # LDS window pitch in dwords (odd: conflict-free for every lane shape)
+
+# slot bases (SURVEY 8a closed form; verified against the reference table in tests)
+BASE_2NxN = {8: 0, 16: 448, 32: 560, 64: 588}
+BASE_Nx2N = {8: 128, 16: 480, 32: 568, 64: 590}
+BASE_AMP = {16: 256, 32: 512, 64: 576}
+BASE_2Nx2N = {8: 384, 16: 544, 32: 584, 64: 592}
+
+
+def slot_2NxN(s, cx, cy, p):
+    n = 64 // s
+    return BASE_2NxN[s] + cy * 2 * n + p * n + cx
+
+
+def slot_Nx2N(s, cx, cy, p):
+    n = 64 // s
+    return BASE_Nx2N[s] + cy * 2 * n + 2 * cx + p
+
+
+def slot_AMP(s, cx, cy, k):
+    n = 64 // s
+    return BASE_AMP[s] + k * n * n + cy * n + cx
+
+
+def slot_2Nx2N(s, cx, cy):
+    n = 64 // s
+    return BASE_2Nx2N[s] + cy * n + cx
+
+
+class Tree:
+    """builds the op list for one lane-iteration"""
+
+    def __init__(self, fen):
+        self.fen = fen
+        self.ops = []
+        self.n = 0
+        self.emitted = []          # slot ids in emission order (None = padding)
+        self.pending = {}          # butterfly level -> var
+        self.group = 0
+        self.loaded = {}
+        self.cu_loads = []
+
+    def new(self, prefix="v"):
+        self.n += 1
+        return f"{prefix}{self.n}"
+
+    # ---- leaves -------------------------------------------------------------------------
+    def lds(self, row, k):
+        key = (row, k)
+        if key not in self.loaded:
+            v = self.new("d")
+            self.ops.append(("LDS", v, row, k))
+            self.loaded[key] = v
+        return self.loaded[key]
+
+    def curld(self, row, cx8):
+        """the 8 current-block bytes of `row` that belong to 8x8 CU column cx8 (wave-uniform LDS read)"""
+        key = ("cur", row, cx8)
+        if key not in self.loaded:
+            v = self.new("w")
+            self.ops.append(("CURLD", v, row, cx8))
+            self.loaded[key] = v
+        return self.loaded[key]
+
+    def block(self, bx, by):
+        """-> (E, A) packed-u16 sums of the 4x4 block at block coords (bx, by)"""
+        def q(row, acc):
+            v = self.new("q")
+            self.ops.append(("QSAD", v, self.lds(row, bx), self.lds(row, bx + 1), self.curld(row, bx >> 1), bx & 1, row, bx, acc))
+            return v
+        r0 = by * 4
+        if self.fen:
+            e = q(r0 + 2, q(r0, None))
+            a = q(r0 + 3, q(r0 + 1, e))
+            return e, a
+        a = q(r0 + 3, q(r0 + 2, q(r0 + 1, q(r0, None))))
+        return a, a
+
+    # ---- packed sums / keys ---------------------------------------------------------------
+    def pkadd(self, a, b):
+        v = self.new("p")
+        self.ops.append(("PKADD", v, a, b))
+        return v
+
+    def pksub(self, a, b):
+        v = self.new("p")
+        self.ops.append(("PKSUB", v, a, b))
+        return v
+
+    def keys(self, p, fam):
+        v = self.new("k")
+        self.ops.append(("KEYS", v, p, fam))
+        return v
+
+    def lin(self, a, b):
+        v = self.new("k")
+        self.ops.append(("LIN", v, a, b))
+        return v
+
+    def sub(self, a, b):
+        v = self.new("k")
+        self.ops.append(("SUB", v, a, b))
+        return v
+
+    # ---- arg-min ----------------------------------------------------------------------------
+    def emit(self, slot, k):
+        r = self.new("r")
+        self.ops.append(("MIN4", r, k))
+        self._push(slot, r)
+
+    def _push(self, slot, r):
+        self.emitted.append(slot)
+        level = 0
+        while level in self.pending:
+            a = self.pending.pop(level)
+            if a is None and r is None:
+                m = None
+            else:
+                m = self.new("m")
+                self.ops.append(("MERGE", level, m, a, r))
+            r = m
+            level += 1
+            if level == 6:
+                if r is not None:
+                    self.ops.append(("ACC", self.group, r))
+                self.group += 1
+                return
+        self.pending[level] = r
+
+    def flush(self):
+        while len(self.emitted) % 64:
+            self._push(None, None)
+        assert not self.pending and self.group == N_GROUPS
+
+    # ---- the tree -------------------------------------------------------------------------------
+    def build(self):
+        U = "E" if self.fen else "A"   # family used by PUs taller than 8 rows
+        quads = []
+        for qy in range(2):
+            for qx in range(2):
+                regions = []
+                for ry in range(2):
+                    for rx in range(2):
+                        cus = []
+                        for cy in range(2):
+                            for cx in range(2):
+                                start = len(self.ops)
+                                cus.append(self.level0(qx * 4 + rx * 2 + cx, qy * 4 + ry * 2 + cy, cx, cy))
+                                new = self.ops[start:]
+                                self.cu_loads.append([o for o in new if o[0] in ("LDS", "CURLD")])
+                                self.ops[start:] = [("LOADS_FOR", len(self.cu_loads))] + \
+                                    [o for o in new if o[0] not in ("LDS", "CURLD")]
+                        regions.append(self.level1(qx * 2 + rx, qy * 2 + ry, rx, ry, cus, U))
+                quads.append(self.level2(qx, qy, regions))
+        self.level3(quads)
+        self.flush()
+        # software prefetch: the loads of CU n+1 are issued at the top of CU n's arithmetic
+        ops = list(self.cu_loads[0])
+        for o in self.ops:
+            if o[0] == "LOADS_FOR":
+                if o[1] < len(self.cu_loads):
+                    ops.extend(self.cu_loads[o[1]])
+            else:
+                ops.append(o)
+        self.ops = ops
+        assert sorted(s for s in self.emitted if s is not None) == list(range(593))
+        return self
+
+    def level0(self, cx8, cy8, cx, cy):
+        """8x8 CU at CU coords (cx8, cy8); (cx, cy) = position inside its 16x16 region"""
+        self.loaded = {}   # window dwords are re-read per CU: short live ranges beat 30% fewer LDS reads
+        (e0, a0), (e1, a1) = self.block(2 * cx8, 2 * cy8), self.block(2 * cx8 + 1, 2 * cy8)
+        (e2, a2), (e3, a3) = self.block(2 * cx8, 2 * cy8 + 1), self.block(2 * cx8 + 1, 2 * cy8 + 1)
+        at, ab = self.pkadd(a0, a1), self.pkadd(a2, a3)
+        al, ar = self.pkadd(a0, a2), self.pkadd(a1, a3)
+        k_at, k_ab = self.keys(at, "A"), self.keys(ab, "A")
+        self.emit(slot_2NxN(8, cx8, cy8, 0), k_at)
+        self.emit(slot_2NxN(8, cx8, cy8, 1), k_ab)
+        self.emit(slot_Nx2N(8, cx8, cy8, 0), self.keys(al, "A"))
+        self.emit(slot_Nx2N(8, cx8, cy8, 1), self.keys(ar, "A"))
+        k_a8 = self.lin(k_at, k_ab)
+        self.emit(slot_2Nx2N(8, cx8, cy8), k_a8)
+        out = {"k_a8": k_a8, "k_at": k_at, "k_ab": k_ab}
+        if self.fen:
+            ut, ub = self.pkadd(e0, e1), self.pkadd(e2, e3)
+            out["ucol"] = self.pkadd(e0, e2) if cx == 0 else self.pkadd(e1, e3)
+        else:
+            ut, ub = at, ab
+            out["ucol"] = al if cx == 0 else ar
+        out["u8"] = self.pkadd(ut, ub)
+        out["urow"] = ut if cy == 0 else ub
+        return out
+
+    def level1(self, rx16, ry16, rx, ry, c, U):
+        """16x16 region at region coords (rx16, ry16); (rx, ry) = position inside its 32x32"""
+        S = 16
+        # all-rows family (h <= 8)
+        k_top = self.lin(c[0]["k_a8"], c[1]["k_a8"])
+        k_bot = self.lin(c[2]["k_a8"], c[3]["k_a8"])
+        self.emit(slot_2NxN(S, rx16, ry16, 0), k_top)
+        self.emit(slot_2NxN(S, rx16, ry16, 1), k_bot)
+        self.emit(slot_AMP(S, rx16, ry16, 0), self.lin(c[0]["k_at"], c[1]["k_at"]))   # 16x4 top
+        self.emit(slot_AMP(S, rx16, ry16, 1), self.lin(c[2]["k_ab"], c[3]["k_ab"]))   # 16x4 bottom
+        # tall family (h > 8): packed sums still fit u16 (<= 16*8*255 even rows / 16*16*255 all rows)
+        left, right = self.pkadd(c[0]["u8"], c[2]["u8"]), self.pkadd(c[1]["u8"], c[3]["u8"])
+        u16 = self.pkadd(left, right)
+        t4, b4 = self.pkadd(c[0]["urow"], c[1]["urow"]), self.pkadd(c[2]["urow"], c[3]["urow"])
+        l4, r4 = self.pkadd(c[0]["ucol"], c[2]["ucol"]), self.pkadd(c[1]["ucol"], c[3]["ucol"])
+        k_left, k_right, k_u16 = self.keys(left, U), self.keys(right, U), self.keys(u16, U)
+        self.emit(slot_Nx2N(S, rx16, ry16, 0), k_left)
+        self.emit(slot_Nx2N(S, rx16, ry16, 1), k_right)
+        self.emit(slot_2Nx2N(S, rx16, ry16), k_u16)
+        self.emit(slot_AMP(S, rx16, ry16, 2), self.keys(self.pksub(u16, b4), U))   # 16x12 top
+        self.emit(slot_AMP(S, rx16, ry16, 3), self.keys(self.pksub(u16, t4), U))   # 16x12 bottom
+        self.emit(slot_AMP(S, rx16, ry16, 4), self.keys(l4, U))                    # 4x16 left
+        self.emit(slot_AMP(S, rx16, ry16, 5), self.keys(r4, U))                    # 4x16 right
+        self.emit(slot_AMP(S, rx16, ry16, 6), self.keys(self.pksub(u16, r4), U))   # 12x16 left
+        self.emit(slot_AMP(S, rx16, ry16, 7), self.keys(self.pksub(u16, l4), U))   # 12x16 right
+        out = {"k_u16": k_u16,
+               "k_ucol": k_left if rx == 0 else k_right,                          # 8x16 strip on the 32x32's edge
+               "k_a16x8": k_top if ry == 0 else k_bot}                            # all-rows 16x8 strip on the edge
+        strip = self.pkadd(c[0]["u8"], c[1]["u8"]) if ry == 0 else self.pkadd(c[2]["u8"], c[3]["u8"])
+        out["k_u16x8"] = self.keys(strip, U)                                        # tall-family 16x8 strip
+        return out
+
+    def level2(self, qx, qy, r):
+        """32x32 CU; every value is a key from here on"""
+        S = 32
+        k_t, k_b = self.lin(r[0]["k_u16"], r[1]["k_u16"]), self.lin(r[2]["k_u16"], r[3]["k_u16"])
+        k_l, k_r = self.lin(r[0]["k_u16"], r[2]["k_u16"]), self.lin(r[1]["k_u16"], r[3]["k_u16"])
+        k_u32 = self.lin(k_t, k_b)
+        self.emit(slot_2NxN(S, qx, qy, 0), k_t)
+        self.emit(slot_2NxN(S, qx, qy, 1), k_b)
+        self.emit(slot_Nx2N(S, qx, qy, 0), k_l)
+        self.emit(slot_Nx2N(S, qx, qy, 1), k_r)
+        self.emit(slot_2Nx2N(S, qx, qy), k_u32)
+        self.emit(slot_AMP(S, qx, qy, 0), self.lin(r[0]["k_a16x8"], r[1]["k_a16x8"]))   # 32x8 top   (all rows)
+        self.emit(slot_AMP(S, qx, qy, 1), self.lin(r[2]["k_a16x8"], r[3]["k_a16x8"]))   # 32x8 bottom
+        k_u32x8t = self.lin(r[0]["k_u16x8"], r[1]["k_u16x8"])
+        k_u32x8b = self.lin(r[2]["k_u16x8"], r[3]["k_u16x8"])
+        k_u8x32l = self.lin(r[0]["k_ucol"], r[2]["k_ucol"])
+        k_u8x32r = self.lin(r[1]["k_ucol"], r[3]["k_ucol"])
+        self.emit(slot_AMP(S, qx, qy, 2), self.sub(k_u32, k_u32x8b))   # 32x24 top
+        self.emit(slot_AMP(S, qx, qy, 3), self.sub(k_u32, k_u32x8t))   # 32x24 bottom
+        self.emit(slot_AMP(S, qx, qy, 4), k_u8x32l)                    # 8x32 left
+        self.emit(slot_AMP(S, qx, qy, 5), k_u8x32r)                    # 8x32 right
+        self.emit(slot_AMP(S, qx, qy, 6), self.sub(k_u32, k_u8x32r))   # 24x32 left
+        self.emit(slot_AMP(S, qx, qy, 7), self.sub(k_u32, k_u8x32l))   # 24x32 right
+        return {"k_u32": k_u32, "k_row": k_t if qy == 0 else k_b, "k_col": k_l if qx == 0 else k_r}
+
+    def level3(self, q):
+        S = 64
+        k_t, k_b = self.lin(q[0]["k_u32"], q[1]["k_u32"]), self.lin(q[2]["k_u32"], q[3]["k_u32"])
+        k_l, k_r = self.lin(q[0]["k_u32"], q[2]["k_u32"]), self.lin(q[1]["k_u32"], q[3]["k_u32"])
+        k_64 = self.lin(k_t, k_b)
+        self.emit(slot_2NxN(S, 0, 0, 0), k_t)
+        self.emit(slot_2NxN(S, 0, 0, 1), k_b)
+        self.emit(slot_Nx2N(S, 0, 0, 0), k_l)
+        self.emit(slot_Nx2N(S, 0, 0, 1), k_r)
+        self.emit(slot_2Nx2N(S, 0, 0), k_64)
+        k_16t, k_16b = self.lin(q[0]["k_row"], q[1]["k_row"]), self.lin(q[2]["k_row"], q[3]["k_row"])
+        k_16l, k_16r = self.lin(q[0]["k_col"], q[2]["k_col"]), self.lin(q[1]["k_col"], q[3]["k_col"])
+        self.emit(slot_AMP(S, 0, 0, 0), k_16t)                   # 64x16 top (h=16: tall family)
+        self.emit(slot_AMP(S, 0, 0, 1), k_16b)                   # 64x16 bottom
+        self.emit(slot_AMP(S, 0, 0, 2), self.sub(k_64, k_16b))   # 64x48 top
+        self.emit(slot_AMP(S, 0, 0, 3), self.sub(k_64, k_16t))   # 64x48 bottom
+        self.emit(slot_AMP(S, 0, 0, 4), k_16l)                   # 16x64 left
+        self.emit(slot_AMP(S, 0, 0, 5), k_16r)                   # 16x64 right
+        self.emit(slot_AMP(S, 0, 0, 6), self.sub(k_64, k_16r))   # 48x64 left
+        self.emit(slot_AMP(S, 0, 0, 7), self.sub(k_64, k_16l))   # 48x64 right
+
+    # ---- slot map ---------------------------------------------------------------------------------
+    def slot_of_lane(self):
+        """[group][lane] -> slot id (or -1): lane l ends up with emission index bitrev6(l)"""
+        t = np.full((N_GROUPS, 64), -1, np.int32)
+        for g in range(N_GROUPS):
+            for lane in range(64):
+                e = int(f"{lane:06b}"[::-1], 2)
+                s = self.emitted[g * 64 + e]
+                t[g, lane] = -1 if s is None else s
+        return t
+
+
+# =====================================================================================================
+# C++ emitter
+# =====================================================================================================
+HEADER = """// GENERATED by tools/gen_me_tree.py -- do not edit.  One lane-iteration of the full-search
+// reduction tree (fen=%d): 256 4x4 leaves -> 593 PU keys -> wave butterfly -> best[0..9].
+// Expects in scope: lpv (per-lane volatile LDS dword pointer at the candidate's window row), curv (volatile
+// LDS copy of the 64x64 current block as uint64[64][8]; volatile = loads stay where the generator put them), c0..c3, nc0..nc3, b0..b9 (running minima), lane role
+// masks rb3, rb2, rb1, rb0, and the ME_* helpers of me_kernel.hip.
+"""
+
+
+def emit_cpp(tree, path):
+    o = [HEADER % tree.fen]
+    max_declared = False
+    for op in tree.ops:
+        t = op[0]
+        if t == "LDS":
+            _, v, row, k = op
+            o.append(f"const uint32_t {v} = lpv[{row * PDW + k}];")
+        elif t == "CURLD":
+            _, v, row, cx8 = op
+            o.append(f"const uint64_t {v} = curv[{row * 8 + cx8}];")
+        elif t == "QSAD":
+            _, v, lo, hi, cw, half, row, bx, acc = op
+            o.append(f"const uint64_t {v} = ME_QSAD({lo}, {hi}, (uint32_t)({cw}{' >> 32' if half else ''}), {acc if acc else '0ull'});")
+        elif t == "PKADD":
+            o.append(f"const uint64_t {op[1]} = me_pkadd({op[2]}, {op[3]});")
+        elif t == "PKSUB":
+            o.append(f"const uint64_t {op[1]} = me_pksub({op[2]}, {op[3]});")
+        elif t == "KEYS":
+            _, v, p, fam = op
+            mult = "mult_e" if fam == "E" else "mult_a"
+            o.append(f"ME_KEYS({v}, {p}, {mult});")
+        elif t == "LIN":
+            o.append(f"ME_LIN({op[1]}, {op[2]}, {op[3]});")
+        elif t == "SUB":
+            o.append(f"ME_SUB({op[1]}, {op[2]}, {op[3]});")
+        elif t == "MIN4":
+            o.append(f"const uint32_t {op[1]} = ME_MIN4({op[2]});")
+        elif t == "MERGE":
+            _, level, m, a, b = op
+            a = a if a is not None else "ME_MAXKEY"
+            b = b if b is not None else "ME_MAXKEY"
+            o.append(f"const uint32_t {m} = me_merge{level}({a}, {b}{'' if level < 2 else f', rb{5 - level}'});")
+        elif t == "ACC":
+            o.append(f"b{op[1]} = min(b{op[1]}, {op[2]});")
+        else:
+            raise ValueError(t)
+    with open(path, "w") as f:
+        f.write("\n".join(o) + "\n")
+
+
+def emit_slotmap(tree, path):
+    t = tree.slot_of_lane()
+    with open(path, "w") as f:
+        f.write("// GENERATED by tools/gen_me_tree.py: slot held by lane l of running-minimum register g\n")
+        f.write("// after the butterfly (-1 = padding).  Same for fen=0 and fen=1.\n")
+        f.write("static __device__ const short ME_SLOT_OF[%d][64] = {\n" % N_GROUPS)
+        for g in range(N_GROUPS):
+            f.write("  {" + ", ".join(str(int(v)) for v in t[g]) + "},\n")
+        f.write("};\n")
+
+
+# =====================================================================================================
+# numpy interpreter (64 lanes at once)
+# =====================================================================================================
+LANES = np.arange(64)
+
+
+def _perm_level(level):
+    """lane permutation and role bit of butterfly level 0..5"""
+    if level == 0:
+        return LANES ^ 32, (LANES >> 5) & 1
+    if level == 1:
+        return LANES ^ 16, (LANES >> 4) & 1
+    if level == 2:
+        return LANES ^ 8, (LANES >> 3) & 1      # row_ror:8
+    if level == 3:
+        return LANES ^ 7, (LANES >> 2) & 1      # row_half_mirror
+    if level == 4:
+        return LANES ^ 2, (LANES >> 1) & 1      # quad_perm [2,3,0,1]
+    return LANES ^ 1, LANES & 1                 # quad_perm [1,0,3,2]
+
+
+def simulate(tree, window, cur, lane_off, c, best):
+    """interpret one lane-iteration.
+    window: (rows, PDW*4) uint8 LDS image; cur: (64,64) uint8; lane_off[l] = byte offset of lane l's
+    (row 0, dword 0) in the flattened window; c: (4, 64) uint32 per-candidate constants;
+    best: (N_GROUPS, 64) uint32, updated in place."""
+    mult = {"A": np.uint32(MULT_A), "E": np.uint32(2 * MULT_A)}
+    flat = window.reshape(-1)
+    pad = np.zeros(8, np.uint8)
+    flat = np.concatenate([flat, pad])
+    val = {}
+    MAXK = np.full(64, 0xFFFFFFFF, np.uint32)
+
+    def bytes_at(row, k):
+        idx = lane_off + (row * PDW + k) * 4
+        return np.stack([flat[idx + i] for i in range(4)], axis=1).astype(np.int32)   # (64, 4)
+
+    for op in tree.ops:
+        t = op[0]
+        if t == "LDS":
+            val[op[1]] = bytes_at(op[2], op[3])
+        elif t == "CURLD":
+            pass
+        elif t == "QSAD":
+            _, v, lo, hi, cw, half, row, bx, acc = op
+            src = np.concatenate([val[lo], val[hi]], axis=1)                           # (64, 8) bytes
+            cb = cur[row, bx * 4:bx * 4 + 4].astype(np.int32)
+            res = np.zeros((64, 4), np.uint32)
+            for j in range(4):
+                res[:, j] = np.abs(src[:, j:j + 4] - cb[None, :]).sum(axis=1)
+            if acc:
+                res = (res + val[acc]) & 0xFFFF
+            val[v] = res                                                               # (64, 4) u16 values
+        elif t == "PKADD":
+            val[op[1]] = (val[op[2]] + val[op[3]]) & 0xFFFF
+        elif t == "PKSUB":
+            val[op[1]] = (val[op[2]] - val[op[3]]) & 0xFFFF
+        elif t == "KEYS":
+            val[op[1]] = (val[op[2]].astype(np.uint32) * mult[op[3]] + c.T).astype(np.uint32)
+        elif t == "LIN":
+            val[op[1]] = (val[op[2]] + val[op[3]] - c.T).astype(np.uint32)
+        elif t == "SUB":
+            val[op[1]] = (val[op[2]] - val[op[3]] + c.T).astype(np.uint32)
+        elif t == "MIN4":
+            val[op[1]] = val[op[2]].min(axis=1).astype(np.uint32)
+        elif t == "MERGE":
+            _, level, m, a, b = op
+            A = val[a] if a is not None else MAXK
+            B = val[b] if b is not None else MAXK
+            perm, role = _perm_level(level)
+            keep = np.where(role == 1, B, A)
+            give = np.where(role == 1, A, B)
+            val[m] = np.minimum(keep, give[perm])
+        elif t == "ACC":
+            best[op[1]] = np.minimum(best[op[1]], val[op[2]])
+    return best
+
+
+def main():
+    for fen in (0, 1):
+        tree = Tree(fen).build()
+        emit_cpp(tree, os.path.join(OUT_DIR, f"me_tree_fen{fen}.inc"))
+        counts = {}
+        for op in tree.ops:
+            counts[op[0]] = counts.get(op[0], 0) + 1
+        valu = (counts.get("PKADD", 0) + counts.get("PKSUB", 0)) * 2 + (counts.get("KEYS", 0) + counts.get("LIN", 0)) * 4 \
+            + counts.get("SUB", 0) * 4 + counts.get("MIN4", 0) * 2 + counts.get("ACC", 0)
+        merges = [sum(1 for op in tree.ops if op[0] == "MERGE" and op[1] == lv) for lv in range(6)]
+        valu += 2 * (merges[0] + merges[1]) + 4 * sum(merges[2:])
+        print(f"fen={fen}: {len(tree.ops)} IR ops {counts}; merges/level {merges}; ~{valu} full-rate VALU + "
+              f"{counts['QSAD']} qsad per lane-iteration (4 candidates)")
+        if fen == 1:
+            emit_slotmap(tree, os.path.join(OUT_DIR, "me_slotmap.inc"))
+        else:
+            ref_map = tree.slot_of_lane()
+    assert np.array_equal(ref_map, Tree(1).build().slot_of_lane()), "slot map must not depend on fen"
+
+
+if __name__ == "__main__":
+    sys.exit(main())
