@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hmme engine (BASELINE.json): integer full-search motion
+estimation of a 3840x2160 8-bit frame against one reference picture, SearchRange 64, CTU 64,
+FEN 1 (encoder_lowdelay_P_main.cfg), all 593 PU shapes per CTU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 2160p|1080p]
+
+A *step* = one whole-picture search (2040 CTUs at 2160p) on every rank; ranks hold different
+frames of the sequence (frame sharding, no data-path collective) and the per-step results are
+gathered with RCCL (torch.distributed "nccl") when N > 1.  Inputs are resident in HBM before the
+timed region; the timed region is K steps between barrier + synchronize, max over ranks.
+Rank 0 prints ONE JSON line: metric GSAD/s (4x4-block SAD evaluations per second, whole job),
+plus `roofline` (algorithmic bytes / measured kernel time against 8 TB/s) and `cpu_baseline`
+(the CPU oracle's exhaustive search and HM's xTZSearch restatement timed on this node's cores).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "hm-opencl_amd"))
+
+SIZES = {"2160p": (3840, 2160), "1080p": (1920, 1080)}
+ALGO_BYTES_PER_CTU = 64 * 64 + 192 * 192 + 593 * 8   # CTU + (64+2SR)^2 window + results, u8, SR=64
+HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+LAMBDA = 57.9                                          # fixed, recorded
+
+
+def work_4x4_sads(api, w, h, sr):
+    """4x4-block SAD evaluations of one picture search: sum over CTUs of (in-picture 4x4 blocks) x
+    (candidates of the CTU's clipped window)"""
+    total = 0
+    for cy in range(0, h, 64):
+        for cx in range(0, w, 64):
+            ltx, lty, rbx, rby = api.set_search_range(0, 0, sr, cx, cy, w, h)
+            blocks = (min(64, w - cx) // 4) * (min(64, h - cy) // 4)
+            total += blocks * (rbx - ltx + 1) * (rby - lty + 1)
+    return total
+
+
+def usable_cores():
+    """host threads this process may actually run on: affinity mask capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
+def cpu_baseline(cur, ref, w, h, sr, lq, budget_s=14.0):
+    """oracle legs on this node's host cores, bounded sample of the same workload"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    from hmme import synth
+    cores = min(usable_cores(), 64)
+    m = synth.MARGIN
+    ctus_x = (w + 63) // 64
+    first = ctus_x * 3            # start on the 4th CTU row: full interior CTUs
+    # exhaustive search (same arithmetic and same work as the GPU kernel)
+    n = cores
+    t0 = time.time(); O.search_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, 8, first, n, cores); dt = time.time() - t0
+    n_full = max(cores, min(ctus_x * 16, int(n * (budget_s * 0.6) / max(dt, 1e-3)) // cores * cores))
+    t0 = time.time(); O.search_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, 8, first, n_full, cores); dt_full = time.time() - t0
+    sads_full = n_full * 256 * (2 * sr + 1) ** 2
+    # HM's default fast search (xTZSearch) over all 593 PU shapes of each CTU
+    n_tz = cores * 4
+    t0 = time.time(); O.tz_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, 8, first, n_tz, cores, True); dt = time.time() - t0
+    n_tz = max(cores, min(ctus_x * 28, int(n_tz * (budget_s * 0.3) / max(dt, 1e-3)) // cores * cores))
+    t0 = time.time(); probes, s4 = O.tz_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, 8, first, n_tz, cores, True); dt_tz = time.time() - t0
+    return {
+        "value": round(sads_full / dt_full / 1e9, 4), "unit": "GSAD/s", "cores": cores, "kind": "port",
+        "sample": f"oracle exhaustive search (xPatternSearch restatement, all 593 PUs) of {n_full} interior CTUs of the "
+                  f"same frame pair, {cores} threads, {dt_full:.2f} s",
+        "ctus_per_s": round(n_full / dt_full, 2),
+        "tz": {"ctus_per_s": round(n_tz / dt_tz, 1), "gsad_equiv_per_s": round(s4 / dt_tz / 1e9, 4),
+               "probes_per_s": round(probes / dt_tz, 0), "cores": cores,
+               "sample": f"oracle xTZSearch restatement, all 593 PUs of {n_tz} CTUs, {dt_tz:.2f} s"},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", default="2160p", choices=sorted(SIZES))
+    ap.add_argument("--search-range", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from hmme import api, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    w, h = SIZES[args.size]
+    sr = args.search_range
+    eng = api.Engine(local_rank, 64)
+    eng.set_lambda(LAMBDA)
+    lq = eng.lambda_q16
+    # frame shard: rank r searches frame pair r of the synthetic sequence (different seeds)
+    cur, ref, _ = synth.make_pair(w, h, seed=1234 + rank, bit_depth=8)
+    pc, pr = eng.plane(w, h), eng.plane(w, h)
+    pc.upload_pel(cur, (synth.MARGIN, synth.MARGIN))
+    pr.upload_pel(ref, (synth.MARGIN, synth.MARGIN))
+    n_ctu = api.load().hmme_num_ctus(w, h)
+    fp = api.FrameParams(sr, 1, 8, 0, n_ctu)
+    d_mv = torch.zeros((n_ctu, api.NUM_PARTS, 2), dtype=torch.int16, device=dev)
+    d_sad = torch.zeros((n_ctu, api.NUM_PARTS), dtype=torch.int32, device=dev)
+    if world > 1:
+        g_mv = torch.zeros((world,) + tuple(d_mv.shape), dtype=torch.int16, device=dev)
+        g_sad = torch.zeros((world,) + tuple(d_sad.shape), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(ev=None):
+        if ev:
+            ev[0].record()
+        eng.search_frame_device(pc, pr, fp, None, d_mv.data_ptr(), d_sad.data_ptr(), stream)
+        if ev:
+            ev[1].record()
+        if world > 1:   # the one exchange step of the path: results to every rank over RCCL/xGMI
+            dist.all_gather_into_tensor(g_mv, d_mv)
+            dist.all_gather_into_tensor(g_sad, d_sad)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))   # HIP events on the launch stream
+
+    if rank == 0:
+        sads = work_4x4_sads(api, w, h, sr)
+        total_sads = sads * world * args.steps
+        algo_bytes = ALGO_BYTES_PER_CTU * n_ctu
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        # sanity: results of the last step vs a freshly computed host call on a few CTUs
+        out = {
+            "metric": "GSAD/s", "value": round(total_sads / elapsed / 1e9, 2), "unit": "GSAD/s (4x4-block SAD evaluations)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "ctus_per_s": round(n_ctu * world * args.steps / elapsed, 1),
+            "config": {"workload": f"{w}x{h} 8-bit luma, lowdelay_P_main (FEN=1), SearchRange={sr}, CTU=64, exhaustive "
+                                   f"integer search of all 593 PU shapes, 1 reference picture, {n_ctu} CTUs per frame",
+                       "frames_per_step": world, "parallelism": f"frame-shard x{world}", "lambda": LAMBDA,
+                       "sads_4x4_per_frame": sads},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel": "me_search_kernel<1>", "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "note": "kernel is VALU-bound (1664 abs-diff ops per unique input byte, SURVEY 8d); "
+                                 "see DESIGN.md for the VALU-issue roofline"},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cur, ref, w, h, sr, lq)
+        print(json.dumps(out), flush=True)
+    pc.close(); pr.close(); eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -560,3 +560,77 @@ int hmo_search_frame(const hmo_pel* cur, int cur_stride, const hmo_pel* ref, int
   for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
   return ctu_count;
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* CPU baseline: HM's default fast search (xTZSearch) over every PU shape of every CTU    */
+/* ------------------------------------------------------------------------------------ */
+typedef struct tz_job {
+  const hmo_pel* cur; int cur_stride; const hmo_pel* ref; int ref_stride;
+  int pic_w, pic_h, sr; const int16_t* pred_q; uint32_t lambda_q16; int fen, bit_depth;
+  int ctu_first, ctu_count, tid, n_threads, all_slots;
+  int32_t *out_x, *out_y; uint32_t* out_sad;
+  long probes; double sad4x4;
+} tz_job;
+
+static void* tz_worker(void* arg) {
+  tz_job* j = (tz_job*)arg;
+  init_slots();
+  const int ctus_x = (j->pic_w + HMO_CTU - 1) / HMO_CTU;
+  for (int i = j->tid; i < j->ctu_count; i += j->n_threads) {
+    const int ctu = j->ctu_first + i;
+    const int cu_x = (ctu % ctus_x) * HMO_CTU, cu_y = (ctu / ctus_x) * HMO_CTU;
+    hmo_params p;
+    p.pred_x = j->pred_q ? j->pred_q[2 * ctu] : 0;
+    p.pred_y = j->pred_q ? j->pred_q[2 * ctu + 1] : 0;
+    p.lambda_q16 = j->lambda_q16; p.fen = j->fen; p.bit_depth = j->bit_depth;
+    hmo_set_search_range(p.pred_x, p.pred_y, j->sr, cu_x, cu_y, j->pic_w, j->pic_h, HMO_CTU,
+                         &p.lt_x, &p.lt_y, &p.rb_x, &p.rb_y);
+    hmo_tz_ctx tz = {j->sr, cu_x, cu_y, j->pic_w, j->pic_h, HMO_CTU};
+    int imv[2] = {0, 0};
+    /* slot 592 (64x64 2Nx2N, no integer-MV predictor) first, then the other shapes seeded with its
+     * result like m_integerMv2Nx2N (TEncSearch.cpp:3780-3789) */
+    for (int n = 0; n < (j->all_slots ? HMO_NUM_CTU_PARTS : 1); ++n) {
+      const int s = n == 0 ? 592 : n - 1;
+      const hmo_rect r = g_slot_rect[s];
+      const ptrdiff_t co = (ptrdiff_t)(cu_y + r.y) * j->cur_stride + cu_x + r.x;
+      const ptrdiff_t ro = (ptrdiff_t)(cu_y + r.y) * j->ref_stride + cu_x + r.x;
+      int mx, my; uint32_t sad;
+      const long pr = hmo_tz_search(j->cur + co, j->cur_stride, r.w, r.h, j->ref + ro, j->ref_stride, &p, &tz,
+                                    n == 0 ? NULL : imv, p.pred_x, p.pred_y, &mx, &my, &sad);
+      if (n == 0) { imv[0] = mx; imv[1] = my; }
+      j->probes += pr;
+      j->sad4x4 += (double)pr * (r.w * r.h / 16.0) * ((j->fen && r.h > 8) ? 0.5 : 1.0);
+      if (j->out_x) {
+        j->out_x[(size_t)i * HMO_NUM_CTU_PARTS + s] = mx;
+        j->out_y[(size_t)i * HMO_NUM_CTU_PARTS + s] = my;
+        j->out_sad[(size_t)i * HMO_NUM_CTU_PARTS + s] = sad;
+      }
+    }
+  }
+  return NULL;
+}
+
+int hmo_tz_frame(const hmo_pel* cur, int cur_stride, const hmo_pel* ref, int ref_stride, int pic_w, int pic_h,
+                 int sr, const int16_t* pred_q, uint32_t lambda_q16, int fen, int bit_depth, int ctu_first,
+                 int ctu_count, int n_threads, int all_slots, int32_t* out_x, int32_t* out_y, uint32_t* out_sad,
+                 long* probes, double* sad4x4) {
+  const int ctus_x = (pic_w + HMO_CTU - 1) / HMO_CTU, ctus_y = (pic_h + HMO_CTU - 1) / HMO_CTU;
+  if (ctu_count < 0) ctu_count = ctus_x * ctus_y - ctu_first;
+  if (n_threads <= 0) n_threads = 1;
+  if (n_threads > 256) n_threads = 256;
+  static tz_job jobs[256];
+  pthread_t th[256];
+  for (int t = 0; t < n_threads; ++t) {
+    tz_job j = {cur, cur_stride, ref, ref_stride, pic_w, pic_h, sr, pred_q, lambda_q16, fen, bit_depth,
+                ctu_first, ctu_count, t, n_threads, all_slots, out_x, out_y, out_sad, 0, 0.0};
+    jobs[t] = j;
+  }
+  if (n_threads == 1) tz_worker(&jobs[0]);
+  else {
+    for (int t = 0; t < n_threads; ++t) pthread_create(&th[t], NULL, tz_worker, &jobs[t]);
+    for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
+  }
+  *probes = 0; *sad4x4 = 0.0;
+  for (int t = 0; t < n_threads; ++t) { *probes += jobs[t].probes; *sad4x4 += jobs[t].sad4x4; }
+  return ctu_count;
+}

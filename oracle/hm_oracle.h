@@ -107,6 +107,15 @@ int hmo_search_frame(const hmo_pel* cur, int cur_stride, const hmo_pel* ref, int
                      uint32_t lambda_q16, int fen, int bit_depth, int ctu_first, int ctu_count,
                      int n_threads, int32_t* out_x, int32_t* out_y, uint32_t* out_sad);
 
+/* CPU baseline leg of bench.py: xTZSearch for the 64x64 PU (all_slots=0) or for all 593 PU
+ * rectangles (all_slots=1) of every CTU in [ctu_first, ctu_first+ctu_count), threaded over CTUs.
+ * probes = SAD evaluations; sad4x4 = the same work in 4x4-block-SAD equivalents (w*h/16 per probe,
+ * halved where FEN sub-sampling applies).  out_* may be NULL. */
+int hmo_tz_frame(const hmo_pel* cur, int cur_stride, const hmo_pel* ref, int ref_stride, int pic_w, int pic_h,
+                 int sr, const int16_t* pred_q, uint32_t lambda_q16, int fen, int bit_depth, int ctu_first,
+                 int ctu_count, int n_threads, int all_slots, int32_t* out_x, int32_t* out_y, uint32_t* out_sad,
+                 long* probes, double* sad4x4);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,11 @@ def oracle():
         L.hmo_search_frame.argtypes = [C.POINTER(C.c_int16), C.c_int, C.POINTER(C.c_int16), C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_int, _i32p, _i32p, _u32p]
+        L.hmo_tz_frame.restype = C.c_int
+        L.hmo_tz_frame.argtypes = [C.POINTER(C.c_int16), C.c_int, C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_long),
+                                   C.POINTER(C.c_double)]
         _oracle = L
     return _oracle
 
@@ -192,3 +197,29 @@ def search_frame(cur, ref_plane, origin, pic_w, pic_h, sr, pred_q, lambda_q16, f
                        pic_w, pic_h, sr, pq, int(lambda_q16), int(fen), int(bit_depth), ctu_first, n,
                        n_threads, ox.reshape(-1), oy.reshape(-1), osad.reshape(-1))
     return ox, oy, osad
+
+
+def tz_frame(cur, ref_plane, origin, pic_w, pic_h, sr, pred_q, lambda_q16, fen, bit_depth, ctu_first=0,
+             ctu_count=-1, n_threads=1, all_slots=True, want_results=False):
+    """oracle xTZSearch over CTUs (CPU baseline).  -> (probes, sad4x4_equiv[, x, y, sad])"""
+    L = oracle()
+    ctus = ((pic_w + 63) // 64) * ((pic_h + 63) // 64)
+    n = ctus - ctu_first if ctu_count < 0 else ctu_count
+    cs, rs = cur.shape[1], ref_plane.shape[1]
+    pq = None
+    if pred_q is not None:
+        pred_q = np.ascontiguousarray(pred_q, dtype=np.int16)
+        pq = pred_q.ctypes.data
+    ox = oy = osad = None
+    px = py = ps = None
+    if want_results:
+        ox = np.zeros((n, NUM_PARTS), np.int32); oy = np.zeros((n, NUM_PARTS), np.int32)
+        osad = np.zeros((n, NUM_PARTS), np.uint32)
+        px, py, ps = ox.ctypes.data, oy.ctypes.data, osad.ctypes.data
+    probes, s4 = C.c_long(), C.c_double()
+    L.hmo_tz_frame(_addr(cur, origin[1] * cs + origin[0]), cs, _addr(ref_plane, origin[1] * rs + origin[0]), rs,
+                   pic_w, pic_h, sr, pq, int(lambda_q16), int(fen), int(bit_depth), ctu_first, n, n_threads,
+                   int(all_slots), px, py, ps, C.byref(probes), C.byref(s4))
+    if want_results:
+        return probes.value, s4.value, ox, oy, osad
+    return probes.value, s4.value

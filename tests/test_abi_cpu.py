@@ -50,3 +50,16 @@ def test_create_without_gpu_fails_loudly():
         assert "no HIP device" in str(e) or "hmme_create failed" in str(e)
     else:
         raise AssertionError("Engine() must not succeed without a GPU")
+
+
+def test_host_module_compiles_inside_the_reference_tree():
+    """drop-in check (compile only, needs /root/reference): TEncOpenCL.{h,cpp} build against HM's own
+    TypeDef.h / TComMv.h in place of the reference's files, with HM's C++98 dialect"""
+    import subprocess
+    import pytest
+    ref = "/root/reference/source/Lib"
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not present")
+    host = os.path.join(ROOT, "hm-opencl_amd", "host")
+    subprocess.run(["g++", "-std=gnu++98", "-fsyntax-only", "-DHMME_IN_HM_TREE", "-DMSYS_LINUX", "-I" + ref,
+                    os.path.join(host, "TEncOpenCL.cpp")], check=True)

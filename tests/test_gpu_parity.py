@@ -197,3 +197,21 @@ def test_1080p_planted_motion_and_oracle_spot_check(engine, oracle_lib):
         ox, oy, osad = oracle_lib.search_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, 8, ctu_first=ctu, ctu_count=1)
         assert np.array_equal(mv[ctu, :, 0], ox[0]) and np.array_equal(mv[ctu, :, 1], oy[0]), ctu
         assert np.array_equal(sad[ctu], osad[0]), ctu
+
+
+def test_cpp_host_module_tencopencl(oracle_lib):
+    """the TEncOpenCL-shaped C++ class, driven like TEncTop / TEncSearch drive the reference's"""
+    import subprocess
+    from conftest import ROOT
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "hm-opencl_amd", "host")], check=True)
+    exe = os.path.join(ROOT, "tests", "cpp", "test_tencopencl")
+    subprocess.run(["g++", "-O2", "-std=c++11", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_tencopencl.cpp"),
+                    "-L" + os.path.join(ROOT, "hm-opencl_amd", "host"), "-lhmme_host",
+                    "-L" + os.path.join(ROOT, "hm-opencl_amd", "csrc"), "-lhmme",
+                    "-L" + os.path.join(ROOT, "oracle"), "-loracle",
+                    "-Wl,-rpath," + os.path.join(ROOT, "hm-opencl_amd", "host"),
+                    "-Wl,-rpath," + os.path.join(ROOT, "hm-opencl_amd", "csrc"),
+                    "-Wl,-rpath," + os.path.join(ROOT, "oracle")], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "PASS" in r.stdout
