@@ -43,6 +43,17 @@ def work_4x4_sads(api, w, h, sr):
     return total
 
 
+def pmc_traffic(size, sr):
+    """HBM bytes per launch of the search kernel from the rocprofv3 --pmc passes of this same command
+    (FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction, + WRITE_SIZE), committed under
+    profiles/ -- counters cannot be read from inside the timed process.  None if no matching profile."""
+    path = os.path.join(ROOT, "profiles", f"latest_pmc_{size}_sr{sr}.json")
+    try:
+        return int(json.load(open(path))["derived"]["hbm_traffic_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def usable_cores():
     """host threads this process may actually run on: affinity mask capped by the cgroup CPU quota"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -105,7 +116,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from hmme import api, synth
+    from hmme import api, shard, synth
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -134,11 +145,9 @@ def main():
     pr.upload_pel(ref, (synth.MARGIN, synth.MARGIN))
     n_ctu = api.load().hmme_num_ctus(w, h)
     fp = api.FrameParams(sr, 1, 8, 0, n_ctu)
-    d_mv = torch.zeros((n_ctu, api.NUM_PARTS, 2), dtype=torch.int16, device=dev)
-    d_sad = torch.zeros((n_ctu, api.NUM_PARTS), dtype=torch.int32, device=dev)
-    if world > 1:
-        g_mv = torch.zeros((world,) + tuple(d_mv.shape), dtype=torch.int16, device=dev)
-        g_sad = torch.zeros((world,) + tuple(d_sad.shape), dtype=torch.int32, device=dev)
+    # one picture pair per rank and step: [pairs_per_rank = 1, n_ctu, 593(, 2)] blocks, see hmme/shard.py
+    d_mv = torch.zeros((1, n_ctu, api.NUM_PARTS, 2), dtype=torch.int16, device=dev)
+    d_sad = torch.zeros((1, n_ctu, api.NUM_PARTS), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step(ev=None):
@@ -147,9 +156,8 @@ def main():
         eng.search_frame_device(pc, pr, fp, None, d_mv.data_ptr(), d_sad.data_ptr(), stream)
         if ev:
             ev[1].record()
-        if world > 1:   # the one exchange step of the path: results to every rank over RCCL/xGMI
-            dist.all_gather_into_tensor(g_mv, d_mv)
-            dist.all_gather_into_tensor(g_sad, d_sad)
+        if world > 1:   # the one exchange step of the path: results of all `world` pairs to every rank (RCCL/xGMI)
+            shard.gather_pair_results(d_mv, d_sad, world)
 
     for _ in range(args.warmup):
         step()
@@ -188,7 +196,7 @@ def main():
                        "frames_per_step": world, "parallelism": f"frame-shard x{world}", "lambda": LAMBDA,
                        "sads_4x4_per_frame": sads},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args.size, sr),
                          "kernel": "me_search_kernel<1>", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "kernel is VALU-bound (1664 abs-diff ops per unique input byte, SURVEY 8d); "

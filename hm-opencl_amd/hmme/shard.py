@@ -1,0 +1,59 @@
+"""Frame sharding across GPUs (one process per GPU, torch.distributed; backend "nccl" = RCCL over
+xGMI on the MI355X node, "gloo" in the CPU tests).
+
+Open-loop motion estimation over a sequence is embarrassingly parallel per (current, reference)
+picture pair: pair p is searched by rank p % world with no exchange during the
+search.  The only collective is the result gather: every rank contributes an equally sized
+[pairs_per_rank, n_ctu, 593] block of (mv, sad) -- 9.7 MB per 2160p pair -- through
+all_gather_into_tensor, and the blocks are re-interleaved into pair order.
+"""
+import torch
+import torch.distributed as dist
+
+
+def pairs_for_rank(n_pairs, rank, world):
+    """indices of the picture pairs rank `rank` searches (round-robin: pair p -> rank p % world)"""
+    return list(range(rank, n_pairs, world))
+
+
+def pairs_per_rank(n_pairs, world):
+    """every rank contributes the same number of blocks to the gather (short ranks pad)"""
+    return (n_pairs + world - 1) // world
+
+
+def gather_pair_results(local_mv, local_sad, n_pairs):
+    """local_mv: [k, n_ctu, 593, 2] int16, local_sad: [k, n_ctu, 593] int32 with k = pairs_per_rank
+    (rows beyond the rank's real pairs are padding).  Returns (mv, sad) in pair order on every rank."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return local_mv[:n_pairs], local_sad[:n_pairs]
+    k = pairs_per_rank(n_pairs, world)
+    assert local_mv.shape[0] == k and local_sad.shape[0] == k
+    # an (mvx, mvy) int16 pair travels as one int32 word (TComMv is 4 bytes; gloo has no int16 collectives)
+    mv_shape = tuple(local_mv.shape)
+    local_mv = local_mv.contiguous().view(torch.int32)
+    # concatenated layout (world * k, ...): accepted by both the RCCL and the gloo implementation
+    g_mv = torch.empty((world * k,) + tuple(local_mv.shape[1:]), dtype=local_mv.dtype, device=local_mv.device)
+    g_sad = torch.empty((world * k,) + tuple(local_sad.shape[1:]), dtype=local_sad.dtype, device=local_sad.device)
+    dist.all_gather_into_tensor(g_mv, local_mv.contiguous())
+    dist.all_gather_into_tensor(g_sad, local_sad.contiguous())
+    g_mv = g_mv.view((world, k) + tuple(local_mv.shape[1:]))
+    g_sad = g_sad.view((world, k) + tuple(local_sad.shape[1:]))
+    # block [r, i] holds pair i * world + r
+    mv = g_mv.transpose(0, 1).reshape((k * world,) + tuple(local_mv.shape[1:])).view(torch.int16)
+    mv = mv.reshape((k * world,) + mv_shape[1:])[:n_pairs]
+    sad = g_sad.transpose(0, 1).reshape((k * world,) + tuple(local_sad.shape[1:]))[:n_pairs]
+    return mv, sad
+
+
+def search_sequence(search_pair, n_pairs, n_ctu, device):
+    """run `search_pair(p, out_mv, out_sad)` (fills device tensors [n_ctu,593,2] / [n_ctu,593]) for the
+    rank's pairs and gather.  `search_pair` is the engine call on GPUs; tests substitute a CPU stand-in."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    k = pairs_per_rank(n_pairs, world)
+    mv = torch.zeros((k, n_ctu, 593, 2), dtype=torch.int16, device=device)
+    sad = torch.zeros((k, n_ctu, 593), dtype=torch.int32, device=device)
+    for i, p in enumerate(pairs_for_rank(n_pairs, rank, world)):
+        search_pair(p, mv[i], sad[i])
+    return gather_pair_results(mv, sad, n_pairs)

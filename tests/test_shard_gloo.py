@@ -1,0 +1,83 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the frame-shard driver (hmme/shard.py).  The GPU
+engine is replaced by the CPU oracle as the per-pair search so the gather/re-interleave logic
+is checked end to end against a single-process run."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+W, H, SR, N_PAIRS = 128, 72, 4, 5
+
+
+def _pair_search(oracle_py, synth):
+    lq = oracle_py.oracle().hmo_lambda_q16(57.9)
+
+    def run(p, out_mv, out_sad):
+        cur, ref, _ = synth.make_pair(W, H, seed=100 + p, max_mv=3, region=64)
+        ox, oy, osad = oracle_py.search_frame(cur, ref, (80, 80), W, H, SR, None, lq, 1, 8)
+        out_mv[:, :, 0] = torch.from_numpy(ox.astype(np.int16))
+        out_mv[:, :, 1] = torch.from_numpy(oy.astype(np.int16))
+        out_sad.copy_(torch.from_numpy(osad.astype(np.int32)))
+    return run
+
+
+def _worker(rank, world, port, q):
+    for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "hm-opencl_amd")):
+        sys.path.insert(0, p)
+    import oracle_py
+    from hmme import shard, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mv, sad = shard.search_sequence(_pair_search(oracle_py, synth), N_PAIRS, 2 * 2, torch.device("cpu"))
+        if rank == 0:
+            q.put((mv.numpy().copy(), sad.numpy().copy()))
+        dist.barrier()
+    except Exception as e:  # surface the failure instead of letting the parent time out
+        if rank == 0:
+            q.put(repr(e))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pairs_round_robin():
+    from hmme import shard
+    assert shard.pairs_for_rank(5, 0, 2) == [0, 2, 4] and shard.pairs_for_rank(5, 1, 2) == [1, 3]
+    assert shard.pairs_per_rank(5, 2) == 3 and shard.pairs_per_rank(64, 8) == 8
+    assert sorted(sum((shard.pairs_for_rank(64, r, 8) for r in range(8)), [])) == list(range(64))
+
+
+def test_two_rank_gloo_matches_single_process(oracle_lib):
+    from hmme import shard, synth
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    assert not isinstance(got, str), got
+    mv2, sad2 = got
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    mv1, sad1 = shard.search_sequence(_pair_search(oracle_lib, synth), N_PAIRS, 4, torch.device("cpu"))
+    assert mv2.shape == (N_PAIRS, 4, 593, 2)
+    assert np.array_equal(mv2, mv1.numpy()) and np.array_equal(sad2, sad1.numpy())
