@@ -28,7 +28,10 @@ constexpr int kWinRowsMax = 192;       // (2*64+1) + 63
 constexpr int kIdxBits = 10;           // key = cost << 10 | iter(2) | lane(6) | j(2)
 constexpr uint32_t kInvCost = 3146751u;  // > any valid cost (<= 1047552 + 65535); + max SAD stays < 2^22
 constexpr int kGroups = 10;
-constexpr int kIterPerTask = 2;        // <= 4 (2 iteration bits in the key)
+#ifndef ME_ITER_PER_TASK
+#define ME_ITER_PER_TASK 2
+#endif
+constexpr int kIterPerTask = ME_ITER_PER_TASK;   // <= 4 (2 iteration bits in the key)
 constexpr int kThreads = 256;
 
 // one CTU search: everything in integer pels except the quarter-pel predictor
@@ -47,18 +50,20 @@ typedef uint16_t u16x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 // LDS reads of the generated tree are volatile: they are issued exactly where the generator put
 // them (one 8x8 CU ahead of their use) instead of being hoisted and spilled by the scheduler
-typedef volatile __attribute__((address_space(3))) uint32_t lds_vu32_t;
+typedef __attribute__((address_space(3))) char lds_char_t;
 typedef volatile __attribute__((address_space(3))) uint64_t lds_vu64_t;
+typedef volatile __attribute__((address_space(3), aligned(4))) uint64_t lds_vu64a4_t;   // -> ds_read2_b32
 
-__device__ __forceinline__ uint64_t me_pkadd(uint64_t a, uint64_t b) {
-  return __builtin_bit_cast(uint64_t, __builtin_bit_cast(u16x4_t, a) + __builtin_bit_cast(u16x4_t, b));
-}
+// packed-u16 x4 sums never carry between halves (every partial SAD here is <= 65 280), so the packed add is
+// a plain 64-bit add (one v_lshl_add_u64, ~4.6 cycles) and the packed subtract two 32-bit subtracts
+// (v_sub_u32, ~2.7 cycles each) instead of two v_pk_*_u16 (~4.3 each)  [profiles/r01_valu_rates2_ubench.txt]
+__device__ __forceinline__ uint64_t me_pkadd(uint64_t a, uint64_t b) { return a + b; }
 __device__ __forceinline__ uint64_t me_pksub(uint64_t a, uint64_t b) {
-  return __builtin_bit_cast(uint64_t, __builtin_bit_cast(u16x4_t, a) - __builtin_bit_cast(u16x4_t, b));
+  return ((uint64_t)((uint32_t)(a >> 32) - (uint32_t)(b >> 32)) << 32) | (uint64_t)((uint32_t)a - (uint32_t)b);
 }
 
 #define ME_MAXKEY 0xFFFFFFFFu
-#define ME_QSAD(lo, hi, cur, acc) __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)(hi) << 32) | (uint64_t)(lo), (cur), (acc))
+#define ME_QSAD(pair, cur, acc) __builtin_amdgcn_qsad_pk_u16_u8((pair), (cur), (acc))
 // key_j = sad_j * mult + c_j : one v_mad_u32_u16 per candidate (op_sel picks the packed half)
 #define ME_KEYS(v, p, mult)                                                                                    \
   uint32_t v##_0, v##_1, v##_2, v##_3;                                                                         \
@@ -84,11 +89,24 @@ __device__ __forceinline__ uint64_t me_pksub(uint64_t a, uint64_t b) {
 
 // butterfly transpose-reduce: merge two slot registers into one; lanes whose role bit is 0 keep
 // slot a (min over the lane pair), lanes whose role bit is 1 keep slot b.
-__device__ __forceinline__ uint32_t me_merge0(uint32_t a, uint32_t b) {   // role = lane bit 5
+// Levels 0/1 (447 of the 588 merges): two DPP mins, the second one bank-masked so that it only
+// overwrites the role-0 lanes.  s_nop 1 = the 2 wait states a DPP read needs after a VALU write of its
+// source (hipcc does not pad hazards inside an asm statement).
+#define ME_MERGE_DPP_MASKED(NAME, CTRL, MASK0)                                                               \
+  __device__ __forceinline__ uint32_t NAME(uint32_t a, uint32_t b) {                                         \
+    uint32_t r;                                                                                              \
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                       \
+        "v_min_u32_dpp %0, %1, %1 " CTRL " row_mask:0xf bank_mask:" MASK0                                    \
+        : "=&v"(r) : "v"(a), "v"(b));                                                                        \
+    return r;                                                                                                \
+  }
+ME_MERGE_DPP_MASKED(me_merge0, "row_ror:8", "0x3")          // role = lane bit 3: lanes 0-7 of a row = banks 0,1
+ME_MERGE_DPP_MASKED(me_merge1, "row_half_mirror", "0x5")    // role = lane bit 2: lanes 0-3, 8-11 = banks 0,2
+__device__ __forceinline__ uint32_t me_merge2(uint32_t a, uint32_t b) {   // role = lane bit 5
   u32x2_t r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
   return min(r.x, r.y);
 }
-__device__ __forceinline__ uint32_t me_merge1(uint32_t a, uint32_t b) {   // role = lane bit 4
+__device__ __forceinline__ uint32_t me_merge3(uint32_t a, uint32_t b) {   // role = lane bit 4
   u32x2_t r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
   return min(r.x, r.y);
 }
@@ -98,8 +116,6 @@ __device__ __forceinline__ uint32_t me_merge_dpp(uint32_t a, uint32_t b, bool ro
   const uint32_t give = role ? a : b;
   return min(keep, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give, DPP_CTRL, 0xf, 0xf, false));
 }
-#define me_merge2(a, b, role) me_merge_dpp<0x128>(a, b, role)   // row_ror:8           role = lane bit 3
-#define me_merge3(a, b, role) me_merge_dpp<0x141>(a, b, role)   // row_half_mirror     role = lane bit 2
 #define me_merge4(a, b, role) me_merge_dpp<0x4E>(a, b, role)    // quad_perm [2,3,0,1] role = lane bit 1
 #define me_merge5(a, b, role) me_merge_dpp<0xB1>(a, b, role)    // quad_perm [1,0,3,2] role = lane bit 0
 
@@ -162,7 +178,7 @@ me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const uint
 
   const uint32_t mult_a = 1u << kIdxBits;
   const uint32_t mult_e = FEN ? (2u << kIdxBits) : (1u << kIdxBits);
-  const bool rb3 = lane & 8, rb2 = lane & 4, rb1 = lane & 2, rb0 = lane & 1;
+  const bool rb1 = lane & 2, rb0 = lane & 1;
 
   while (true) {
     int t = 0;
@@ -206,7 +222,7 @@ me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const uint
       const uint32_t c0 = cc[0], c1 = cc[1], c2 = cc[2], c3 = cc[3];
       const uint32_t nc0 = 0u - c0, nc1 = 0u - c1, nc2 = 0u - c2, nc3 = 0u - c3;
       // lanes outside the window still run (wave-uniform code) on clamped, in-bounds addresses
-      const lds_vu32_t* lpv = (const lds_vu32_t*)(win + min(cy, wy - 1) * kPDW + (min(cx, wx - 1) >> 2));
+      const lds_char_t* lpc = (const lds_char_t*)(win + min(cy, wy - 1) * kPDW + (min(cx, wx - 1) >> 2));
       const lds_vu64_t* curv = (const lds_vu64_t*)curl;
       if constexpr (FEN) {
 #include "me_tree_fen1.inc"

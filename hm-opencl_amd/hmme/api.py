@@ -11,7 +11,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
-LIB_PATH = os.path.join(CSRC, "libhmme.so")
+LIB_PATH = os.environ.get("HMME_LIB", os.path.join(CSRC, "libhmme.so"))   # HMME_LIB: A/B builds of the kernel
 NUM_PARTS = 593
 
 # every symbol include/hmme.h declares (tests check the library exports all of them)

@@ -86,10 +86,17 @@ class Tree:
 
     # ---- leaves -------------------------------------------------------------------------
     def lds(self, row, k):
+        """dwords k, k+1 of window row `row`.  ds_read2_b32 reaches only 255 dwords from its address
+        register, so each 4-row block row of a CU gets its own (opaque) base: 2 v_add per CU."""
         key = (row, k)
         if key not in self.loaded:
+            bkey = ("base", row // 4, self.cu_k0)
+            if bkey not in self.loaded:
+                b = self.new("a")
+                self.ops.append(("BASE", b, (row // 4) * 4, self.cu_k0))
+                self.loaded[bkey] = b
             v = self.new("d")
-            self.ops.append(("LDS", v, row, k))
+            self.ops.append(("LDS", v, row, k, self.loaded[bkey], (row % 4) * PDW + (k - self.cu_k0)))
             self.loaded[key] = v
         return self.loaded[key]
 
@@ -106,7 +113,7 @@ class Tree:
         """-> (E, A) packed-u16 sums of the 4x4 block at block coords (bx, by)"""
         def q(row, acc):
             v = self.new("q")
-            self.ops.append(("QSAD", v, self.lds(row, bx), self.lds(row, bx + 1), self.curld(row, bx >> 1), bx & 1, row, bx, acc))
+            self.ops.append(("QSAD", v, self.lds(row, bx), self.curld(row, bx >> 1), bx & 1, row, bx, acc))
             return v
         r0 = by * 4
         if self.fen:
@@ -187,9 +194,9 @@ class Tree:
                                 start = len(self.ops)
                                 cus.append(self.level0(qx * 4 + rx * 2 + cx, qy * 4 + ry * 2 + cy, cx, cy))
                                 new = self.ops[start:]
-                                self.cu_loads.append([o for o in new if o[0] in ("LDS", "CURLD")])
+                                self.cu_loads.append([o for o in new if o[0] in ("LDS", "CURLD", "BASE")])
                                 self.ops[start:] = [("LOADS_FOR", len(self.cu_loads))] + \
-                                    [o for o in new if o[0] not in ("LDS", "CURLD")]
+                                    [o for o in new if o[0] not in ("LDS", "CURLD", "BASE")]
                         regions.append(self.level1(qx * 2 + rx, qy * 2 + ry, rx, ry, cus, U))
                 quads.append(self.level2(qx, qy, regions))
         self.level3(quads)
@@ -209,6 +216,7 @@ class Tree:
     def level0(self, cx8, cy8, cx, cy):
         """8x8 CU at CU coords (cx8, cy8); (cx, cy) = position inside its 16x16 region"""
         self.loaded = {}   # window dwords are re-read per CU: short live ranges beat 30% fewer LDS reads
+        self.cu_k0 = 2 * cx8
         (e0, a0), (e1, a1) = self.block(2 * cx8, 2 * cy8), self.block(2 * cx8 + 1, 2 * cy8)
         (e2, a2), (e3, a3) = self.block(2 * cx8, 2 * cy8 + 1), self.block(2 * cx8 + 1, 2 * cy8 + 1)
         at, ab = self.pkadd(a0, a1), self.pkadd(a2, a3)
@@ -315,7 +323,7 @@ class Tree:
         t = np.full((N_GROUPS, 64), -1, np.int32)
         for g in range(N_GROUPS):
             for lane in range(64):
-                e = int(f"{lane:06b}"[::-1], 2)
+                e = sum(((lane >> LEVEL_ROLE_BIT[lv]) & 1) << lv for lv in range(6))   # emission index bit lv = role at level lv
                 s = self.emitted[g * 64 + e]
                 t[g, lane] = -1 if s is None else s
         return t
@@ -326,7 +334,7 @@ class Tree:
 # =====================================================================================================
 HEADER = """// GENERATED by tools/gen_me_tree.py -- do not edit.  One lane-iteration of the full-search
 // reduction tree (fen=%d): 256 4x4 leaves -> 593 PU keys -> wave butterfly -> best[0..9].
-// Expects in scope: lpv (per-lane volatile LDS dword pointer at the candidate's window row), curv (volatile
+// Expects in scope: lpc (per-lane LDS byte pointer at the candidate's window row), curv (volatile
 // LDS copy of the 64x64 current block as uint64[64][8]; volatile = loads stay where the generator put them), c0..c3, nc0..nc3, b0..b9 (running minima), lane role
 // masks rb3, rb2, rb1, rb0, and the ME_* helpers of me_kernel.hip.
 """
@@ -337,15 +345,20 @@ def emit_cpp(tree, path):
     max_declared = False
     for op in tree.ops:
         t = op[0]
-        if t == "LDS":
-            _, v, row, k = op
-            o.append(f"const uint32_t {v} = lpv[{row * PDW + k}];")
+        if t == "BASE":
+            _, b, row, k = op
+            o.append(f"const lds_char_t* {b} = lpc + {(row * PDW + k) * 4}; asm volatile(\"\" : \"+v\"({b}));")
+        elif t == "LDS":
+            _, v, row, k, b, off = op
+            # dwords k, k+1 of the window row as ONE 4-byte-aligned 64-bit LDS read (ds_read2_b32): lands in an
+            # even-aligned VGPR pair, which is what v_qsad_pk_u16_u8's 64-bit operand needs -> no v_mov
+            o.append(f"const uint64_t {v} = *(const lds_vu64a4_t*)({b} + {off * 4});")
         elif t == "CURLD":
             _, v, row, cx8 = op
             o.append(f"const uint64_t {v} = curv[{row * 8 + cx8}];")
         elif t == "QSAD":
-            _, v, lo, hi, cw, half, row, bx, acc = op
-            o.append(f"const uint64_t {v} = ME_QSAD({lo}, {hi}, (uint32_t)({cw}{' >> 32' if half else ''}), {acc if acc else '0ull'});")
+            _, v, pair, cw, half, row, bx, acc = op
+            o.append(f"const uint64_t {v} = ME_QSAD({pair}, (uint32_t)({cw}{' >> 32' if half else ''}), {acc if acc else '0ull'});")
         elif t == "PKADD":
             o.append(f"const uint64_t {op[1]} = me_pkadd({op[2]}, {op[3]});")
         elif t == "PKSUB":
@@ -364,7 +377,7 @@ def emit_cpp(tree, path):
             _, level, m, a, b = op
             a = a if a is not None else "ME_MAXKEY"
             b = b if b is not None else "ME_MAXKEY"
-            o.append(f"const uint32_t {m} = me_merge{level}({a}, {b}{'' if level < 2 else f', rb{5 - level}'});")
+            o.append(f"const uint32_t {m} = me_merge{level}({a}, {b}{'' if level < 4 else f', rb{5 - level}'});")
         elif t == "ACC":
             o.append(f"b{op[1]} = min(b{op[1]}, {op[2]});")
         else:
@@ -387,22 +400,22 @@ def emit_slotmap(tree, path):
 # =====================================================================================================
 # numpy interpreter (64 lanes at once)
 # =====================================================================================================
+
+
 LANES = np.arange(64)
+
+# butterfly levels, cheapest mechanism for the most numerous merges (measured on gfx950: masked DPP pair
+# 2 x 4.3 cycles, v_permlane*_swap 8 + v_min 4.3, cndmask pair + DPP min 3 x 4.3):
+#   level 0  row_ror:8 + bank masks        role = lane bit 3      level 3  v_permlane16_swap     role = bit 4
+#   level 1  row_half_mirror + bank masks  role = lane bit 2      level 4  quad_perm [2,3,0,1]   role = bit 1
+#   level 2  v_permlane32_swap             role = lane bit 5      level 5  quad_perm [1,0,3,2]   role = bit 0
+LEVEL_XOR = [8, 7, 32, 16, 2, 1]
+LEVEL_ROLE_BIT = [3, 2, 5, 4, 1, 0]
 
 
 def _perm_level(level):
     """lane permutation and role bit of butterfly level 0..5"""
-    if level == 0:
-        return LANES ^ 32, (LANES >> 5) & 1
-    if level == 1:
-        return LANES ^ 16, (LANES >> 4) & 1
-    if level == 2:
-        return LANES ^ 8, (LANES >> 3) & 1      # row_ror:8
-    if level == 3:
-        return LANES ^ 7, (LANES >> 2) & 1      # row_half_mirror
-    if level == 4:
-        return LANES ^ 2, (LANES >> 1) & 1      # quad_perm [2,3,0,1]
-    return LANES ^ 1, LANES & 1                 # quad_perm [1,0,3,2]
+    return LANES ^ LEVEL_XOR[level], (LANES >> LEVEL_ROLE_BIT[level]) & 1
 
 
 def simulate(tree, window, cur, lane_off, c, best):
@@ -424,12 +437,12 @@ def simulate(tree, window, cur, lane_off, c, best):
     for op in tree.ops:
         t = op[0]
         if t == "LDS":
-            val[op[1]] = bytes_at(op[2], op[3])
-        elif t == "CURLD":
+            val[op[1]] = np.concatenate([bytes_at(op[2], op[3]), bytes_at(op[2], op[3] + 1)], axis=1)   # (64, 8) bytes
+        elif t in ("CURLD", "BASE"):
             pass
         elif t == "QSAD":
-            _, v, lo, hi, cw, half, row, bx, acc = op
-            src = np.concatenate([val[lo], val[hi]], axis=1)                           # (64, 8) bytes
+            _, v, pair, cw, half, row, bx, acc = op
+            src = val[pair]
             cb = cur[row, bx * 4:bx * 4 + 4].astype(np.int32)
             res = np.zeros((64, 4), np.uint32)
             for j in range(4):
