@@ -11,6 +11,31 @@ import torch
 import torch.distributed as dist
 
 
+# reference-picture offsets (POC deltas) of the reference's two GOP presets, per position in the GOP of 4
+GOP_REFS = {
+    # cfg/encoder_randomaccess_main.cfg:28-31  (Frame1..4: POC 4, 2, 1, 3)
+    "randomaccess": {4: (-4,), 2: (-2, 2), 1: (-1, 1, 3), 3: (-1, 1)},
+    # cfg/encoder_lowdelay_P_main.cfg:24-27    (4 active references per P picture)
+    "lowdelay_P": {1: (-1, -5, -9, -13), 2: (-1, -2, -6, -10), 3: (-1, -3, -7, -11), 4: (-1, -4, -8, -12)},
+}
+
+
+def gop_pairs(n_frames, structure="randomaccess"):
+    """(current POC, reference POC) pairs an open-loop ME pass over `n_frames` pictures searches,
+    in coding order of the reference's GOP structure; references outside the sequence are dropped."""
+    refs = GOP_REFS[structure]
+    pairs = []
+    for base in range(0, n_frames, 4):
+        for pos in (refs.keys() if structure != "randomaccess" else (4, 2, 1, 3)):
+            cur = base + pos
+            if cur >= n_frames:
+                continue
+            for d in refs[pos]:
+                if 0 <= cur + d < n_frames:
+                    pairs.append((cur, cur + d))
+    return pairs
+
+
 def pairs_for_rank(n_pairs, rank, world):
     """indices of the picture pairs rank `rank` searches (round-robin: pair p -> rank p % world)"""
     return list(range(rank, n_pairs, world))

@@ -26,12 +26,14 @@ def pad_plane(img, margin=MARGIN):
     return np.ascontiguousarray(np.pad(img, margin, mode="edge").astype(np.int16))
 
 
-def make_pair(width, height, seed=1234, bit_depth=8, max_mv=12, region=128, noise_sigma=2.0, margin=MARGIN):
+def make_pair(width, height, seed=1234, bit_depth=8, max_mv=12, region=128, noise_sigma=2.0, margin=MARGIN,
+              shift=(0, 0)):
     """-> (cur_padded, ref_padded, true_mv[regions_y, regions_x, 2]) ; planes are
-    (height+2*margin, width+2*margin) int16, sample (0,0) at [margin, margin]."""
+    (height+2*margin, width+2*margin) int16, sample (0,0) at [margin, margin].
+    shift=(sx, sy) additionally translates `cur` as a whole (frame t of a synthetic sequence)."""
     rng = np.random.default_rng(seed)
     maxv = (1 << bit_depth) - 1
-    g = max_mv + 2
+    g = max_mv + 2 + max(abs(shift[0]), abs(shift[1]))
     base = _box5(rng.integers(0, 256, size=(height + 2 * g, width + 2 * g)).astype(np.float64))
     lo, hi = base.min(), base.max()
     base = np.clip(np.rint((base - lo) * (maxv / (hi - lo))), 0, maxv)
@@ -43,7 +45,7 @@ def make_pair(width, height, seed=1234, bit_depth=8, max_mv=12, region=128, nois
         for i in range(rx):
             y0, y1 = j * region, min((j + 1) * region, height)
             x0, x1 = i * region, min((i + 1) * region, width)
-            dx, dy = int(mv[j, i, 0]), int(mv[j, i, 1])
+            dx, dy = int(mv[j, i, 0]) + shift[0], int(mv[j, i, 1]) + shift[1]
             # cur(x,y) = ref(x+dx, y+dy): the best integer MV of the region is (dx,dy)
             cur[y0:y1, x0:x1] = base[g + y0 + dy:g + y1 + dy, g + x0 + dx:g + x1 + dx]
     cur = np.clip(np.rint(cur + rng.normal(0.0, noise_sigma * (1 << (bit_depth - 8)), size=cur.shape)), 0, maxv)

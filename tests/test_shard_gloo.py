@@ -64,6 +64,16 @@ def test_pairs_round_robin():
     assert sorted(sum((shard.pairs_for_rank(64, r, 8) for r in range(8)), [])) == list(range(64))
 
 
+def test_gop_pairs_follow_the_reference_cfgs():
+    from hmme import shard
+    ra = shard.gop_pairs(9, "randomaccess")   # cfg/encoder_randomaccess_main.cfg:28-31
+    assert ra[:8] == [(4, 0), (2, 0), (2, 4), (1, 0), (1, 2), (1, 4), (3, 2), (3, 4)]
+    assert (8, 4) in ra and all(0 <= c < 9 and 0 <= r < 9 for c, r in ra)
+    ld = shard.gop_pairs(6, "lowdelay_P")      # cfg/encoder_lowdelay_P_main.cfg:24-27
+    assert ld == [(1, 0), (2, 1), (2, 0), (3, 2), (3, 0), (4, 3), (4, 0), (5, 4), (5, 0)]
+    assert len(shard.gop_pairs(64, "randomaccess")) == 124   # BASELINE config 4: one 64-picture sequence
+
+
 def test_two_rank_gloo_matches_single_process(oracle_lib):
     from hmme import shard, synth
     world, port = 2, _free_port()
