@@ -43,15 +43,20 @@ def work_4x4_sads(api, w, h, sr):
     return total
 
 
-def pmc_traffic(size, sr):
-    """HBM bytes per launch of the search kernel from the rocprofv3 --pmc passes of this same command
-    (FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction, + WRITE_SIZE), committed under
-    profiles/ -- counters cannot be read from inside the timed process.  None if no matching profile."""
-    path = os.path.join(ROOT, "profiles", f"latest_pmc_{size}_sr{sr}.json")
+def pmc_profile(size, sr):
+    """derived figures of the last rocprofv3 --pmc passes of this same command (tools/profile_bench.sh),
+    committed under profiles/ -- counters cannot be read from inside the timed process."""
     try:
-        return int(json.load(open(path))["derived"]["hbm_traffic_bytes_per_launch"])
+        return json.load(open(os.path.join(ROOT, "profiles", f"latest_pmc_{size}_sr{sr}.json")))["derived"]
     except (OSError, KeyError, ValueError):
-        return None
+        return {}
+
+
+def pmc_traffic(size, sr):
+    """HBM bytes per launch of the search kernel: FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950
+    correction, + WRITE_SIZE.  None if no matching profile."""
+    v = pmc_profile(size, sr).get("hbm_traffic_bytes_per_launch")
+    return int(v) if v is not None else None
 
 
 def usable_cores():
@@ -202,6 +207,12 @@ def main():
                          "note": "kernel is VALU-bound (1664 abs-diff ops per unique input byte, SURVEY 8d); "
                                  "see DESIGN.md for the VALU-issue roofline"},
         }
+        prof = pmc_profile(args.size, sr)
+        if prof.get("valu_busy_frac") is not None:   # what actually binds: integer VALU issue
+            out["valu_roofline"] = {"bound": "valu-issue", "valu_busy_frac": round(prof["valu_busy_frac"], 4),
+                                    "valu_wave_instructions_per_launch": int(prof["valu_wave_instructions_per_launch"]),
+                                    "effective_clock_ghz": round(prof.get("effective_clock_ghz", 0.0), 3),
+                                    "source": "profiles/latest_pmc_%s_sr%d.json (rocprofv3 --pmc passes of this command)" % (args.size, sr)}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cur, ref, w, h, sr, lq)
         print(json.dumps(out), flush=True)
