@@ -14,10 +14,14 @@
 #include "me_kernels.hpp"
 
 using hmme::MeJob;
+using hmme::MeJob16;
 
 namespace {
-constexpr int kMarginX = 128;  // >= 72 needed by clipMv's bounds (+3 for dword staging); 128 keeps CTU rows 64B-aligned
+constexpr int kMarginX = 128;  // samples; >= 72 needed by clipMv's bounds (+3 for dword staging); keeps CTU rows 64B-aligned
 constexpr int kMarginY = 80;   // TComPicYuv: maxCUHeight + 16 (reference TComPicYuv.cpp:91-92)
+constexpr int kWinPitch = 1024;  // per-CTU path: bytes per packed window row (>= 2 * (257 + 63) + 8)
+constexpr int kWinRows = 2 * 128 + 1 + 63;
+constexpr size_t kLdsBudget16 = 78 * 1024;   // per workgroup of the 16-bit path -> 2 workgroups per CU
 std::string g_create_error;
 }  // namespace
 
@@ -29,7 +33,7 @@ struct hmme_ctx {
   std::string info;
   hipStream_t stream = nullptr;   // private stream of the synchronous entry points
   // per-CTU path scratch
-  uint8_t* d_ctu = nullptr;       // 64 x 64
+  uint8_t* d_ctu = nullptr;       // 64 x 64 samples (1 or 2 bytes each)
   uint8_t* d_win = nullptr;       // window copy, pitch kWinPitch
   uint8_t* h_stage = nullptr;     // pinned: ctu + window
   int16_t* h_mv = nullptr;        // pinned results
@@ -38,8 +42,12 @@ struct hmme_ctx {
   uint32_t* d_sad1 = nullptr;
   MeJob* d_job1 = nullptr;
   // frame path scratch (grown on demand)
-  MeJob* d_jobs = nullptr;
-  int jobs_cap = 0;
+  void* d_jobs = nullptr;         // MeJob[] or MeJob16[]
+  size_t jobs_bytes = 0;
+  int* d_first_strip = nullptr;
+  int first_strip_cap = 0;
+  unsigned long long* d_best = nullptr;   // 16-bit path: [jobs][593] merge table
+  size_t best_cap = 0;
   int16_t* d_pred = nullptr;
   int16_t* d_mv = nullptr;
   uint32_t* d_sad = nullptr;
@@ -50,17 +58,17 @@ struct hmme_ctx {
 struct hmme_plane {
   hmme_ctx* ctx = nullptr;
   int width = 0, height = 0;
+  int bit_depth = 8;
+  int bps = 1;            // bytes per sample: 1 (8-bit path) or 2 (9..12 bit)
   int pitch = 0;          // bytes per row, multiple of 256
   int rows = 0;           // height + 2 * kMarginY
   uint8_t* d_data = nullptr;
-  void* d_stage = nullptr;  // device staging for uploads (int16 or u8 picture area)
+  void* d_stage = nullptr;  // device staging for uploads
   size_t stage_bytes = 0;
-  const uint8_t* origin() const { return d_data + (size_t)kMarginY * pitch + kMarginX; }
+  const uint8_t* origin() const { return d_data + (size_t)kMarginY * pitch + (size_t)kMarginX * bps; }
 };
 
 namespace {
-
-constexpr int kWinPitch = 256;   // per-CTU path: window rows are packed at this pitch
 
 int fail(hmme_ctx* ctx, int code, const char* fmt, ...) {
   char buf[512];
@@ -79,8 +87,19 @@ int fail(hmme_ctx* ctx, int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(ctx, HMME_ERR_DEVICE, "%s -> %s", #call, hipGetErrorString(e_));   \
   } while (0)
 
-int launch_search(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const uint8_t* ref, int ref_pitch, const MeJob* d_jobs,
-                  int n_jobs, int fen, int16_t* d_mv, uint32_t* d_sad, hipStream_t stream) {
+template <typename T>
+int ensure(hmme_ctx* ctx, T** p, size_t* cap_bytes, size_t bytes) {
+  if (bytes <= *cap_bytes) return HMME_OK;
+  if (*p) hipFree(*p);
+  *p = nullptr; *cap_bytes = 0;
+  HIP_TRY(ctx, hipMalloc((void**)p, bytes));
+  *cap_bytes = bytes;
+  return HMME_OK;
+}
+
+// ---- 8-bit path --------------------------------------------------------------------------------------
+int launch_search8(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const uint8_t* ref, int ref_pitch, const MeJob* d_jobs,
+                   int n_jobs, int fen, int16_t* d_mv, uint32_t* d_sad, hipStream_t stream) {
   if (n_jobs <= 0) return HMME_OK;
   if (fen)
     hipLaunchKernelGGL(hmme::me_search_kernel<1>, dim3(n_jobs), dim3(hmme::kThreads), 0, stream, cur, cur_pitch, ref,
@@ -92,14 +111,69 @@ int launch_search(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const uint8_
   return HMME_OK;
 }
 
+// ---- 16-bit path -------------------------------------------------------------------------------------
+constexpr int kPdw16Small = 97, kPdw16Large = 161;   // window pitch in dwords for SR <= 64 / SR <= 128 (odd: no LDS conflicts)
+
+size_t lds_bytes16(int pdw, int strip_rows) { return (size_t)(2 * 594 + 64 * 8 * 4 + 4 + (strip_rows + 63) * pdw) * 4; }
+
+// strips of candidate rows so that one strip's window rows fit the LDS budget
+int strips_for(int pdw, int wy_max) {
+  int n = 1;
+  while (lds_bytes16(pdw, (wy_max + n - 1) / n) > kLdsBudget16) ++n;
+  return n;
+}
+
+template <int FEN, int PDW>
+int launch16_t(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const uint8_t* ref, int ref_pitch, const MeJob16* d_jobs, int n_wg,
+               size_t lds, int sh, unsigned long long* d_best, hipStream_t stream) {
+  static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+  if (!attr_set) {
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)hmme::me_search16_kernel<FEN, PDW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((hmme::me_search16_kernel<FEN, PDW>), dim3(n_wg), dim3(hmme::kThreads), lds, stream, cur, cur_pitch, ref,
+                     ref_pitch, d_jobs, ctx->lambda_q16, sh, d_best);
+  HIP_TRY(ctx, hipGetLastError());
+  return HMME_OK;
+}
+
+// d_jobs: n_jobs * n_strips MeJob16; results merged in ctx->d_best then decoded into d_mv / d_sad
+int launch_search16(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const uint8_t* ref, int ref_pitch, const MeJob16* d_jobs,
+                    const int* d_first_strip, int n_jobs, int n_strips, int pdw, int strip_rows_max, int fen, int bit_depth,
+                    int16_t* d_mv, uint32_t* d_sad, hipStream_t stream) {
+  if (n_jobs <= 0) return HMME_OK;
+  size_t cap = ctx->best_cap;
+  int rc = ensure(ctx, &ctx->d_best, &cap, sizeof(unsigned long long) * HMME_NUM_CTU_PARTS * (size_t)n_jobs);
+  ctx->best_cap = cap;
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_best, 0xFF, sizeof(unsigned long long) * HMME_NUM_CTU_PARTS * (size_t)n_jobs, stream));
+  const size_t lds = lds_bytes16(pdw, strip_rows_max);
+  const int sh = bit_depth - 8, n_wg = n_jobs * n_strips;
+  if (pdw == kPdw16Small)
+    rc = fen ? launch16_t<1, kPdw16Small>(ctx, cur, cur_pitch, ref, ref_pitch, d_jobs, n_wg, lds, sh, ctx->d_best, stream)
+             : launch16_t<0, kPdw16Small>(ctx, cur, cur_pitch, ref, ref_pitch, d_jobs, n_wg, lds, sh, ctx->d_best, stream);
+  else
+    rc = fen ? launch16_t<1, kPdw16Large>(ctx, cur, cur_pitch, ref, ref_pitch, d_jobs, n_wg, lds, sh, ctx->d_best, stream)
+             : launch16_t<0, kPdw16Large>(ctx, cur, cur_pitch, ref, ref_pitch, d_jobs, n_wg, lds, sh, ctx->d_best, stream);
+  if (rc) return rc;
+  const long total = (long)n_jobs * HMME_NUM_CTU_PARTS;
+  hipLaunchKernelGGL(hmme::me_finalize16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, ctx->d_best, d_jobs,
+                     d_first_strip, n_jobs, ctx->lambda_q16, d_mv, d_sad);
+  HIP_TRY(ctx, hipGetLastError());
+  return HMME_OK;
+}
+
 int check_frame_args(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp, int* first,
                      int* count) {
   if (!ctx) return HMME_ERR_ARG;
   if (!cur || !ref || !fp) return fail(ctx, HMME_ERR_ARG, "null plane / params");
   if (cur->width != ref->width || cur->height != ref->height) return fail(ctx, HMME_ERR_ARG, "cur/ref size mismatch");
-  if (fp->bit_depth != 8) return fail(ctx, HMME_ERR_UNSUPPORTED, "bit depth %d: only the 8-bit path exists in this build", fp->bit_depth);
-  if (fp->search_range < 1 || fp->search_range > ctx->sr_max)
-    return fail(ctx, HMME_ERR_ARG, "search range %d outside [1, %d]", fp->search_range, ctx->sr_max);
+  if (fp->bit_depth < 8 || fp->bit_depth > 12) return fail(ctx, HMME_ERR_UNSUPPORTED, "bit depth %d outside 8..12", fp->bit_depth);
+  if (cur->bit_depth != fp->bit_depth || ref->bit_depth != fp->bit_depth)
+    return fail(ctx, HMME_ERR_ARG, "planes hold %d/%d-bit samples, search asks for %d", cur->bit_depth, ref->bit_depth, fp->bit_depth);
+  const int sr_cap = fp->bit_depth == 8 ? (ctx->sr_max < 64 ? ctx->sr_max : 64) : ctx->sr_max;
+  if (fp->search_range < 1 || fp->search_range > sr_cap)
+    return fail(ctx, HMME_ERR_ARG, "search range %d outside [1, %d] (8-bit path: 64, 16-bit path: 128)", fp->search_range, sr_cap);
   const int n = hmme_num_ctus(cur->width, cur->height);
   *first = fp->ctu_first;
   *count = fp->ctu_count < 0 ? n - fp->ctu_first : fp->ctu_count;
@@ -107,24 +181,12 @@ int check_frame_args(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref
   return HMME_OK;
 }
 
-int ensure_jobs(hmme_ctx* ctx, int n) {
-  if (n <= ctx->jobs_cap) return HMME_OK;
-  if (ctx->d_jobs) hipFree(ctx->d_jobs);
-  ctx->d_jobs = nullptr; ctx->jobs_cap = 0;
-  HIP_TRY(ctx, hipMalloc(&ctx->d_jobs, sizeof(MeJob) * (size_t)n));
-  ctx->jobs_cap = n;
-  return HMME_OK;
-}
-
-}  // namespace
-
-namespace {
-template <typename T>
-int plane_fill(hmme_plane* pl, const T* d_src, int src_pitch_elems, hipStream_t s, bool check) {
+template <typename SrcT, typename DstT>
+int plane_fill(hmme_plane* pl, const SrcT* d_src, int src_pitch_elems, hipStream_t s, bool check) {
   hmme_ctx* ctx = pl->ctx;
   dim3 grid((pl->pitch / 4 + 255) / 256, pl->rows);
-  hipLaunchKernelGGL(hmme::me_fill_plane_kernel<T>, grid, dim3(256), 0, s, pl->d_data, pl->pitch, kMarginX, kMarginY,
-                     pl->width, pl->height, d_src, src_pitch_elems, ctx->d_flag);
+  hipLaunchKernelGGL((hmme::me_fill_plane_kernel<SrcT, DstT>), grid, dim3(256), 0, s, pl->d_data, pl->pitch, kMarginX, kMarginY,
+                     pl->width, pl->height, d_src, src_pitch_elems, (1 << pl->bit_depth) - 1, ctx->d_flag);
   HIP_TRY(ctx, hipGetLastError());
   if (check) {
     int flag = 0;
@@ -132,7 +194,7 @@ int plane_fill(hmme_plane* pl, const T* d_src, int src_pitch_elems, hipStream_t 
     HIP_TRY(ctx, hipStreamSynchronize(s));
     if (flag) {
       HIP_TRY(ctx, hipMemset(ctx->d_flag, 0, sizeof(int)));
-      return fail(ctx, HMME_ERR_RANGE, "plane upload: sample outside [0,255] in the 8-bit path");
+      return fail(ctx, HMME_ERR_RANGE, "plane upload: sample outside [0,%d] for a %d-bit plane", (1 << pl->bit_depth) - 1, pl->bit_depth);
     }
   }
   return HMME_OK;
@@ -152,8 +214,10 @@ int plane_upload(hmme_plane* pl, const T* origin, int stride) {
   }
   HIP_TRY(ctx, hipMemcpy2DAsync(pl->d_stage, sizeof(T) * pl->width, origin, sizeof(T) * (size_t)stride, sizeof(T) * pl->width,
                                 pl->height, hipMemcpyHostToDevice, ctx->stream));
-  return plane_fill<T>(pl, (const T*)pl->d_stage, pl->width, ctx->stream, true);
+  if (pl->bps == 1) return plane_fill<T, uint8_t>(pl, (const T*)pl->d_stage, pl->width, ctx->stream, true);
+  return plane_fill<T, uint16_t>(pl, (const T*)pl->d_stage, pl->width, ctx->stream, true);
 }
+
 }  // namespace
 
 extern "C" {
@@ -182,21 +246,21 @@ int hmme_create(int device, int sr_max, unsigned flags, hmme_ctx** out) {
   snprintf(info, sizeof info, "%s (%s), %d CUs, %.0f GiB", prop.name, prop.gcnArchName, prop.multiProcessorCount,
            (double)prop.totalGlobalMem / (1 << 30));
   ctx->info = info;
-  const size_t win_bytes = (size_t)hmme::kWinRowsMax * kWinPitch + 64;
+  const size_t win_bytes = (size_t)kWinRows * kWinPitch + 64;
 #define CREATE_TRY(call)                                                                                           \
   do {                                                                                                             \
     hipError_t e_ = (call);                                                                                        \
     if (e_ != hipSuccess) { int rc = fail(nullptr, HMME_ERR_NOMEM, "hmme_create: %s -> %s", #call, hipGetErrorString(e_)); hmme_destroy(ctx); return rc; } \
   } while (0)
   CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-  CREATE_TRY(hipMalloc(&ctx->d_ctu, 64 * 64));
+  CREATE_TRY(hipMalloc(&ctx->d_ctu, 64 * 64 * 2));
   CREATE_TRY(hipMalloc(&ctx->d_win, win_bytes));
-  CREATE_TRY(hipHostMalloc(&ctx->h_stage, 64 * 64 + win_bytes));
+  CREATE_TRY(hipHostMalloc(&ctx->h_stage, 64 * 64 * 2 + win_bytes));
   CREATE_TRY(hipHostMalloc(&ctx->h_mv, sizeof(int16_t) * 2 * HMME_NUM_CTU_PARTS));
   CREATE_TRY(hipHostMalloc(&ctx->h_sad, sizeof(uint32_t) * HMME_NUM_CTU_PARTS));
   CREATE_TRY(hipMalloc(&ctx->d_mv1, sizeof(int16_t) * 2 * HMME_NUM_CTU_PARTS));
   CREATE_TRY(hipMalloc(&ctx->d_sad1, sizeof(uint32_t) * HMME_NUM_CTU_PARTS));
-  CREATE_TRY(hipMalloc(&ctx->d_job1, sizeof(MeJob)));
+  CREATE_TRY(hipMalloc(&ctx->d_job1, sizeof(MeJob16) * 16));
   CREATE_TRY(hipMalloc(&ctx->d_flag, sizeof(int)));
   CREATE_TRY(hipMemset(ctx->d_flag, 0, sizeof(int)));
 #undef CREATE_TRY
@@ -209,7 +273,8 @@ void hmme_destroy(hmme_ctx* ctx) {
   hipSetDevice(ctx->device);
   if (ctx->stream) { hipStreamSynchronize(ctx->stream); hipStreamDestroy(ctx->stream); }
   hipFree(ctx->d_ctu); hipFree(ctx->d_win); hipFree(ctx->d_mv1); hipFree(ctx->d_sad1); hipFree(ctx->d_job1);
-  hipFree(ctx->d_jobs); hipFree(ctx->d_pred); hipFree(ctx->d_mv); hipFree(ctx->d_sad); hipFree(ctx->d_flag);
+  hipFree(ctx->d_jobs); hipFree(ctx->d_first_strip); hipFree(ctx->d_best);
+  hipFree(ctx->d_pred); hipFree(ctx->d_mv); hipFree(ctx->d_sad); hipFree(ctx->d_flag);
   if (ctx->h_stage) hipHostFree(ctx->h_stage);
   if (ctx->h_mv) hipHostFree(ctx->h_mv);
   if (ctx->h_sad) hipHostFree(ctx->h_sad);
@@ -249,44 +314,72 @@ int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
                     const hmme_search_params* p, int16_t* out_mv, uint32_t* out_sad) {
   if (!ctx) return HMME_ERR_ARG;
   if (!ctu || !ref0 || !p || !out_mv || !out_sad) return fail(ctx, HMME_ERR_ARG, "hmme_search_ctu: null argument");
-  if (p->bit_depth != 8) return fail(ctx, HMME_ERR_UNSUPPORTED, "bit depth %d: only the 8-bit path exists in this build", p->bit_depth);
+  if (p->bit_depth < 8 || p->bit_depth > 12) return fail(ctx, HMME_ERR_UNSUPPORTED, "bit depth %d outside 8..12", p->bit_depth);
+  const bool wide = p->bit_depth > 8;
+  const int sr_cap = wide ? ctx->sr_max : (ctx->sr_max < 64 ? ctx->sr_max : 64);
   const int wx = p->rb_x - p->lt_x + 1, wy = p->rb_y - p->lt_y + 1;
-  if (wx < 1 || wy < 1 || wx > 2 * ctx->sr_max + 1 || wy > 2 * ctx->sr_max + 1)
-    return fail(ctx, HMME_ERR_ARG, "window %dx%d outside 1..%d", wx, wy, 2 * ctx->sr_max + 1);
+  if (wx < 1 || wy < 1 || wx > 2 * sr_cap + 1 || wy > 2 * sr_cap + 1)
+    return fail(ctx, HMME_ERR_ARG, "window %dx%d outside 1..%d", wx, wy, 2 * sr_cap + 1);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  // pack CTU and window to bytes in pinned memory (the reference copies the same window with a scalar
-  // CPU loop, TEncOpenCL.cpp:275-277)
+  // pack CTU and window in pinned memory (the reference copies the same window with a scalar CPU loop,
+  // TEncOpenCL.cpp:275-277); 1 byte per sample on the 8-bit path, 2 otherwise
+  const int bps = wide ? 2 : 1, maxv = (1 << p->bit_depth) - 1;
   uint8_t* h_ctu = ctx->h_stage;
-  uint8_t* h_win = ctx->h_stage + 64 * 64;
-  unsigned bad = 0;
+  uint8_t* h_win = ctx->h_stage + 64 * 64 * 2;
+  const int rows = wy + 63, cols = wx + 63;
+  const int16_t* src = ref0 + (long)p->lt_y * ref_stride + p->lt_x;
+  bool bad = false;
   for (int y = 0; y < 64; ++y)
     for (int x = 0; x < 64; ++x) {
       const int v = ctu[y * ctu_stride + x];
-      bad |= (unsigned)v;
-      h_ctu[y * 64 + x] = (uint8_t)v;
+      bad |= v < 0 || v > maxv;
+      if (wide) ((uint16_t*)h_ctu)[y * 64 + x] = (uint16_t)v; else h_ctu[y * 64 + x] = (uint8_t)v;
     }
-  const int rows = wy + 63, cols = wx + 63;
-  const int16_t* src = ref0 + (long)p->lt_y * ref_stride + p->lt_x;
   for (int y = 0; y < rows; ++y) {
+    uint8_t* row = h_win + (size_t)y * kWinPitch;
     for (int x = 0; x < cols; ++x) {
       const int v = src[(long)y * ref_stride + x];
-      bad |= (unsigned)v;
-      h_win[y * kWinPitch + x] = (uint8_t)v;
+      bad |= v < 0 || v > maxv;
+      if (wide) ((uint16_t*)row)[x] = (uint16_t)v; else row[x] = (uint8_t)v;
     }
-    std::memset(h_win + y * kWinPitch + cols, 0, kWinPitch - cols);
+    std::memset(row + cols * bps, 0, kWinPitch - cols * bps);
   }
-  if (bad & ~0xffu) return fail(ctx, HMME_ERR_RANGE, "hmme_search_ctu: sample outside [0,255] in the 8-bit path");
+  if (bad) return fail(ctx, HMME_ERR_RANGE, "hmme_search_ctu: sample outside [0,%d] for bit depth %d", maxv, p->bit_depth);
   MeJob job;
   job.ctu_x = 0; job.ctu_y = 0;
   job.lt_x = (int16_t)p->lt_x; job.lt_y = (int16_t)p->lt_y; job.rb_x = (int16_t)p->rb_x; job.rb_y = (int16_t)p->rb_y;
   job.pred_x = (int16_t)p->pred_x; job.pred_y = (int16_t)p->pred_y;
   hipStream_t s = ctx->stream;
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ctu, h_ctu, 64 * 64, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ctu, h_ctu, 64 * 64 * bps, hipMemcpyHostToDevice, s));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_win, h_win, (size_t)rows * kWinPitch + 64, hipMemcpyHostToDevice, s));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_job1, &job, sizeof job, hipMemcpyHostToDevice, s));
-  // the kernel addresses ref(ctu + lt): bias the base so that (lt_x, lt_y) lands on the window copy's first byte
-  const uint8_t* ref_base = ctx->d_win - (long)p->lt_y * kWinPitch - p->lt_x;
-  int rc = launch_search(ctx, ctx->d_ctu, 64, ref_base, kWinPitch, ctx->d_job1, 1, p->fen, ctx->d_mv1, ctx->d_sad1, s);
+  // the kernel addresses ref(ctu + lt): bias the base so that (lt_x, lt_y) lands on the window copy's first sample
+  const uint8_t* ref_base = ctx->d_win - (long)p->lt_y * kWinPitch - (long)p->lt_x * bps;
+  int rc;
+  if (!wide) {
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_job1, &job, sizeof job, hipMemcpyHostToDevice, s));
+    rc = launch_search8(ctx, ctx->d_ctu, 64, ref_base, kWinPitch, ctx->d_job1, 1, p->fen, ctx->d_mv1, ctx->d_sad1, s);
+  } else {
+    const int pdw = (wx <= 129 && wy <= 129) ? kPdw16Small : kPdw16Large;
+    const int n_strips = strips_for(pdw, wy);
+    if (n_strips > 16) return fail(ctx, HMME_ERR_UNSUPPORTED, "window needs %d strips", n_strips);
+    MeJob16 js[16];
+    int smax = 0;
+    for (int i = 0; i < n_strips; ++i) {
+      js[i].j = job; js[i].job = 0;
+      js[i].y0 = (int16_t)((long)wy * i / n_strips); js[i].y1 = (int16_t)((long)wy * (i + 1) / n_strips);
+      if (js[i].y1 - js[i].y0 > smax) smax = js[i].y1 - js[i].y0;
+    }
+    const int zero = 0;
+    size_t cap = (size_t)ctx->first_strip_cap * sizeof(int);
+    rc = ensure(ctx, &ctx->d_first_strip, &cap, sizeof(int) * 16);
+    ctx->first_strip_cap = (int)(cap / sizeof(int));
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_first_strip, &zero, sizeof zero, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_job1, js, sizeof(MeJob16) * n_strips, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));   // js / zero live on this stack frame
+    rc = launch_search16(ctx, ctx->d_ctu, 128, ref_base, kWinPitch, (const MeJob16*)ctx->d_job1, ctx->d_first_strip, 1, n_strips, pdw,
+                         smax, p->fen, p->bit_depth, ctx->d_mv1, ctx->d_sad1, s);
+  }
   if (rc) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mv, ctx->d_mv1, sizeof(int16_t) * 2 * HMME_NUM_CTU_PARTS, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_sad, ctx->d_sad1, sizeof(uint32_t) * HMME_NUM_CTU_PARTS, hipMemcpyDeviceToHost, s));
@@ -297,19 +390,22 @@ int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
 }
 
 // ---- planes ----------------------------------------------------------------------------------------------
-int hmme_plane_create(hmme_ctx* ctx, int width, int height, hmme_plane** out) {
+int hmme_plane_create_ex(hmme_ctx* ctx, int width, int height, int bit_depth, hmme_plane** out) {
   if (!ctx) return HMME_ERR_ARG;
   if (!out || width < 8 || height < 8 || width > 16384 || height > 16384) return fail(ctx, HMME_ERR_ARG, "hmme_plane_create(%d, %d)", width, height);
+  if (bit_depth < 8 || bit_depth > 12) return fail(ctx, HMME_ERR_UNSUPPORTED, "bit depth %d outside 8..12", bit_depth);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hmme_plane* pl = new hmme_plane;
   pl->ctx = ctx; pl->width = width; pl->height = height;
-  pl->pitch = (width + 2 * kMarginX + 255) & ~255;
+  pl->bit_depth = bit_depth; pl->bps = bit_depth > 8 ? 2 : 1;
+  pl->pitch = ((width + 2 * kMarginX) * pl->bps + 255) & ~255;
   pl->rows = height + 2 * kMarginY;
   hipError_t e = hipMalloc(&pl->d_data, (size_t)pl->pitch * (pl->rows + 1));
   if (e != hipSuccess) { delete pl; return fail(ctx, HMME_ERR_NOMEM, "hipMalloc plane: %s", hipGetErrorString(e)); }
   *out = pl;
   return HMME_OK;
 }
+int hmme_plane_create(hmme_ctx* ctx, int width, int height, hmme_plane** out) { return hmme_plane_create_ex(ctx, width, height, 8, out); }
 
 void hmme_plane_destroy(hmme_plane* pl) {
   if (!pl) return;
@@ -321,7 +417,7 @@ void hmme_plane_destroy(hmme_plane* pl) {
 
 int hmme_plane_width(const hmme_plane* pl) { return pl ? pl->width : 0; }
 int hmme_plane_height(const hmme_plane* pl) { return pl ? pl->height : 0; }
-
+int hmme_plane_bit_depth(const hmme_plane* pl) { return pl ? pl->bit_depth : 0; }
 
 int hmme_plane_upload_pel(hmme_plane* pl, const int16_t* origin, int stride) { return plane_upload<int16_t>(pl, origin, stride); }
 int hmme_plane_upload_u8(hmme_plane* pl, const uint8_t* origin, int stride) { return plane_upload<uint8_t>(pl, origin, stride); }
@@ -330,10 +426,45 @@ int hmme_plane_set_device_u8(hmme_plane* pl, const void* d_src, int src_pitch, v
   if (!pl) return HMME_ERR_ARG;
   if (!d_src || src_pitch < pl->width) return fail(pl->ctx, HMME_ERR_ARG, "hmme_plane_set_device_u8: bad source");
   HIP_TRY(pl->ctx, hipSetDevice(pl->ctx->device));
-  return plane_fill<uint8_t>(pl, (const uint8_t*)d_src, src_pitch, (hipStream_t)stream, false);
+  if (pl->bps == 1) return plane_fill<uint8_t, uint8_t>(pl, (const uint8_t*)d_src, src_pitch, (hipStream_t)stream, false);
+  return plane_fill<uint8_t, uint16_t>(pl, (const uint8_t*)d_src, src_pitch, (hipStream_t)stream, false);
 }
 
 // ---- frame search --------------------------------------------------------------------------------------------
+// builds the device job table of the picture search on `stream`; 8-bit: MeJob[count]; 16-bit: MeJob16[count * strips]
+static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_params* fp, const void* d_pred_q, int first, int count,
+                     hipStream_t s, int* n_strips, int* pdw, int* strip_rows) {
+  const bool wide = fp->bit_depth > 8;
+  *pdw = fp->search_range <= 64 ? kPdw16Small : kPdw16Large;
+  *n_strips = wide ? strips_for(*pdw, 2 * fp->search_range + 1) : 1;
+  *strip_rows = (2 * fp->search_range + 1 + *n_strips - 1) / *n_strips;
+  size_t cap = ctx->jobs_bytes;
+  int rc = ensure(ctx, (uint8_t**)&ctx->d_jobs, &cap, wide ? sizeof(MeJob16) * (size_t)count * *n_strips : sizeof(MeJob) * (size_t)count);
+  ctx->jobs_bytes = cap;
+  if (rc) return rc;
+  if (!wide) {
+    hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, dim3((count + 255) / 256), dim3(256), 0, s, (MeJob*)ctx->d_jobs,
+                       (const int16_t*)d_pred_q, first, count, cur->width, cur->height, fp->search_range);
+  } else {
+    size_t fcap = (size_t)ctx->first_strip_cap * sizeof(int);
+    rc = ensure(ctx, &ctx->d_first_strip, &fcap, sizeof(int) * (size_t)count);
+    ctx->first_strip_cap = (int)(fcap / sizeof(int));
+    if (rc) return rc;
+    hipLaunchKernelGGL(hmme::me_prep_jobs16_kernel, dim3((count + 255) / 256), dim3(256), 0, s, (MeJob16*)ctx->d_jobs,
+                       ctx->d_first_strip, (const int16_t*)d_pred_q, first, count, cur->width, cur->height, fp->search_range, *n_strips);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  return HMME_OK;
+}
+
+static int run_search(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp, int count, int n_strips,
+                      int pdw, int strip_rows, int16_t* d_mv, uint32_t* d_sad, hipStream_t s) {
+  if (fp->bit_depth == 8)
+    return launch_search8(ctx, cur->origin(), cur->pitch, ref->origin(), ref->pitch, (const MeJob*)ctx->d_jobs, count, fp->fen, d_mv, d_sad, s);
+  return launch_search16(ctx, cur->origin(), cur->pitch, ref->origin(), ref->pitch, (const MeJob16*)ctx->d_jobs, ctx->d_first_strip, count,
+                         n_strips, pdw, strip_rows, fp->fen, fp->bit_depth, d_mv, d_sad, s);
+}
+
 int hmme_search_frame_device(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp,
                              const void* d_pred_q, void* d_out_mv, void* d_out_sad, void* stream) {
   int first, count;
@@ -342,14 +473,11 @@ int hmme_search_frame_device(hmme_ctx* ctx, const hmme_plane* cur, const hmme_pl
   if (!d_out_mv || !d_out_sad) return fail(ctx, HMME_ERR_ARG, "null output buffer");
   if (count == 0) return HMME_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  rc = ensure_jobs(ctx, count);
-  if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, dim3((count + 255) / 256), dim3(256), 0, s, ctx->d_jobs,
-                     (const int16_t*)d_pred_q, first, count, cur->width, cur->height, fp->search_range);
-  HIP_TRY(ctx, hipGetLastError());
-  return launch_search(ctx, cur->origin(), cur->pitch, ref->origin(), ref->pitch, ctx->d_jobs, count, fp->fen,
-                       (int16_t*)d_out_mv, (uint32_t*)d_out_sad, s);
+  int n_strips, pdw, strip_rows;
+  rc = prep_jobs(ctx, cur, fp, d_pred_q, first, count, s, &n_strips, &pdw, &strip_rows);
+  if (rc) return rc;
+  return run_search(ctx, cur, ref, fp, count, n_strips, pdw, strip_rows, (int16_t*)d_out_mv, (uint32_t*)d_out_sad, s);
 }
 
 int hmme_search_frame(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp,
@@ -387,18 +515,16 @@ int hmme_time_search_kernel(hmme_ctx* ctx, const hmme_plane* cur, const hmme_pla
   if (!avg_ms || reps < 1) return fail(ctx, HMME_ERR_ARG, "hmme_time_search_kernel: bad reps/avg_ms");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
-  // job table once (it is not part of the timed kernel), then `reps` launches of the search kernel alone
-  rc = ensure_jobs(ctx, count);
+  // job table once (it is not part of the timed kernel), then `reps` launches of the search kernel(s) alone
+  int n_strips, pdw, strip_rows;
+  rc = prep_jobs(ctx, cur, fp, d_pred_q, first, count, s, &n_strips, &pdw, &strip_rows);
   if (rc) return rc;
-  hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, dim3((count + 255) / 256), dim3(256), 0, s, ctx->d_jobs,
-                     (const int16_t*)d_pred_q, first, count, cur->width, cur->height, fp->search_range);
   hipEvent_t e0, e1;
   HIP_TRY(ctx, hipEventCreate(&e0));
   HIP_TRY(ctx, hipEventCreate(&e1));
   HIP_TRY(ctx, hipEventRecord(e0, s));
   for (int i = 0; i < reps; ++i) {
-    rc = launch_search(ctx, cur->origin(), cur->pitch, ref->origin(), ref->pitch, ctx->d_jobs, count, fp->fen,
-                       (int16_t*)d_out_mv, (uint32_t*)d_out_sad, s);
+    rc = run_search(ctx, cur, ref, fp, count, n_strips, pdw, strip_rows, (int16_t*)d_out_mv, (uint32_t*)d_out_sad, s);
     if (rc) return rc;
   }
   HIP_TRY(ctx, hipEventRecord(e1, s));

@@ -302,27 +302,187 @@ __global__ void me_prep_jobs_kernel(MeJob* jobs, const int16_t* __restrict__ pre
   jobs[i] = j;
 }
 
-// picture area (int16 Pel or u8, pitch in elements) -> padded u8 plane, borders edge-replicated like
+// picture area (int16 Pel, u16 or u8; pitch in elements) -> padded u8 / u16 plane, borders edge-replicated like
 // TComPicYuv::extendPicBorder (reference TComPicYuv.cpp:214-262).  One thread per 4 output bytes.
-// flag[0] is set when a sample lies outside [0,255].
-template <typename SrcT>
+// flag[0] is set when a sample lies outside [0, max_val].
+template <typename SrcT, typename DstT>
 __global__ void me_fill_plane_kernel(uint8_t* __restrict__ dst, int dst_pitch, int margin_x, int margin_y, int w, int h,
-                                     const SrcT* __restrict__ src, int src_pitch, int* __restrict__ flag) {
-  const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;   // plane column of the first byte
+                                     const SrcT* __restrict__ src, int src_pitch, int max_val, int* __restrict__ flag) {
+  constexpr int N = 4 / (int)sizeof(DstT);                        // samples per thread
+  const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * N;   // plane column of the first sample
   const int y = blockIdx.y;                                       // plane row
-  if (x4 >= dst_pitch) return;
+  if (x0 * (int)sizeof(DstT) >= dst_pitch) return;
   const int sy = min(max(y - margin_y, 0), h - 1);
   uint32_t packed = 0;
   bool bad = false;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int sx = min(max(x4 + i - margin_x, 0), w - 1);
+  for (int i = 0; i < N; ++i) {
+    const int sx = min(max(x0 + i - margin_x, 0), w - 1);
     const int v = (int)src[(long)sy * src_pitch + sx];
-    bad |= (v < 0) | (v > 255);
-    packed |= (uint32_t)(v & 0xff) << (8 * i);
+    bad |= (v < 0) | (v > max_val);
+    packed |= (uint32_t)(v & (sizeof(DstT) == 1 ? 0xff : 0xffff)) << (8 * (int)sizeof(DstT) * i);
   }
-  *(uint32_t*)(dst + (long)y * dst_pitch + x4) = packed;
+  *(uint32_t*)(dst + (long)y * dst_pitch + (long)x0 * sizeof(DstT)) = packed;
   if (bad) atomicOr(flag, 1);
+}
+
+// ---- 16-bit sample path (bit depth 9..12) -----------------------------------------------------------------
+// Same task / key / butterfly / merge machinery as me_search_kernel; differences (see tools/gen_me_tree.py,
+// class Tree16): v_sad_u16 leaves on u16 samples, two candidates per lane, exact 32-bit sums and
+//   key = ((sum << fen_shift) >> (bitDepth-8)) << 10 + c     (reference TComRdCost.cpp:520-521),
+// lanes packed linearly over the window (candidate pair q = iteration*64 + lane), and the window is cut into
+// horizontal strips of candidate rows so that one strip's reference rows fit LDS (SR 128: 320 x 322 samples);
+// strips of a CTU are separate workgroups that merge through 64-bit atomicMin on a global table.
+struct MeJob16 {
+  MeJob j;
+  int16_t y0, y1;      // candidate rows [y0, y1) of the window handled by this workgroup
+  int32_t job;         // index into the result arrays
+};
+static_assert(sizeof(MeJob16) == 24, "MeJob16 layout");
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef volatile __attribute__((address_space(3))) uint32_t lds_vu32_t;
+typedef volatile __attribute__((address_space(3))) u32x4_t lds_vu32x4_t;
+#define ME_SAD16(a, b, acc) __builtin_amdgcn_sad_u16((a), (b), (acc))
+
+template <int FEN, int PDW>
+__global__ void __launch_bounds__(kThreads, 2)
+me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const uint8_t* __restrict__ ref_base,
+                   int ref_pitch, const MeJob16* __restrict__ jobs, uint32_t lambda_q16, int sh,
+                   unsigned long long* __restrict__ g_best) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  unsigned long long* best64 = (unsigned long long*)smem;              // [593] (+1 pad)
+  u32x4_t* curl = (u32x4_t*)(smem + 2 * 594);                          // [64][8]: 64x64 u16 current block
+  int* task_ctr = (int*)(smem + 2 * 594 + 64 * 8 * 4);
+  uint32_t* win = smem + 2 * 594 + 64 * 8 * 4 + 4;                     // [(ny + 63)][PDW]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const MeJob16 jb = jobs[blockIdx.x];
+  const MeJob job = jb.j;
+  const int wx = job.rb_x - job.lt_x + 1;
+  const int ny = jb.y1 - jb.y0;                                        // candidate rows of this strip
+
+  for (int s = tid; s < kParts; s += kThreads) best64[s] = ~0ull;
+  if (tid == 0) *task_ctr = 0;
+  for (int i = tid; i < 64 * 8; i += kThreads) {
+    const int r = i >> 3, q = i & 7;
+    curl[i] = *(const u32x4_t*)(cur_base + (long)(job.ctu_y + r) * cur_pitch + 2 * job.ctu_x + 16 * q);
+  }
+  {
+    const uint8_t* src = ref_base + (long)(job.ctu_y + job.lt_y + jb.y0) * ref_pitch + 2 * (job.ctu_x + job.lt_x);
+    const uint32_t mis = (uint32_t)(uintptr_t)src & 3u;
+    const uint32_t* src_al = (const uint32_t*)(src - mis);
+    const int pitch_dw = ref_pitch >> 2;
+    const int n = (ny + 63) * PDW;
+    for (int i = tid; i < n; i += kThreads) {
+      const int r = i / PDW, k = i - r * PDW;
+      const uint32_t lo = src_al[(long)r * pitch_dw + k], hi = src_al[(long)r * pitch_dw + k + 1];
+      win[i] = __builtin_amdgcn_alignbyte(hi, lo, mis);
+    }
+  }
+  __syncthreads();
+
+  const int pairs = (wx + 1) >> 1;                                     // candidate pairs per window row
+  const int n_iters = (ny * pairs + 63) >> 6;
+  const int n_tasks = (n_iters + kIterPerTask - 1) / kIterPerTask;
+  // key = ((sum & mask) << lsh) + c  ==  (((sum << fen_shift) >> sh) << 10) + c
+  const uint32_t mask_a = ~((1u << sh) - 1u), lsh_a = kIdxBits - sh;
+  const uint32_t mask_e = FEN ? ~((1u << (sh > 0 ? sh - 1 : 0)) - 1u) : mask_a, lsh_e = FEN ? kIdxBits + 1 - sh : lsh_a;
+  const bool rb1 = lane & 2, rb0 = lane & 1;
+  const lds_vu32x4_t* curv4 = (const lds_vu32x4_t*)curl;
+  constexpr int ME16_PDW = PDW;
+
+  while (true) {
+    int t = 0;
+    if (lane == 0) t = atomicAdd(task_ctr, 1);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t >= n_tasks) break;
+    const int it0 = t * kIterPerTask;
+    const int n_it = min(kIterPerTask, n_iters - it0);
+    uint32_t b0 = ME_MAXKEY, b1 = ME_MAXKEY, b2 = ME_MAXKEY, b3 = ME_MAXKEY, b4 = ME_MAXKEY, b5 = ME_MAXKEY,
+             b6 = ME_MAXKEY, b7 = ME_MAXKEY, b8 = ME_MAXKEY, b9 = ME_MAXKEY;
+    for (int it = 0; it < n_it; ++it) {
+      const int q = (it0 + it) * 64 + lane;
+      const int row = q / pairs, pr = q - row * pairs;
+      const int cx = 2 * pr, cy = jb.y0 + row;
+      const bool vy = row < ny;
+      const int mvy = job.lt_y + cy, mvx = job.lt_x + cx;
+      const uint32_t by = me_component_bits((mvy << 2) - job.pred_y);
+      const uint32_t tag = ((uint32_t)it << 8) | ((uint32_t)lane << 2);
+      uint32_t cc[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const uint32_t cost = (lambda_q16 * (me_component_bits(((mvx + j) << 2) - job.pred_x) + by)) >> 16;
+        cc[j] = (((vy && (cx + j) < wx) ? cost : kInvCost) << kIdxBits) | tag | (uint32_t)j;
+      }
+      const uint32_t c0 = cc[0], c1 = cc[1];
+      const lds_vu32_t* lpv = (const lds_vu32_t*)(win + min(row, ny - 1) * PDW + pr);
+      if constexpr (FEN) {
+#include "me_tree16_fen1.inc"
+      } else {
+#include "me_tree16_fen0.inc"
+      }
+    }
+#define ME_FLUSH16(g, key_)                                                                                        \
+    {                                                                                                              \
+      const int slot = ME_SLOT_OF[g][lane];                                                                        \
+      const uint32_t key = (key_);                                                                                 \
+      const uint32_t cost = key >> kIdxBits;                                                                       \
+      if (slot >= 0 && cost < kInvCost) {                                                                          \
+        const int kq = (it0 + (int)((key >> 8) & 3)) * 64 + (int)((key >> 2) & 63);                                \
+        const int krow = kq / pairs;                                                                               \
+        const int bx = 2 * (kq - krow * pairs) + (int)(key & 3);                                                   \
+        atomicMin(&best64[slot], ((unsigned long long)cost << 32) | ((unsigned long long)(jb.y0 + krow) << 16) |   \
+                                     (unsigned long long)bx);                                                      \
+      }                                                                                                            \
+    }
+    ME_FLUSH16(0, b0) ME_FLUSH16(1, b1) ME_FLUSH16(2, b2) ME_FLUSH16(3, b3) ME_FLUSH16(4, b4)
+    ME_FLUSH16(5, b5) ME_FLUSH16(6, b6) ME_FLUSH16(7, b7) ME_FLUSH16(8, b8) ME_FLUSH16(9, b9)
+#undef ME_FLUSH16
+  }
+  __syncthreads();
+  for (int s = tid; s < kParts; s += kThreads) atomicMin(&g_best[(long)jb.job * kParts + s], best64[s]);
+}
+
+// strips of one CTU have merged into g_best: decode (cost, y, x) -> TComMv + pure SAD
+__global__ void me_finalize16_kernel(const unsigned long long* __restrict__ g_best, const MeJob16* __restrict__ jobs,
+                                     const int* __restrict__ first_strip_of_job, int n_jobs, uint32_t lambda_q16,
+                                     int16_t* __restrict__ out_mv, uint32_t* __restrict__ out_sad) {
+  const long o = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= (long)n_jobs * kParts) return;
+  const MeJob job = jobs[first_strip_of_job[o / kParts]].j;
+  const unsigned long long v = g_best[o];
+  const int mvx = job.lt_x + (int)(v & 0xffff), mvy = job.lt_y + (int)((v >> 16) & 0xffff);
+  out_mv[2 * o] = (int16_t)mvx;
+  out_mv[2 * o + 1] = (int16_t)mvy;
+  out_sad[o] = (uint32_t)(v >> 32) - me_mv_cost(lambda_q16, mvx, mvy, job.pred_x, job.pred_y);
+}
+
+// one MeJob16 per (CTU, strip) from the per-CTU predictors
+__global__ void me_prep_jobs16_kernel(MeJob16* jobs, int* first_strip_of_job, const int16_t* __restrict__ pred_q,
+                                      int ctu_first, int ctu_count, int pic_w, int pic_h, int sr, int n_strips) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ctu_count) return;
+  const int ctu = ctu_first + i, ctus_x = (pic_w + 63) >> 6;
+  const int cu_x = (ctu % ctus_x) * 64, cu_y = (ctu / ctus_x) * 64;
+  const int px = pred_q ? pred_q[2 * ctu] : 0, py = pred_q ? pred_q[2 * ctu + 1] : 0;
+  int ltx, lty, rbx, rby;
+  set_search_range(px, py, sr, cu_x, cu_y, pic_w, pic_h, ltx, lty, rbx, rby);
+  MeJob j;
+  j.ctu_x = (int16_t)cu_x; j.ctu_y = (int16_t)cu_y;
+  j.lt_x = (int16_t)ltx; j.lt_y = (int16_t)lty; j.rb_x = (int16_t)rbx; j.rb_y = (int16_t)rby;
+  j.pred_x = (int16_t)px; j.pred_y = (int16_t)py;
+  const int wy = rby - lty + 1;
+  first_strip_of_job[i] = i * n_strips;
+  for (int s = 0; s < n_strips; ++s) {          // equal strips; empty ones (clipped windows) have y0 == y1
+    MeJob16 js;
+    js.j = j;
+    js.y0 = (int16_t)((long)wy * s / n_strips);
+    js.y1 = (int16_t)((long)wy * (s + 1) / n_strips);
+    js.job = i;
+    jobs[i * n_strips + s] = js;
+  }
 }
 
 }  // namespace hmme

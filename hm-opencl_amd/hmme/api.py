@@ -17,7 +17,7 @@ NUM_PARTS = 593
 # every symbol include/hmme.h declares (tests check the library exports all of them)
 SYMBOLS = ["hmme_create", "hmme_destroy", "hmme_last_error", "hmme_device_info", "hmme_set_lambda",
            "hmme_set_lambda_q16", "hmme_get_lambda_q16", "hmme_params_ocl_compat", "hmme_set_search_range",
-           "hmme_search_ctu", "hmme_plane_create", "hmme_plane_destroy", "hmme_plane_upload_pel",
+           "hmme_search_ctu", "hmme_plane_create", "hmme_plane_create_ex", "hmme_plane_bit_depth", "hmme_plane_destroy", "hmme_plane_upload_pel",
            "hmme_plane_upload_u8", "hmme_plane_set_device_u8", "hmme_plane_width", "hmme_plane_height",
            "hmme_num_ctus", "hmme_search_frame", "hmme_search_frame_device", "hmme_time_search_kernel"]
 
@@ -70,6 +70,8 @@ def load():
     L.hmme_set_search_range.restype = None
     L.hmme_search_ctu.argtypes = [vp, vp, i, vp, i, C.POINTER(SearchParams), vp, vp]
     L.hmme_plane_create.argtypes = [vp, i, i, C.POINTER(vp)]
+    L.hmme_plane_create_ex.argtypes = [vp, i, i, i, C.POINTER(vp)]
+    L.hmme_plane_bit_depth.argtypes = [vp]
     L.hmme_plane_destroy.argtypes = [vp]
     L.hmme_plane_destroy.restype = None
     L.hmme_plane_upload_pel.argtypes = [vp, vp, i]
@@ -86,11 +88,11 @@ def load():
 
 
 class Plane:
-    def __init__(self, engine, width, height):
+    def __init__(self, engine, width, height, bit_depth=8):
         self.engine = engine
-        self.width, self.height = width, height
+        self.width, self.height, self.bit_depth = width, height, bit_depth
         h = C.c_void_p()
-        engine._check(engine.L.hmme_plane_create(engine.h, width, height, C.byref(h)))
+        engine._check(engine.L.hmme_plane_create_ex(engine.h, width, height, bit_depth, C.byref(h)))
         self.h = h
 
     def upload_pel(self, padded, origin):
@@ -147,8 +149,8 @@ class Engine:
     def lambda_q16(self):
         return int(self.L.hmme_get_lambda_q16(self.h))
 
-    def plane(self, width, height):
-        return Plane(self, width, height)
+    def plane(self, width, height, bit_depth=8):
+        return Plane(self, width, height, bit_depth)
 
     def search_ctu(self, cur_plane, cur_xy, ref_plane, ref_xy, params):
         """per-CTU drop-in (calcMotionVectors).  planes: 2-D int16; *_xy = CTU origin inside them.
@@ -163,8 +165,9 @@ class Engine:
                                            mv.ctypes.data, sad.ctypes.data))
         return mv, sad
 
-    def search_frame(self, cur, ref, sr, pred_q=None, fen=1, bit_depth=8, ctu_first=0, ctu_count=-1):
+    def search_frame(self, cur, ref, sr, pred_q=None, fen=1, bit_depth=None, ctu_first=0, ctu_count=-1):
         """-> (mv int16[count,593,2], sad uint32[count,593])"""
+        bit_depth = cur.bit_depth if bit_depth is None else bit_depth
         n = self.L.hmme_num_ctus(cur.width, cur.height)
         count = n - ctu_first if ctu_count < 0 else ctu_count
         fp = FrameParams(sr, int(fen), bit_depth, ctu_first, count)

@@ -45,7 +45,7 @@ extern "C" {
 
 #define HMME_NUM_CTU_PARTS 593 /* TLibCommon/TypeDef.h:263 */
 #define HMME_CTU_SIZE 64
-#define HMME_MAX_SEARCH_RANGE 64 /* window side (2*SR+1) <= 129 in this build */
+#define HMME_MAX_SEARCH_RANGE 128 /* 8-bit path: SR <= 64 (window 129^2); 16-bit path (bit depth 9..12): SR <= 128 */
 
 enum {
   HMME_OK = 0,
@@ -65,7 +65,7 @@ typedef struct hmme_search_params {
   int rb_x, rb_y;      /* cMvSrchRngRB, inclusive */
   int pred_x, pred_y;  /* m_pcRdCost->setPredictor(*pcMvPred), quarter pels (TEncSearch.cpp:3737) */
   int fen;             /* m_pcEncCfg->getUseFastEnc() (TEncSearch.cpp:3853-3859) */
-  int bit_depth;       /* 8 in this build */
+  int bit_depth;       /* 8 (packed-byte path) or 9..12 (16-bit path): SAD >> (bitDepth-8), TComRdCost.cpp:520-521 */
 } hmme_search_params;
 
 /* one whole-picture search: window derived per CTU from the predictor exactly like
@@ -101,11 +101,13 @@ int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
                     int ref_stride, const hmme_search_params* p, int16_t* out_mv, uint32_t* out_sad);
 
 /* ---- frame path ------------------------------------------------------------------------ */
-/* device-resident 8-bit luma plane with edge-replicated margins */
-int hmme_plane_create(hmme_ctx* ctx, int width, int height, hmme_plane** out);
+/* device-resident luma plane with edge-replicated margins; 8-bit planes store bytes, 9..12-bit planes u16 */
+int hmme_plane_create(hmme_ctx* ctx, int width, int height, hmme_plane** out);   /* 8-bit */
+int hmme_plane_create_ex(hmme_ctx* ctx, int width, int height, int bit_depth, hmme_plane** out);
 void hmme_plane_destroy(hmme_plane* plane);
 /* upload the width x height picture area of an HM plane (origin = sample (0,0)); borders are
- * re-extended on the device like TComPicYuv::extendPicBorder */
+ * re-extended on the device like TComPicYuv::extendPicBorder.  Samples outside [0, 2^bitDepth) are
+ * rejected with HMME_ERR_RANGE */
 int hmme_plane_upload_pel(hmme_plane* plane, const int16_t* origin, int stride);
 int hmme_plane_upload_u8(hmme_plane* plane, const uint8_t* origin, int stride);
 /* device-side producers (e.g. a torch tensor): copy a width x height u8 image that already
@@ -113,6 +115,7 @@ int hmme_plane_upload_u8(hmme_plane* plane, const uint8_t* origin, int stride);
 int hmme_plane_set_device_u8(hmme_plane* plane, const void* d_src, int src_pitch, void* stream);
 int hmme_plane_width(const hmme_plane* plane);
 int hmme_plane_height(const hmme_plane* plane);
+int hmme_plane_bit_depth(const hmme_plane* plane);
 
 /* number of CTUs (partial edge CTUs included) of a width x height picture */
 int hmme_num_ctus(int width, int height);

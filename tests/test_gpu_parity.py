@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def engine():
     from hmme import api
-    e = api.Engine(0, 64)
+    e = api.Engine(0, 128)
     yield e
     e.close()
 
@@ -32,10 +32,8 @@ def test_search_ctu_matches_reference_goldens(engine, fname):
     from hmme import api
     n = 0
     for i, m, cur, ref, want in _golden_cases(fname):
-        if m["bit_depth"] != 8:
-            continue
-        engine.set_lambda_q16(m["lambda_q16"])
-        p = api.SearchParams(m["lt_x"], m["lt_y"], m["rb_x"], m["rb_y"], m["pred_x"], m["pred_y"], m["fen"], 8)
+        engine.set_lambda_q16(m["lambda_q16"])   # 8-bit cases run the packed-byte kernel, 10-bit ones the 16-bit kernel
+        p = api.SearchParams(m["lt_x"], m["lt_y"], m["rb_x"], m["rb_y"], m["pred_x"], m["pred_y"], m["fen"], m["bit_depth"])
         mv, sad = engine.search_ctu(cur, (0, 0), ref, (m["origin_x"], m["origin_y"]), p)
         assert np.array_equal(mv.astype(np.int64), want[:, :2]), f"{fname} case {i}: MV mismatch"
         assert np.array_equal(sad.astype(np.int64), want[:, 2]), f"{fname} case {i}: SAD mismatch"
@@ -146,9 +144,12 @@ def test_error_behaviour(engine):
     bad = api.SearchParams(-70, -8, 70, 8, 0, 0, 1, 8)           # window wider than sr_max
     with pytest.raises(api.HmmeError, match="window"):
         engine.search_ctu(cur, (0, 0), ref, (18, 18), bad)
-    p10 = api.SearchParams(-8, -8, 8, 8, 0, 0, 1, 10)
+    p14 = api.SearchParams(-8, -8, 8, 8, 0, 0, 1, 14)
     with pytest.raises(api.HmmeError, match="bit depth"):
-        engine.search_ctu(cur, (0, 0), ref, (18, 18), p10)
+        engine.search_ctu(cur, (0, 0), ref, (18, 18), p14)
+    wide8 = api.SearchParams(-100, -8, 100, 8, 0, 0, 1, 8)          # SR > 64 exists on the 16-bit path only
+    with pytest.raises(api.HmmeError, match="window"):
+        engine.search_ctu(cur, (0, 0), np.zeros((100, 300), np.int16), (118, 18), wide8)
     cur2 = cur.copy(); cur2[5, 5] = 300                             # bi-pred style origin outside [0,255]
     p = api.SearchParams(-8, -8, 8, 8, 0, 0, 1, 8)
     with pytest.raises(api.HmmeError, match="outside"):
@@ -215,3 +216,66 @@ def test_cpp_host_module_tencopencl(oracle_lib):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "PASS" in r.stdout
+
+
+def test_16bit_path_random_windows_vs_oracle(engine, oracle_lib):
+    """bit depth 10 / 12 (v_sad_u16 kernel): ragged windows up to SR 128, FEN 0/1, strips"""
+    from hmme import api
+    rng = np.random.default_rng(1010)
+    for it in range(14):
+        bd = int(rng.choice([10, 10, 12, 9]))
+        sr = int(rng.choice([2, 8, 33, 64, 100, 128]))
+        side = 64 + 2 * sr + 8
+        cur = rng.integers(0, 1 << bd, size=(64, 64)).astype(np.int16)
+        ref = rng.integers(0, 1 << bd, size=(side, side)).astype(np.int16)
+        o = sr + 4
+        if it % 3 == 2:   # planted motion
+            dx, dy = int(rng.integers(-min(sr, 9), min(sr, 9) + 1)), int(rng.integers(-min(sr, 9), min(sr, 9) + 1))
+            cur = ref[o + dy:o + dy + 64, o + dx:o + dx + 64].copy()
+        lt = (-int(rng.integers(0, sr + 1)), -int(rng.integers(0, sr + 1)))
+        rb = (int(rng.integers(0, sr + 1)), int(rng.integers(0, sr + 1)))
+        if it % 4 == 0:
+            lt, rb = (-sr, -sr), (sr, sr)
+        pred = (int(rng.integers(-80, 81)), int(rng.integers(-80, 81)))
+        fen = int(rng.integers(0, 2))
+        lam = float(rng.choice([0.0, 57.9, 900.0, 6.0e6]))
+        lq = oracle_lib.oracle().hmo_lambda_q16(lam)
+        engine.set_lambda(lam)
+        p = api.SearchParams(lt[0], lt[1], rb[0], rb[1], pred[0], pred[1], fen, bd)
+        mv, sad = engine.search_ctu(cur, (0, 0), ref, (o, o), p)
+        ox, oy, osad = oracle_lib.search_ctu(cur, (0, 0), ref, (o, o), oracle_lib.make_params(lt, rb, pred, lq, fen, bd))
+        assert np.array_equal(mv[:, 0], ox) and np.array_equal(mv[:, 1], oy), f"iter {it} (bd {bd}, sr {sr}): MV mismatch"
+        assert np.array_equal(sad, osad), f"iter {it}: SAD mismatch"
+
+
+@pytest.mark.parametrize("w,h,sr,fen", [(200, 136, 16, 1), (256, 192, 64, 1), (192, 128, 128, 0)])
+def test_search_frame_10bit_vs_oracle(engine, oracle_lib, w, h, sr, fen):
+    """BASELINE config 5 shape in small: 10-bit planes, SR up to 128 (window strips merged through global atomics)"""
+    from hmme import synth
+    cur, ref, _ = synth.make_pair(w, h, seed=w + sr, bit_depth=10, max_mv=min(sr, 12), region=64)
+    n_ctu = ((w + 63) // 64) * ((h + 63) // 64)
+    pred = synth.random_predictors(n_ctu, seed=4, max_pel=min(sr, 24))
+    lq = oracle_lib.oracle().hmo_lambda_q16(238.5)
+    engine.set_lambda(238.5)
+    m = synth.MARGIN
+    pc, pr = engine.plane(w, h, 10), engine.plane(w, h, 10)
+    pc.upload_pel(cur, (m, m)); pr.upload_pel(ref, (m, m))
+    mv, sad = engine.search_frame(pc, pr, sr, pred, fen=fen)
+    pc.close(); pr.close()
+    ox, oy, osad = oracle_lib.search_frame(cur, ref, (m, m), w, h, sr, pred, lq, fen, 10, n_threads=8)
+    assert np.array_equal(mv[:, :, 0], ox) and np.array_equal(mv[:, :, 1], oy)
+    assert np.array_equal(sad, osad)
+
+
+def test_plane_bit_depth_mismatch_is_an_error(engine):
+    from hmme import api
+    p8, p10 = engine.plane(64, 64), engine.plane(64, 64, 10)
+    p8.upload_u8(np.zeros((64, 64), np.uint8))
+    p10.upload_pel(np.full((64, 64), 1000, np.int16), (0, 0))
+    with pytest.raises(api.HmmeError, match="outside"):
+        p10.upload_pel(np.full((64, 64), 1024, np.int16), (0, 0))
+    with pytest.raises(api.HmmeError, match="bit"):
+        engine.search_frame(p8, p10, 8)
+    with pytest.raises(api.HmmeError, match="search range"):
+        engine.search_frame(p8, p8, 100)          # SR > 64 needs the 16-bit path
+    p8.close(); p10.close()

@@ -94,3 +94,63 @@ def test_generated_tree_reproduces_reference_goldens(case):
     got = model_search(tree, cur, ref, (m["origin_x"], m["origin_y"]), (m["lt_x"], m["lt_y"]), (m["rb_x"], m["rb_y"]),
                        (m["pred_x"], m["pred_y"]), m["lambda_q16"])
     assert np.array_equal(got, d["out"][case])
+
+
+def model_search16(tree, cur, ref, origin, lt, rb, pred, lq, bit_depth, iters_per_task=2):
+    """python model of me_search16_kernel (16-bit samples, 2 candidates per lane, linear lane packing)"""
+    sh = bit_depth - 8
+    wx, wy = rb[0] - lt[0] + 1, rb[1] - lt[1] + 1
+    ox, oy = origin[0] + lt[0], origin[1] + lt[1]
+    pitch = 2 * ((wx + 63 + 2 + 1) // 2) + 2
+    win = np.zeros((wy + 63, pitch), np.uint16)
+    w = ref[oy:oy + wy + 63, ox:ox + min(pitch, ref.shape[1] - ox)]
+    win[:w.shape[0], :w.shape[1]] = w
+    slot_of = tree.slot_of_lane()
+    best64 = np.full(593, (1 << 64) - 1, dtype=np.uint64)
+    lanes = np.arange(64)
+    P = (wx + 1) // 2
+    iters = (wy * P + 63) // 64
+    for it0 in range(0, iters, iters_per_task):
+        best = np.full((G.N_GROUPS, 64), 0xFFFFFFFF, np.uint32)
+        for it in range(min(iters_per_task, iters - it0)):
+            q = (it0 + it) * 64 + lanes
+            cy, cx = q // P, 2 * (q % P)
+            c = np.zeros((2, 64), np.uint32)
+            for l in range(64):
+                by = cbits(((lt[1] + int(cy[l])) << 2) - pred[1])
+                for j in range(2):
+                    cost = ((lq * (cbits(((lt[0] + int(cx[l]) + j) << 2) - pred[0]) + by)) & 0xFFFFFFFF) >> 16
+                    valid = cy[l] < wy and cx[l] + j < wx
+                    c[j, l] = ((cost if valid else INV) << IDX) | (it << 8) | (l << 2) | j
+            lane_off = np.minimum(cy, wy - 1) * pitch + cx
+            G.simulate16(tree, win, cur, lane_off, c, best, sh)
+        for g in range(G.N_GROUPS):
+            for l in range(64):
+                s, key = slot_of[g, l], int(best[g, l])
+                cost = key >> IDX
+                if s < 0 or cost >= INV:
+                    continue
+                kit, kl, kj = (key >> 8) & 3, (key >> 2) & 63, key & 3
+                q = (it0 + kit) * 64 + kl
+                v = np.uint64((cost << 32) | ((q // P) << 16) | (2 * (q % P) + kj))
+                if v < best64[s]:
+                    best64[s] = v
+    out = np.zeros((593, 3), np.int64)
+    for s in range(593):
+        v = int(best64[s])
+        mvx, mvy = lt[0] + (v & 0xffff), lt[1] + ((v >> 16) & 0xffff)
+        mvc = ((lq * (cbits((mvx << 2) - pred[0]) + cbits((mvy << 2) - pred[1]))) & 0xFFFFFFFF) >> 16
+        out[s] = (mvx, mvy, (v >> 32) - mvc)
+    return out
+
+
+@pytest.mark.parametrize("case", [3, 4, 11, 15, 0, 1, 5, 10])
+def test_generated_16bit_tree_reproduces_reference_goldens(case):
+    """10-bit goldens through the 16-bit tree; 8-bit goldens too (shift 0 must also be exact)"""
+    d = np.load(os.path.join(GOLDEN, "search_sr8.npz"))
+    m = dict(zip(d["meta_columns"].tolist(), (int(v) for v in d["meta"][case])))
+    tree = G.Tree16(m["fen"]).build()
+    got = model_search16(tree, d["cur"][case].astype(np.uint16), d["ref"][case].astype(np.uint16),
+                         (m["origin_x"], m["origin_y"]), (m["lt_x"], m["lt_y"]), (m["rb_x"], m["rb_y"]),
+                         (m["pred_x"], m["pred_y"]), m["lambda_q16"], m["bit_depth"])
+    assert np.array_equal(got, d["out"][case])

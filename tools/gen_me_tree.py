@@ -67,6 +67,9 @@ def slot_2Nx2N(s, cx, cy):
     return BASE_2Nx2N[s] + cy * n + cx
 
 
+LOAD_OPS = ("LDS", "CURLD", "BASE", "LDS16", "CURLD16")
+
+
 class Tree:
     """builds the op list for one lane-iteration"""
 
@@ -194,9 +197,9 @@ class Tree:
                                 start = len(self.ops)
                                 cus.append(self.level0(qx * 4 + rx * 2 + cx, qy * 4 + ry * 2 + cy, cx, cy))
                                 new = self.ops[start:]
-                                self.cu_loads.append([o for o in new if o[0] in ("LDS", "CURLD", "BASE")])
+                                self.cu_loads.append([o for o in new if o[0] in LOAD_OPS])
                                 self.ops[start:] = [("LOADS_FOR", len(self.cu_loads))] + \
-                                    [o for o in new if o[0] not in ("LDS", "CURLD", "BASE")]
+                                    [o for o in new if o[0] not in LOAD_OPS]
                         regions.append(self.level1(qx * 2 + rx, qy * 2 + ry, rx, ry, cus, U))
                 quads.append(self.level2(qx, qy, regions))
         self.level3(quads)
@@ -329,6 +332,94 @@ class Tree:
         return t
 
 
+class Tree16(Tree):
+    """Reduction tree of the 16-bit sample path (10-bit video; later bi-pred int16 origins).
+
+    A lane owns TWO horizontally adjacent candidates (x even, x+1) and every value is a pair of exact
+    32-bit sums: HM applies `>> (bitDepth-8)` to the whole-PU sum *after* the FEN `<< 1`
+    (TComRdCost.cpp:520-521), which is a floor and therefore not linear -- no key linearity, no u16
+    packing; each slot's key is formed from its own exact sum:
+        key_j = ((S_j & MASK_f) << LSH_f) + C_j      (v_and_b32 + v_lshl_add_u32)
+    Leaves are v_sad_u16 (2 samples per op); the odd candidate's dwords come from v_alignbit_b32."""
+
+    def block16(self, cx8, cy8):
+        """-> [(E, A)] for the 4 blocks TL, TR, BL, BR of the CU; E/A are 2-candidate sum pairs"""
+        out = []
+        rows = {}
+        for r in range(8):
+            row = cy8 * 8 + r
+            d = []
+            for i in range(5):
+                v = self.new("d")
+                self.ops.append(("LDS16", v, row, 4 * cx8 + i))
+                d.append(v)
+            w = self.new("w")
+            self.ops.append(("CURLD16", w, row, cx8))
+            o = []
+            for i in range(4):
+                v = self.new("o")
+                self.ops.append(("ALIGN16", v, d[i + 1], d[i]))
+                o.append(v)
+            rows[r] = (d, o, w)
+        for by in range(2):
+            for bl in range(2):
+                def chain(r, acc):
+                    d, o, w = rows[by * 4 + r]
+                    v = self.new("s")
+                    self.ops.append(("SAD16x2", v, d[2 * bl], d[2 * bl + 1], o[2 * bl], o[2 * bl + 1], w, 2 * bl, acc,
+                                     cy8 * 8 + by * 4 + r, cx8 * 8 + bl * 4))
+                    return v
+                if self.fen:
+                    e = chain(2, chain(0, None))
+                    a = chain(3, chain(1, e))
+                    out.append((e, a))
+                else:
+                    a = chain(3, chain(2, chain(1, chain(0, None))))
+                    out.append((a, a))
+        return out
+
+    def level0(self, cx8, cy8, cx, cy):
+        self._blocks = self.block16(cx8, cy8)
+        self._next_block = 0
+        return Tree.level0(self, cx8, cy8, cx, cy)
+
+    def block(self, bx, by):
+        b = self._blocks[self._next_block]   # level0 asks for TL, TR, BL, BR in this order
+        self._next_block += 1
+        return b
+
+    def pkadd(self, a, b):
+        v = self.new("p")
+        self.ops.append(("ADD2", v, a, b))
+        return v
+
+    def pksub(self, a, b):
+        v = self.new("p")
+        self.ops.append(("SUB2", v, a, b))
+        return v
+
+    # "keys" stay exact sums tagged with their family until they are emitted
+    def keys(self, p, fam):
+        return (p, fam)
+
+    def lin(self, a, b):
+        assert a[1] == b[1]
+        return (self.pkadd(a[0], b[0]), a[1])
+
+    def sub(self, a, b):
+        assert a[1] == b[1]
+        return (self.pksub(a[0], b[0]), a[1])
+
+    def emit(self, slot, k):
+        r = self.new("r")
+        self.ops.append(("KEYMIN2", r, k[0], k[1]))
+        self._push(slot, r)
+
+    def build(self):
+        Tree.build(self)
+        return self
+
+
 # =====================================================================================================
 # C++ emitter
 # =====================================================================================================
@@ -340,8 +431,16 @@ HEADER = """// GENERATED by tools/gen_me_tree.py -- do not edit.  One lane-itera
 """
 
 
-def emit_cpp(tree, path):
-    o = [HEADER % tree.fen]
+HEADER16 = """// GENERATED by tools/gen_me_tree.py -- do not edit.  One lane-iteration of the 16-bit-sample
+// reduction tree (fen=%d): two candidates (x even, x+1) per lane, exact 32-bit sums, v_sad_u16 leaves.
+// Expects in scope: lpv (per-lane volatile LDS dword pointer at the even candidate, window row 0),
+// ME16_PDW (window pitch in dwords), curv4 (volatile LDS copy of the 64x64 current block, u32x4[64][8]),
+// c0, c1, mask_a/lsh_a/mask_e/lsh_e, b0..b9, rb1, rb0 and the me_merge* helpers.
+"""
+
+
+def emit_cpp(tree, path, header=None):
+    o = [(header or HEADER) % tree.fen]
     max_declared = False
     for op in tree.ops:
         t = op[0]
@@ -380,6 +479,25 @@ def emit_cpp(tree, path):
             o.append(f"const uint32_t {m} = me_merge{level}({a}, {b}{'' if level < 4 else f', rb{5 - level}'});")
         elif t == "ACC":
             o.append(f"b{op[1]} = min(b{op[1]}, {op[2]});")
+        elif t == "LDS16":
+            o.append(f"const uint32_t {op[1]} = lpv[{op[2]} * ME16_PDW + {op[3]}];")
+        elif t == "CURLD16":
+            o.append(f"const u32x4_t {op[1]} = curv4[{op[2] * 8 + op[3]}];")
+        elif t == "ALIGN16":
+            o.append(f"const uint32_t {op[1]} = __builtin_amdgcn_alignbit({op[2]}, {op[3]}, 16);")
+        elif t == "SAD16x2":
+            _, v, d0, d1, o0, o1, w, wi, acc, row, col = op
+            a0 = f"{acc}_0" if acc else "0u"
+            a1 = f"{acc}_1" if acc else "0u"
+            o.append(f"const uint32_t {v}_0 = ME_SAD16({d1}, {w}[{wi + 1}], ME_SAD16({d0}, {w}[{wi}], {a0})), "
+                     f"{v}_1 = ME_SAD16({o1}, {w}[{wi + 1}], ME_SAD16({o0}, {w}[{wi}], {a1}));")
+        elif t == "ADD2":
+            o.append(f"const uint32_t {op[1]}_0 = {op[2]}_0 + {op[3]}_0, {op[1]}_1 = {op[2]}_1 + {op[3]}_1;")
+        elif t == "SUB2":
+            o.append(f"const uint32_t {op[1]}_0 = {op[2]}_0 - {op[3]}_0, {op[1]}_1 = {op[2]}_1 - {op[3]}_1;")
+        elif t == "KEYMIN2":
+            f_ = "e" if op[3] == "E" else "a"
+            o.append(f"const uint32_t {op[1]} = min((({op[2]}_0 & mask_{f_}) << lsh_{f_}) + c0, (({op[2]}_1 & mask_{f_}) << lsh_{f_}) + c1);")
         else:
             raise ValueError(t)
     with open(path, "w") as f:
@@ -416,6 +534,54 @@ LEVEL_ROLE_BIT = [3, 2, 5, 4, 1, 0]
 def _perm_level(level):
     """lane permutation and role bit of butterfly level 0..5"""
     return LANES ^ LEVEL_XOR[level], (LANES >> LEVEL_ROLE_BIT[level]) & 1
+
+
+def simulate16(tree, window, cur, lane_off, c, best, sh):
+    """interpret one lane-iteration of a Tree16.  window: (rows, pitch_samples) uint16 LDS image;
+    cur: (64,64) uint16; lane_off[l] = sample index of lane l's even candidate at window row 0;
+    c: (2, 64) uint32; sh = bit_depth - 8."""
+    flat = np.concatenate([window.reshape(-1), np.zeros(64, window.dtype)]).astype(np.int64)
+    pitch = window.shape[1]
+    mask = {"A": ~((1 << sh) - 1), "E": ~((1 << max(sh - 1, 0)) - 1) if tree.fen else ~((1 << sh) - 1)}
+    lsh = {"A": IDX_BITS - sh, "E": (IDX_BITS + 1 - sh) if tree.fen else IDX_BITS - sh}
+    val = {}
+    MAXK = np.full(64, 0xFFFFFFFF, np.uint32)
+    for op in tree.ops:
+        t = op[0]
+        if t == "LDS16":       # dword k of row = samples 2k, 2k+1 (relative to the lane's even candidate)
+            idx = lane_off + op[2] * pitch + 2 * op[3]
+            val[op[1]] = np.stack([flat[idx], flat[idx + 1]], axis=1)
+        elif t == "CURLD16":
+            val[op[1]] = cur[op[2], op[3] * 8:op[3] * 8 + 8].astype(np.int64).reshape(4, 2)
+        elif t == "ALIGN16":   # (hi, lo) >> 16 : samples (lo.hi, hi.lo)
+            val[op[1]] = np.stack([val[op[3]][:, 1], val[op[2]][:, 0]], axis=1)
+        elif t == "SAD16x2":
+            _, v, d0, d1, o0, o1, w, wi, acc, row, col = op
+            cw = val[w]
+            e = np.abs(val[d0] - cw[wi][None, :]).sum(axis=1) + np.abs(val[d1] - cw[wi + 1][None, :]).sum(axis=1)
+            od = np.abs(val[o0] - cw[wi][None, :]).sum(axis=1) + np.abs(val[o1] - cw[wi + 1][None, :]).sum(axis=1)
+            res = np.stack([e, od], axis=1)
+            if acc:
+                res = res + val[acc]
+            val[v] = res
+        elif t == "ADD2":
+            val[op[1]] = val[op[2]] + val[op[3]]
+        elif t == "SUB2":
+            val[op[1]] = val[op[2]] - val[op[3]]
+        elif t == "KEYMIN2":
+            k = ((val[op[2]] & mask[op[3]]) << lsh[op[3]]) + c.T.astype(np.int64)
+            val[op[1]] = k.min(axis=1).astype(np.uint32)
+        elif t == "MERGE":
+            _, level, m, a, b = op
+            A = val[a] if a is not None else MAXK
+            B = val[b] if b is not None else MAXK
+            perm, role = _perm_level(level)
+            val[m] = np.minimum(np.where(role == 1, B, A), np.where(role == 1, A, B)[perm])
+        elif t == "ACC":
+            best[op[1]] = np.minimum(best[op[1]], val[op[2]])
+        else:
+            raise ValueError(t)
+    return best
 
 
 def simulate(tree, window, cur, lane_off, c, best):
@@ -493,6 +659,14 @@ def main():
         else:
             ref_map = tree.slot_of_lane()
     assert np.array_equal(ref_map, Tree(1).build().slot_of_lane()), "slot map must not depend on fen"
+    for fen in (0, 1):
+        t16 = Tree16(fen).build()
+        assert np.array_equal(ref_map, t16.slot_of_lane()), "the 16-bit tree must use the same slot map"
+        emit_cpp(t16, os.path.join(OUT_DIR, f"me_tree16_fen{fen}.inc"), HEADER16)
+        counts = {}
+        for op in t16.ops:
+            counts[op[0]] = counts.get(op[0], 0) + 1
+        print(f"16-bit fen={fen}: {len(t16.ops)} IR ops {counts}")
 
 
 if __name__ == "__main__":
