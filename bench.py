@@ -26,7 +26,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "hm-opencl_amd"))
 
 SIZES = {"2160p": (3840, 2160), "1080p": (1920, 1080)}
-ALGO_BYTES_PER_CTU = 64 * 64 + 192 * 192 + 593 * 8   # CTU + (64+2SR)^2 window + results, u8, SR=64
+
+
+def algo_bytes_per_ctu(sr, bit_depth):
+    """B_px * (64*64 + (64+2SR)^2) + 593*8  (CTU + window + results)"""
+    return (1 if bit_depth == 8 else 2) * (64 * 64 + (64 + 2 * sr) ** 2) + 593 * 8
+
+
 HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 LAMBDA = 57.9                                          # fixed, recorded (SURVEY 8d)
 
@@ -78,7 +84,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(cur, ref, w, h, sr, lq, budget_s=14.0):
+def cpu_baseline(cur, ref, w, h, sr, lq, bd=8, budget_s=14.0):
     """oracle legs on this node's host cores, bounded sample of the same workload"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
@@ -89,15 +95,15 @@ def cpu_baseline(cur, ref, w, h, sr, lq, budget_s=14.0):
     first = ctus_x * 3            # start on the 4th CTU row: full interior CTUs
     # exhaustive search (same arithmetic and same work as the GPU kernel)
     n = cores
-    t0 = time.time(); O.search_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, 8, first, n, cores); dt = time.time() - t0
+    t0 = time.time(); O.search_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, bd, first, n, cores); dt = time.time() - t0
     n_full = max(cores, min(ctus_x * 16, int(n * (budget_s * 0.6) / max(dt, 1e-3)) // cores * cores))
-    t0 = time.time(); O.search_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, 8, first, n_full, cores); dt_full = time.time() - t0
+    t0 = time.time(); O.search_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, bd, first, n_full, cores); dt_full = time.time() - t0
     sads_full = n_full * 256 * (2 * sr + 1) ** 2
     # HM's default fast search (xTZSearch) over all 593 PU shapes of each CTU
     n_tz = cores * 4
-    t0 = time.time(); O.tz_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, 8, first, n_tz, cores, True); dt = time.time() - t0
+    t0 = time.time(); O.tz_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, bd, first, n_tz, cores, True); dt = time.time() - t0
     n_tz = max(cores, min(ctus_x * 28, int(n_tz * (budget_s * 0.3) / max(dt, 1e-3)) // cores * cores))
-    t0 = time.time(); probes, s4 = O.tz_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, 8, first, n_tz, cores, True); dt_tz = time.time() - t0
+    t0 = time.time(); probes, s4 = O.tz_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, bd, first, n_tz, cores, True); dt_tz = time.time() - t0
     return {
         "value": round(sads_full / dt_full / 1e9, 4), "unit": "GSAD/s", "cores": cores, "kind": "port",
         "sample": f"oracle exhaustive search (xPatternSearch restatement, all 593 PUs) of {n_full} interior CTUs of the "
@@ -116,6 +122,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", default="2160p", choices=sorted(SIZES))
     ap.add_argument("--search-range", type=int, default=64)
+    ap.add_argument("--bit-depth", type=int, default=8, help="8 = headline config; 10 + --search-range 128 = BASELINE config 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -140,16 +147,17 @@ def main():
 
     w, h = SIZES[args.size]
     sr = args.search_range
-    eng = api.Engine(local_rank, 64)
+    bd = args.bit_depth
+    eng = api.Engine(local_rank, 128)
     eng.set_lambda(LAMBDA)
     lq = eng.lambda_q16
     # frame shard: rank r searches frame pair r of the synthetic sequence (different seeds)
-    cur, ref, _ = synth.make_pair(w, h, seed=1234 + rank, bit_depth=8)
-    pc, pr = eng.plane(w, h), eng.plane(w, h)
+    cur, ref, _ = synth.make_pair(w, h, seed=1234 + rank, bit_depth=bd)
+    pc, pr = eng.plane(w, h, bd), eng.plane(w, h, bd)
     pc.upload_pel(cur, (synth.MARGIN, synth.MARGIN))
     pr.upload_pel(ref, (synth.MARGIN, synth.MARGIN))
     n_ctu = api.load().hmme_num_ctus(w, h)
-    fp = api.FrameParams(sr, 1, 8, 0, n_ctu)
+    fp = api.FrameParams(sr, 1, bd, 0, n_ctu)
     # one picture pair per rank and step: [pairs_per_rank = 1, n_ctu, 593(, 2)] blocks, see hmme/shard.py
     d_mv = torch.zeros((1, n_ctu, api.NUM_PARTS, 2), dtype=torch.int16, device=dev)
     d_sad = torch.zeros((1, n_ctu, api.NUM_PARTS), dtype=torch.int32, device=dev)
@@ -187,34 +195,35 @@ def main():
     if rank == 0:
         sads = work_4x4_sads(api, w, h, sr)
         total_sads = sads * world * args.steps
-        algo_bytes = ALGO_BYTES_PER_CTU * n_ctu
+        algo_bytes = algo_bytes_per_ctu(sr, bd) * n_ctu
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         # sanity: results of the last step vs a freshly computed host call on a few CTUs
         out = {
             "metric": "GSAD/s", "value": round(total_sads / elapsed / 1e9, 2), "unit": "GSAD/s (4x4-block SAD evaluations)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u8" if bd == 8 else "u16", "data": "synthetic",
             "ctus_per_s": round(n_ctu * world * args.steps / elapsed, 1),
-            "config": {"workload": f"{w}x{h} 8-bit luma, lowdelay_P_main (FEN=1), SearchRange={sr}, CTU=64, exhaustive "
+            "config": {"workload": f"{w}x{h} {bd}-bit luma, lowdelay_P_main{'' if bd == 8 else '10'} (FEN=1), SearchRange={sr}, CTU=64, exhaustive "
                                    f"integer search of all 593 PU shapes, 1 reference picture, {n_ctu} CTUs per frame",
                        "frames_per_step": world, "parallelism": f"frame-shard x{world}", "lambda": LAMBDA,
                        "sads_4x4_per_frame": sads},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args.size, sr),
-                         "kernel": "me_search_kernel<1>", "kernel_ms": round(kernel_ms, 4),
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args.size, sr) if bd == 8 else None,
+                         "kernel": "me_search_kernel<1>" if bd == 8 else "me_search16_kernel<1,*> (+ finalize)",
+                         "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "kernel is VALU-bound (1664 abs-diff ops per unique input byte, SURVEY 8d); "
                                  "see DESIGN.md for the VALU-issue roofline"},
         }
-        prof = pmc_profile(args.size, sr)
+        prof = pmc_profile(args.size, sr) if bd == 8 else {}
         if prof.get("valu_busy_frac") is not None:   # what actually binds: integer VALU issue
             out["valu_roofline"] = {"bound": "valu-issue", "valu_busy_frac": round(prof["valu_busy_frac"], 4),
                                     "valu_wave_instructions_per_launch": int(prof["valu_wave_instructions_per_launch"]),
                                     "effective_clock_ghz": round(prof.get("effective_clock_ghz", 0.0), 3),
                                     "source": "profiles/latest_pmc_%s_sr%d.json (rocprofv3 --pmc passes of this command)" % (args.size, sr)}
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cur, ref, w, h, sr, lq)
+            out["cpu_baseline"] = cpu_baseline(cur, ref, w, h, sr, lq, bd)
         print(json.dumps(out), flush=True)
     pc.close(); pr.close(); eng.close()
     if world > 1:
