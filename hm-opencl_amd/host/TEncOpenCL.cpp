@@ -2,19 +2,23 @@
 #include "TEncOpenCL.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/hmme.h"
 
 TEncOpenCL::TEncOpenCL()
     : m_ctx(0), m_deviceId(0), m_deviceFound(false), m_enabled(false), m_lastOk(false), m_searchRange(0),
-      m_mode(ME_MODE_OCL_COMPAT), m_fen(false), m_bitDepth(8), m_lambda(0.0) {
+      m_mode(ME_MODE_OCL_COMPAT), m_fen(false), m_bitDepth(8), m_lambda(0.0), m_calls(0), m_failed(0) {
   std::memset(m_x, 0, sizeof m_x);
   std::memset(m_y, 0, sizeof m_y);
   std::memset(m_ruiCosts, 0, sizeof m_ruiCosts);
 }
 
 TEncOpenCL::~TEncOpenCL() {
+  if (std::getenv("HMME_TRACE"))   // one summary line for A/B harnesses (tests/test_hm_dropin.py)
+    fprintf(stderr, "TEncOpenCL(hmme): %ld calcMotionVectors calls, %ld failed, device: %s\n", m_calls, m_failed,
+            m_ctx ? hmme_device_info(m_ctx) : "none");
   if (m_ctx) hmme_destroy(m_ctx);
   m_ctx = 0;
 }
@@ -61,6 +65,8 @@ Void TEncOpenCL::setLambda(Double lambda) {   // reference TEncOpenCL.h:121
 Void TEncOpenCL::calcMotionVectors(Pel* pelCtu, Pel* pelSearch, Int iRefStride, Int iCtuStride, Int i_areaSize,
                                    TComMv* pcMvSrchRngLT) {
   m_lastOk = false;
+  ++m_calls;
+  ++m_failed;
   if (!m_ctx) {
     fprintf(stderr, "ERROR: TEncOpenCL::calcMotionVectors called without a device context\n");
     return;
@@ -87,4 +93,5 @@ Void TEncOpenCL::calcMotionVectors(Pel* pelCtu, Pel* pelSearch, Int iRefStride, 
     m_y[i] = m_mv[i].getVer();
   }
   m_lastOk = true;
+  --m_failed;
 }

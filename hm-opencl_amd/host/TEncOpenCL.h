@@ -67,6 +67,7 @@ class TEncOpenCL {
   Bool m_fen;
   Int m_bitDepth;
   Double m_lambda;
+  long m_calls, m_failed;
   Int m_x[NUM_CTU_PARTS], m_y[NUM_CTU_PARTS];
   Distortion m_ruiCosts[NUM_CTU_PARTS];
   TComMv m_mv[NUM_CTU_PARTS];
