@@ -58,10 +58,14 @@ def gather_pair_results(local_mv, local_sad, n_pairs):
     mv_shape = tuple(local_mv.shape)
     local_mv = local_mv.contiguous().view(torch.int32)
     # concatenated layout (world * k, ...): accepted by both the RCCL and the gloo implementation
+    dev = local_mv.device
+    if dist.get_backend() == "gloo" and dev.type != "cpu":   # rehearsal of the N > 1 path without RCCL: stage on host
+        local_mv, local_sad = local_mv.cpu(), local_sad.cpu()
     g_mv = torch.empty((world * k,) + tuple(local_mv.shape[1:]), dtype=local_mv.dtype, device=local_mv.device)
     g_sad = torch.empty((world * k,) + tuple(local_sad.shape[1:]), dtype=local_sad.dtype, device=local_sad.device)
     dist.all_gather_into_tensor(g_mv, local_mv.contiguous())
     dist.all_gather_into_tensor(g_sad, local_sad.contiguous())
+    g_mv, g_sad = g_mv.to(dev), g_sad.to(dev)
     g_mv = g_mv.view((world, k) + tuple(local_mv.shape[1:]))
     g_sad = g_sad.view((world, k) + tuple(local_sad.shape[1:]))
     # block [r, i] holds pair i * world + r
@@ -69,6 +73,26 @@ def gather_pair_results(local_mv, local_sad, n_pairs):
     mv = mv.reshape((k * world,) + mv_shape[1:])[:n_pairs]
     sad = g_sad.transpose(0, 1).reshape((k * world,) + tuple(local_sad.shape[1:]))[:n_pairs]
     return mv, sad
+
+
+def gather_packed(buf, out=None, async_op=False):
+    """one collective for both result tables.  buf: int32 [2, k, n_ctu, 593] (plane 0 = TComMv words,
+    plane 1 = SADs) of this rank; returns (out int32 [world, 2, k, n_ctu, 593], work-or-None).
+    With async_op=True the gather runs on RCCL's stream while the caller launches the next search
+    (the handle's wait() is a stream-side dependency, not a host block)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return buf.unsqueeze(0), None
+    if out is None:
+        out = torch.empty((world,) + tuple(buf.shape), dtype=buf.dtype, device=buf.device)
+    flat_out = out.view((world * buf.shape[0],) + tuple(buf.shape[1:]))
+    if dist.get_backend() == "gloo" and buf.device.type != "cpu":   # rehearsal path: stage on the host
+        tmp = torch.empty(flat_out.shape, dtype=buf.dtype)
+        dist.all_gather_into_tensor(tmp, buf.cpu())
+        flat_out.copy_(tmp)
+        return out, None
+    work = dist.all_gather_into_tensor(flat_out, buf, async_op=async_op)
+    return out, work
 
 
 def search_sequence(search_pair, n_pairs, n_ctu, device):
