@@ -315,15 +315,29 @@ int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
   if (!ctx) return HMME_ERR_ARG;
   if (!ctu || !ref0 || !p || !out_mv || !out_sad) return fail(ctx, HMME_ERR_ARG, "hmme_search_ctu: null argument");
   if (p->bit_depth < 8 || p->bit_depth > 12) return fail(ctx, HMME_ERR_UNSUPPORTED, "bit depth %d outside 8..12", p->bit_depth);
-  const bool wide = p->bit_depth > 8;
-  const int sr_cap = wide ? ctx->sr_max : (ctx->sr_max < 64 ? ctx->sr_max : 64);
+  const int maxv = (1 << p->bit_depth) - 1;
+  // samples outside [0, maxv] are the bi-prediction origin 2*org - pred_other (reference TEncSearch.cpp:3702-3712,
+  // TComYuv::removeHighFreq TComYuv.cpp:409-440, unclipped).  They stay exact: the 16-bit kernel runs on samples
+  // biased by 2^bitDepth (|a - b| is unchanged), so pick the kernel after looking at the data.
+  int lo = 0, hi = 0;
+  for (int y = 0; y < 64; ++y)
+    for (int x = 0; x < 64; ++x) {
+      const int v = ctu[y * ctu_stride + x];
+      lo = v < lo ? v : lo; hi = v > hi ? v : hi;
+    }
   const int wx = p->rb_x - p->lt_x + 1, wy = p->rb_y - p->lt_y + 1;
+  const bool bipred_origin = lo < 0 || hi > maxv;
+  if (lo < -maxv || hi > 2 * maxv)
+    return fail(ctx, HMME_ERR_RANGE, "hmme_search_ctu: current-block sample outside [%d, %d] (bit depth %d)", -maxv, 2 * maxv, p->bit_depth);
+  const bool wide = p->bit_depth > 8 || bipred_origin;
+  const int bias = bipred_origin ? (1 << p->bit_depth) : 0;
+  const int sr_cap = wide ? ctx->sr_max : (ctx->sr_max < 64 ? ctx->sr_max : 64);
   if (wx < 1 || wy < 1 || wx > 2 * sr_cap + 1 || wy > 2 * sr_cap + 1)
     return fail(ctx, HMME_ERR_ARG, "window %dx%d outside 1..%d", wx, wy, 2 * sr_cap + 1);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   // pack CTU and window in pinned memory (the reference copies the same window with a scalar CPU loop,
   // TEncOpenCL.cpp:275-277); 1 byte per sample on the 8-bit path, 2 otherwise
-  const int bps = wide ? 2 : 1, maxv = (1 << p->bit_depth) - 1;
+  const int bps = wide ? 2 : 1;
   uint8_t* h_ctu = ctx->h_stage;
   uint8_t* h_win = ctx->h_stage + 64 * 64 * 2;
   const int rows = wy + 63, cols = wx + 63;
@@ -331,8 +345,7 @@ int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
   bool bad = false;
   for (int y = 0; y < 64; ++y)
     for (int x = 0; x < 64; ++x) {
-      const int v = ctu[y * ctu_stride + x];
-      bad |= v < 0 || v > maxv;
+      const int v = ctu[y * ctu_stride + x] + bias;
       if (wide) ((uint16_t*)h_ctu)[y * 64 + x] = (uint16_t)v; else h_ctu[y * 64 + x] = (uint8_t)v;
     }
   for (int y = 0; y < rows; ++y) {
@@ -340,11 +353,11 @@ int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
     for (int x = 0; x < cols; ++x) {
       const int v = src[(long)y * ref_stride + x];
       bad |= v < 0 || v > maxv;
-      if (wide) ((uint16_t*)row)[x] = (uint16_t)v; else row[x] = (uint8_t)v;
+      if (wide) ((uint16_t*)row)[x] = (uint16_t)(v + bias); else row[x] = (uint8_t)v;
     }
     std::memset(row + cols * bps, 0, kWinPitch - cols * bps);
   }
-  if (bad) return fail(ctx, HMME_ERR_RANGE, "hmme_search_ctu: sample outside [0,%d] for bit depth %d", maxv, p->bit_depth);
+  if (bad) return fail(ctx, HMME_ERR_RANGE, "hmme_search_ctu: reference sample outside [0,%d] for bit depth %d", maxv, p->bit_depth);
   MeJob job;
   job.ctu_x = 0; job.ctu_y = 0;
   job.lt_x = (int16_t)p->lt_x; job.lt_y = (int16_t)p->lt_y; job.rb_x = (int16_t)p->rb_x; job.rb_y = (int16_t)p->rb_y;

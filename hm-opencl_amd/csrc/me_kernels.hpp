@@ -333,6 +333,10 @@ __global__ void me_fill_plane_kernel(uint8_t* __restrict__ dst, int dst_pitch, i
 // lanes packed linearly over the window (candidate pair q = iteration*64 + lane), and the window is cut into
 // horizontal strips of candidate rows so that one strip's reference rows fit LDS (SR 128: 320 x 322 samples);
 // strips of a CTU are separate workgroups that merge through 64-bit atomicMin on a global table.
+constexpr int kIdxBits16 = 9;              // key = cost << 9 | iter(1) | lane(6) | j(2): 23-bit cost field
+constexpr uint32_t kInvCost16 = 4000000u;  // > any valid cost (bi-pred origins: <= 3 142 656 + 65 535); + max SAD < 2^23
+constexpr int kIterPerTask16 = kIterPerTask < 2 ? kIterPerTask : 2;
+
 struct MeJob16 {
   MeJob j;
   int16_t y0, y1;      // candidate rows [y0, y1) of the window handled by this workgroup
@@ -385,10 +389,10 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const ui
 
   const int pairs = (wx + 1) >> 1;                                     // candidate pairs per window row
   const int n_iters = (ny * pairs + 63) >> 6;
-  const int n_tasks = (n_iters + kIterPerTask - 1) / kIterPerTask;
+  const int n_tasks = (n_iters + kIterPerTask16 - 1) / kIterPerTask16;
   // key = ((sum & mask) << lsh) + c  ==  (((sum << fen_shift) >> sh) << 10) + c
-  const uint32_t mask_a = ~((1u << sh) - 1u), lsh_a = kIdxBits - sh;
-  const uint32_t mask_e = FEN ? ~((1u << (sh > 0 ? sh - 1 : 0)) - 1u) : mask_a, lsh_e = FEN ? kIdxBits + 1 - sh : lsh_a;
+  const uint32_t mask_a = ~((1u << sh) - 1u), lsh_a = kIdxBits16 - sh;
+  const uint32_t mask_e = FEN ? ~((1u << (sh > 0 ? sh - 1 : 0)) - 1u) : mask_a, lsh_e = FEN ? kIdxBits16 + 1 - sh : lsh_a;
   const bool rb1 = lane & 2, rb0 = lane & 1;
   const lds_vu32x4_t* curv4 = (const lds_vu32x4_t*)curl;
   constexpr int ME16_PDW = PDW;
@@ -398,8 +402,8 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const ui
     if (lane == 0) t = atomicAdd(task_ctr, 1);
     t = __builtin_amdgcn_readfirstlane(t);
     if (t >= n_tasks) break;
-    const int it0 = t * kIterPerTask;
-    const int n_it = min(kIterPerTask, n_iters - it0);
+    const int it0 = t * kIterPerTask16;
+    const int n_it = min(kIterPerTask16, n_iters - it0);
     uint32_t b0 = ME_MAXKEY, b1 = ME_MAXKEY, b2 = ME_MAXKEY, b3 = ME_MAXKEY, b4 = ME_MAXKEY, b5 = ME_MAXKEY,
              b6 = ME_MAXKEY, b7 = ME_MAXKEY, b8 = ME_MAXKEY, b9 = ME_MAXKEY;
     for (int it = 0; it < n_it; ++it) {
@@ -414,7 +418,7 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const ui
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const uint32_t cost = (lambda_q16 * (me_component_bits(((mvx + j) << 2) - job.pred_x) + by)) >> 16;
-        cc[j] = (((vy && (cx + j) < wx) ? cost : kInvCost) << kIdxBits) | tag | (uint32_t)j;
+        cc[j] = (((vy && (cx + j) < wx) ? cost : kInvCost16) << kIdxBits16) | tag | (uint32_t)j;
       }
       const uint32_t c0 = cc[0], c1 = cc[1];
       const lds_vu32_t* lpv = (const lds_vu32_t*)(win + min(row, ny - 1) * PDW + pr);
@@ -428,9 +432,9 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const ui
     {                                                                                                              \
       const int slot = ME_SLOT_OF[g][lane];                                                                        \
       const uint32_t key = (key_);                                                                                 \
-      const uint32_t cost = key >> kIdxBits;                                                                       \
-      if (slot >= 0 && cost < kInvCost) {                                                                          \
-        const int kq = (it0 + (int)((key >> 8) & 3)) * 64 + (int)((key >> 2) & 63);                                \
+      const uint32_t cost = key >> kIdxBits16;                                                                       \
+      if (slot >= 0 && cost < kInvCost16) {                                                                          \
+        const int kq = (it0 + (int)((key >> 8) & 1)) * 64 + (int)((key >> 2) & 63);                                \
         const int krow = kq / pairs;                                                                               \
         const int bx = 2 * (kq - krow * pairs) + (int)(key & 3);                                                   \
         atomicMin(&best64[slot], ((unsigned long long)cost << 32) | ((unsigned long long)(jb.y0 + krow) << 16) |   \

@@ -150,10 +150,13 @@ def test_error_behaviour(engine):
     wide8 = api.SearchParams(-100, -8, 100, 8, 0, 0, 1, 8)          # SR > 64 exists on the 16-bit path only
     with pytest.raises(api.HmmeError, match="window"):
         engine.search_ctu(cur, (0, 0), np.zeros((100, 300), np.int16), (118, 18), wide8)
-    cur2 = cur.copy(); cur2[5, 5] = 300                             # bi-pred style origin outside [0,255]
+    cur2 = cur.copy(); cur2[5, 5] = 999                             # beyond even a bi-pred origin (2*255)
     p = api.SearchParams(-8, -8, 8, 8, 0, 0, 1, 8)
     with pytest.raises(api.HmmeError, match="outside"):
         engine.search_ctu(cur2, (0, 0), ref, (18, 18), p)
+    ref2 = ref.copy(); ref2[30, 30] = -1                            # reference samples must be real samples
+    with pytest.raises(api.HmmeError, match="reference sample"):
+        engine.search_ctu(cur, (0, 0), ref2, (18, 18), p)
     pl = engine.plane(64, 64)
     with pytest.raises(api.HmmeError, match="outside"):
         pl.upload_pel(np.full((64, 64), 700, np.int16), (0, 0))
@@ -279,3 +282,33 @@ def test_plane_bit_depth_mismatch_is_an_error(engine):
     with pytest.raises(api.HmmeError, match="search range"):
         engine.search_frame(p8, p8, 100)          # SR > 64 needs the 16-bit path
     p8.close(); p10.close()
+
+
+def test_bipred_origins_outside_the_sample_range(engine, oracle_lib):
+    """bi-prediction refinement (reference TEncSearch.cpp:3702-3712, 3221): the current block is
+    2*org - pred_other, unclipped (TComYuv.cpp:409-440), SearchRange = BipredSearchRange = 4.
+    Such blocks run on the 16-bit kernel with biased samples and must stay bit-exact."""
+    from hmme import api
+    rng = np.random.default_rng(4242)
+    for it in range(10):
+        bd = 8 if it % 3 else 10
+        maxv = (1 << bd) - 1
+        sr = 4 if it % 2 == 0 else int(rng.choice([8, 20]))
+        side = 64 + 2 * sr + 8
+        org = rng.integers(0, maxv + 1, size=(64, 64))
+        other = rng.integers(0, maxv + 1, size=(64, 64))
+        cur = (2 * org - other).astype(np.int16)                       # in [-maxv, 2*maxv]
+        if it == 0:
+            cur[0, 0], cur[63, 63] = -maxv, 2 * maxv                   # the extremes
+        ref = rng.integers(0, maxv + 1, size=(side, side)).astype(np.int16)
+        o = sr + 4
+        lt, rb = (-sr, -sr), (sr, sr)
+        pred = (int(rng.integers(-20, 21)), int(rng.integers(-20, 21)))
+        fen = int(rng.integers(0, 2))
+        lam = float(rng.choice([4.7, 57.9, 5.0e6]))
+        lq = oracle_lib.oracle().hmo_lambda_q16(lam)
+        engine.set_lambda(lam)
+        mv, sad = engine.search_ctu(cur, (0, 0), ref, (o, o), api.SearchParams(lt[0], lt[1], rb[0], rb[1], pred[0], pred[1], fen, bd))
+        ox, oy, osad = oracle_lib.search_ctu(cur, (0, 0), ref, (o, o), oracle_lib.make_params(lt, rb, pred, lq, fen, bd))
+        assert np.array_equal(mv[:, 0], ox) and np.array_equal(mv[:, 1], oy), f"iter {it}: MV mismatch"
+        assert np.array_equal(sad, osad), f"iter {it}: SAD mismatch"

@@ -96,6 +96,9 @@ def test_generated_tree_reproduces_reference_goldens(case):
     assert np.array_equal(got, d["out"][case])
 
 
+INV16, IDX16 = 4000000, G.IDX_BITS16
+
+
 def model_search16(tree, cur, ref, origin, lt, rb, pred, lq, bit_depth, iters_per_task=2):
     """python model of me_search16_kernel (16-bit samples, 2 candidates per lane, linear lane packing)"""
     sh = bit_depth - 8
@@ -121,16 +124,16 @@ def model_search16(tree, cur, ref, origin, lt, rb, pred, lq, bit_depth, iters_pe
                 for j in range(2):
                     cost = ((lq * (cbits(((lt[0] + int(cx[l]) + j) << 2) - pred[0]) + by)) & 0xFFFFFFFF) >> 16
                     valid = cy[l] < wy and cx[l] + j < wx
-                    c[j, l] = ((cost if valid else INV) << IDX) | (it << 8) | (l << 2) | j
+                    c[j, l] = ((cost if valid else INV16) << IDX16) | (it << 8) | (l << 2) | j
             lane_off = np.minimum(cy, wy - 1) * pitch + cx
             G.simulate16(tree, win, cur, lane_off, c, best, sh)
         for g in range(G.N_GROUPS):
             for l in range(64):
                 s, key = slot_of[g, l], int(best[g, l])
-                cost = key >> IDX
-                if s < 0 or cost >= INV:
+                cost = key >> IDX16
+                if s < 0 or cost >= INV16:
                     continue
-                kit, kl, kj = (key >> 8) & 3, (key >> 2) & 63, key & 3
+                kit, kl, kj = (key >> 8) & 1, (key >> 2) & 63, key & 3
                 q = (it0 + kit) * 64 + kl
                 v = np.uint64((cost << 32) | ((q // P) << 16) | (2 * (q % P) + kj))
                 if v < best64[s]:

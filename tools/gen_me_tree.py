@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT_DIR = os.path.join(ROOT, "hm-opencl_amd", "csrc")
 
 IDX_BITS = 10          # key = cost << 10 | iter(2) | lane(6) | j(2)
+IDX_BITS16 = 9         # 16-bit path: cost << 9 | iter(1) | lane(6) | j(2)  (23-bit cost: bi-pred origins reach 3.2 M)
 MULT_A = 1 << IDX_BITS
 N_GROUPS = 10          # ceil(593 / 64)
 PDW = 49               # LDS window pitch in dwords (odd: conflict-free for every lane shape)
@@ -543,7 +544,7 @@ def simulate16(tree, window, cur, lane_off, c, best, sh):
     flat = np.concatenate([window.reshape(-1), np.zeros(64, window.dtype)]).astype(np.int64)
     pitch = window.shape[1]
     mask = {"A": ~((1 << sh) - 1), "E": ~((1 << max(sh - 1, 0)) - 1) if tree.fen else ~((1 << sh) - 1)}
-    lsh = {"A": IDX_BITS - sh, "E": (IDX_BITS + 1 - sh) if tree.fen else IDX_BITS - sh}
+    lsh = {"A": IDX_BITS16 - sh, "E": (IDX_BITS16 + 1 - sh) if tree.fen else IDX_BITS16 - sh}
     val = {}
     MAXK = np.full(64, 0xFFFFFFFF, np.uint32)
     for op in tree.ops:
