@@ -27,13 +27,14 @@ def pad_plane(img, margin=MARGIN):
 
 
 def make_pair(width, height, seed=1234, bit_depth=8, max_mv=12, region=128, noise_sigma=2.0, margin=MARGIN,
-              shift=(0, 0)):
+              shift=(0, 0), pad=0):
     """-> (cur_padded, ref_padded, true_mv[regions_y, regions_x, 2]) ; planes are
     (height+2*margin, width+2*margin) int16, sample (0,0) at [margin, margin].
-    shift=(sx, sy) additionally translates `cur` as a whole (frame t of a synthetic sequence)."""
+    shift=(sx, sy) additionally translates `cur` as a whole (frame t of a synthetic sequence); give all frames
+    of a sequence the same `pad` (>= the largest shift + max_mv + 2) so that they share one base texture."""
     rng = np.random.default_rng(seed)
     maxv = (1 << bit_depth) - 1
-    g = max_mv + 2 + max(abs(shift[0]), abs(shift[1]))
+    g = max(max_mv + 2 + max(abs(shift[0]), abs(shift[1])), pad)
     base = _box5(rng.integers(0, 256, size=(height + 2 * g, width + 2 * g)).astype(np.float64))
     lo, hi = base.min(), base.max()
     base = np.clip(np.rint((base - lo) * (maxv / (hi - lo))), 0, maxv)

@@ -312,3 +312,76 @@ def test_bipred_origins_outside_the_sample_range(engine, oracle_lib):
         ox, oy, osad = oracle_lib.search_ctu(cur, (0, 0), ref, (o, o), oracle_lib.make_params(lt, rb, pred, lq, fen, bd))
         assert np.array_equal(mv[:, 0], ox) and np.array_equal(mv[:, 1], oy), f"iter {it}: MV mismatch"
         assert np.array_equal(sad, osad), f"iter {it}: SAD mismatch"
+
+
+def test_2160p_whole_frame_properties_and_spot_checks(engine, oracle_lib):
+    """BASELINE config 3 shape (3840x2160, SR 64, FEN 1): per-CTU random predictors (clipped windows at the
+    picture edges), planted motion recovered everywhere it is recoverable, oracle equality on a CTU sample."""
+    from hmme import synth
+    w, h, sr = 3840, 2160, 64
+    cur, ref, true_mv = synth.make_pair(w, h, seed=77, max_mv=20, region=256, noise_sigma=0.0)
+    m = synth.MARGIN
+    n_ctu = 60 * 34
+    pred = synth.random_predictors(n_ctu, seed=77, max_pel=24)
+    engine.set_lambda(57.9)
+    lq = engine.lambda_q16
+    pc, pr = engine.plane(w, h), engine.plane(w, h)
+    pc.upload_pel(cur, (m, m)); pr.upload_pel(ref, (m, m))
+    mv, sad = engine.search_frame(pc, pr, sr, pred)
+    mv2, sad2 = engine.search_frame(pc, pr, sr, pred)                    # idempotence: no state leaks between launches
+    pc.close(); pr.close()
+    assert mv.shape == (n_ctu, 593, 2) and np.array_equal(mv, mv2) and np.array_equal(sad, sad2)
+    hits = 0
+    for cy in range(1, 32):
+        for cx in range(1, 59):
+            if (cx % 4) in (0, 3) or (cy % 4) in (0, 3):                  # keep CTUs strictly inside one 256x256 region
+                continue
+            dx, dy = (int(v) for v in true_mv[cy // 4, cx // 4])
+            ctu = cy * 60 + cx
+            px, py = int(pred[ctu, 0]) >> 2, int(pred[ctu, 1]) >> 2
+            if abs(dx - px) < sr - 1 and abs(dy - py) < sr - 1:           # planted MV lies inside this CTU's window
+                assert sad[ctu, 592] == 0 and tuple(mv[ctu, 592]) == (dx, dy), (cx, cy)
+                hits += 1
+    assert hits > 300
+    for ctu in (0, 59, 61, 1017, 2039, 1980, 33 * 60 + 30, 777):          # corners, interior, partial bottom row
+        ox, oy, osad = oracle_lib.search_frame(cur, ref, (m, m), w, h, sr, pred, lq, 1, 8, ctu_first=ctu, ctu_count=1)
+        assert np.array_equal(mv[ctu, :, 0], ox[0]) and np.array_equal(mv[ctu, :, 1], oy[0]) and np.array_equal(sad[ctu], osad[0]), ctu
+
+
+def test_engine_lifecycle_and_two_contexts(oracle_lib):
+    from hmme import api, synth
+    w, h, sr = 128, 128, 8
+    cur, ref, _ = synth.make_pair(w, h, seed=3, max_mv=5, region=64)
+    m = synth.MARGIN
+    lq = oracle_lib.oracle().hmo_lambda_q16(57.9)
+    want = oracle_lib.search_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, 8)
+    engines = []
+    for i in range(4):                                                    # create/destroy cycles and two live contexts
+        e = api.Engine(0, 16 + 16 * i)
+        e.set_lambda(57.9)
+        engines.append(e)
+        if len(engines) > 2:
+            engines.pop(0).close()
+        for eng in engines:
+            pc, pr = eng.plane(w, h), eng.plane(w, h)
+            pc.upload_pel(cur, (m, m)); pr.upload_pel(ref, (m, m))
+            mv, sad = eng.search_frame(pc, pr, sr)
+            assert np.array_equal(mv[:, :, 0], want[0]) and np.array_equal(mv[:, :, 1], want[1]) and np.array_equal(sad, want[2])
+            pc.close(); pr.close()
+    for e in engines:
+        e.close()
+
+
+def test_sequence_driver_single_gpu(tmp_path):
+    """tools/me_sequence.py (BASELINE config 4 driver) on one GPU with a small synthetic sequence"""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "me_sequence.py"), "--frames", "6", "--gop", "randomaccess",
+                        "--size", "640x448", "--search-range", "16"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["pairs"] == 9 and d["gpus"] == 1
+    # frame t is the texture shifted by (3t, 2t): pair (4, 0) -> MV (-12, -8) for cur(x) = ref(x + mv) ... sign per synth.make_pair
+    assert d["first_pairs"][0] == [4, 0] and [abs(v) for v in d["median_mv_64x64_of_first_pairs"][0]] == [12, 8]

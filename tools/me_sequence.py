@@ -50,7 +50,8 @@ def main():
         if args.yuv:
             pl.upload_u8(yuv.read_luma(args.yuv, w, h, poc))
         else:   # frame poc = texture translated by a per-frame global motion (synthetic sequence)
-            cur, _, _ = synth.make_pair(w, h, seed=777, max_mv=0, noise_sigma=0.0, shift=(3 * poc, 2 * poc))
+            cur, _, _ = synth.make_pair(w, h, seed=777, max_mv=0, noise_sigma=0.0, shift=(3 * poc, 2 * poc),
+                                        pad=3 * args.frames + 4)
             pl.upload_pel(cur, (synth.MARGIN, synth.MARGIN))
         planes[poc] = pl
     n_ctu = api.load().hmme_num_ctus(w, h)
