@@ -309,6 +309,63 @@ void hmme_set_search_range(int pred_x_q, int pred_y_q, int sr, int cu_x, int cu_
   hmme::set_search_range(pred_x_q, pred_y_q, sr, cu_x, cu_y, pic_w, pic_h, *lt_x, *lt_y, *rb_x, *rb_y);
 }
 
+// ---- slot layout: closed form of the 593-case switch of TComDataCU::getIndexBlock ------------------------
+namespace {
+const int kBase2NxN[4] = {588, 560, 448, 0}, kBaseNx2N[4] = {590, 568, 480, 128};      // indexed by depth (CU 64,32,16,8)
+const int kBaseAMP[4] = {576, 512, 256, -1}, kBase2Nx2N[4] = {592, 584, 544, 384};
+
+int slot_of(int part_size, int depth, int part_idx, int cx, int cy) {
+  const int n = 1 << depth, r = cy * n + cx;
+  if (part_idx < 0 || part_idx > 1) return -1;
+  switch (part_size) {
+    case 0: return part_idx == 0 ? kBase2Nx2N[depth] + r : -1;
+    case 1: return kBase2NxN[depth] + cy * 2 * n + part_idx * n + cx;
+    case 2: return kBaseNx2N[depth] + cy * 2 * n + 2 * cx + part_idx;
+    default: break;
+  }
+  if (depth == 3) return -1;
+  static const int k_of[4][2] = {{0, 3}, {2, 1}, {4, 7}, {6, 5}};   // 2NxnU, 2NxnD, nLx2N, nRx2N x part_idx -> AMP family
+  if (part_size < 4 || part_size > 7) return -1;
+  return kBaseAMP[depth] + k_of[part_size - 4][part_idx] * n * n + r;
+}
+}  // namespace
+
+int hmme_slot_index(int part_size, int depth, int part_idx, int abs_z_idx) {
+  if (depth < 0 || depth > 3 || abs_z_idx < 0 || abs_z_idx > 255) return -1;
+  int bx = 0, by = 0;   // z-order -> raster in 4x4 units
+  for (int b = 0; b < 4; ++b) { bx |= ((abs_z_idx >> (2 * b)) & 1) << b; by |= ((abs_z_idx >> (2 * b + 1)) & 1) << b; }
+  const int s4 = 16 >> depth;   // CU size in 4x4 units
+  if (bx % s4 || by % s4) return -1;
+  return slot_of(part_size, depth, part_idx, bx / s4, by / s4);
+}
+
+int hmme_slot_rect(int slot, int* x, int* y, int* w, int* h) {
+  if (!x || !y || !w || !h) return HMME_ERR_ARG;
+  static const int part_sizes[7] = {0, 1, 2, 4, 5, 6, 7};
+  for (int depth = 0; depth < 4; ++depth) {
+    const int s = 64 >> depth, n = 1 << depth;
+    for (int cy = 0; cy < n; ++cy)
+      for (int cx = 0; cx < n; ++cx)
+        for (int pi = 0; pi < 7; ++pi)
+          for (int idx = 0; idx < 2; ++idx) {
+            if (slot_of(part_sizes[pi], depth, idx, cx, cy) != slot) continue;
+            int rx = 0, ry = 0, rw = s, rh = s;
+            switch (part_sizes[pi]) {   // TComDataCU::getPartIndexAndSize
+              case 1: rh = s / 2; ry = idx ? s / 2 : 0; break;
+              case 2: rw = s / 2; rx = idx ? s / 2 : 0; break;
+              case 4: rh = idx ? 3 * s / 4 : s / 4; ry = idx ? s / 4 : 0; break;
+              case 5: rh = idx ? s / 4 : 3 * s / 4; ry = idx ? 3 * s / 4 : 0; break;
+              case 6: rw = idx ? 3 * s / 4 : s / 4; rx = idx ? s / 4 : 0; break;
+              case 7: rw = idx ? s / 4 : 3 * s / 4; rx = idx ? 3 * s / 4 : 0; break;
+              default: break;
+            }
+            *x = cx * s + rx; *y = cy * s + ry; *w = rw; *h = rh;
+            return HMME_OK;
+          }
+  }
+  return HMME_ERR_ARG;
+}
+
 // ---- per-CTU drop-in ---------------------------------------------------------------------------------
 int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref0, int ref_stride,
                     const hmme_search_params* p, int16_t* out_mv, uint32_t* out_sad) {

@@ -17,7 +17,7 @@ NUM_PARTS = 593
 # every symbol include/hmme.h declares (tests check the library exports all of them)
 SYMBOLS = ["hmme_create", "hmme_destroy", "hmme_last_error", "hmme_device_info", "hmme_set_lambda",
            "hmme_set_lambda_q16", "hmme_get_lambda_q16", "hmme_params_ocl_compat", "hmme_set_search_range",
-           "hmme_search_ctu", "hmme_plane_create", "hmme_plane_create_ex", "hmme_plane_bit_depth", "hmme_plane_destroy", "hmme_plane_upload_pel",
+           "hmme_slot_index", "hmme_slot_rect", "hmme_search_ctu", "hmme_plane_create", "hmme_plane_create_ex", "hmme_plane_bit_depth", "hmme_plane_destroy", "hmme_plane_upload_pel",
            "hmme_plane_upload_u8", "hmme_plane_set_device_u8", "hmme_plane_width", "hmme_plane_height",
            "hmme_num_ctus", "hmme_search_frame", "hmme_search_frame_device", "hmme_time_search_kernel"]
 
@@ -68,6 +68,8 @@ def load():
     L.hmme_params_ocl_compat.restype = None
     L.hmme_set_search_range.argtypes = [i] * 7 + [C.POINTER(i)] * 4
     L.hmme_set_search_range.restype = None
+    L.hmme_slot_index.argtypes = [i, i, i, i]
+    L.hmme_slot_rect.argtypes = [i] + [C.POINTER(i)] * 4
     L.hmme_search_ctu.argtypes = [vp, vp, i, vp, i, C.POINTER(SearchParams), vp, vp]
     L.hmme_plane_create.argtypes = [vp, i, i, C.POINTER(vp)]
     L.hmme_plane_create_ex.argtypes = [vp, i, i, i, C.POINTER(vp)]
@@ -200,4 +202,16 @@ def ocl_compat_params(lt_x, lt_y, sr):
 def set_search_range(pred_x_q, pred_y_q, sr, cu_x, cu_y, pic_w, pic_h):
     out = [C.c_int() for _ in range(4)]
     load().hmme_set_search_range(pred_x_q, pred_y_q, sr, cu_x, cu_y, pic_w, pic_h, *[C.byref(o) for o in out])
+    return tuple(o.value for o in out)
+
+
+def slot_index(part_size, depth, part_idx, abs_z_idx):
+    return load().hmme_slot_index(part_size, depth, part_idx, abs_z_idx)
+
+
+def slot_rect(slot):
+    out = [C.c_int() for _ in range(4)]
+    rc = load().hmme_slot_rect(slot, *[C.byref(o) for o in out])
+    if rc != 0:
+        raise HmmeError(f"slot {slot} out of range")
     return tuple(o.value for o in out)

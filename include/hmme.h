@@ -93,6 +93,14 @@ void hmme_params_ocl_compat(hmme_search_params* p, int lt_x, int lt_y, int searc
 void hmme_set_search_range(int pred_x_q, int pred_y_q, int search_range, int cu_x, int cu_y, int pic_w,
                            int pic_h, int* lt_x, int* lt_y, int* rb_x, int* rb_y);
 
+/* ---- slot layout (TComDataCU::getIndexBlock, TComDataCU.cpp:3379-3391 + case table :4676-6461) ------ */
+/* slot 0..592 of a PU: part_size = HM PartSize enum (0 2Nx2N, 1 2NxN, 2 Nx2N, 4 2NxnU, 5 2NxnD, 6 nLx2N, 7 nRx2N),
+ * depth 0..3 (CU size 64 >> depth), part_idx 0/1, abs_z_idx = z-order address of the CU in 4x4 units.
+ * Returns -1 for combinations the reference does not tabulate (NxN, AMP at 8x8). */
+int hmme_slot_index(int part_size, int depth, int part_idx, int abs_z_idx);
+/* rectangle of a slot inside the 64x64 CTU; returns 0 or HMME_ERR_ARG */
+int hmme_slot_rect(int slot, int* x, int* y, int* w, int* h);
+
 /* ---- per-CTU drop-in (host buffers, HM `Pel` = int16) --------------------------------- */
 /* ctu: 64x64 current block (TEncSearch.cpp:3747); ref_at_ctu_origin: reference plane at the CTU
  * origin inside its padded buffer, as handed to calcMotionVectors.  Synchronous.

@@ -63,3 +63,14 @@ def test_host_module_compiles_inside_the_reference_tree():
     host = os.path.join(ROOT, "hm-opencl_amd", "host")
     subprocess.run(["g++", "-std=gnu++98", "-fsyntax-only", "-DHMME_IN_HM_TREE", "-DMSYS_LINUX", "-I" + ref,
                     os.path.join(host, "TEncOpenCL.cpp")], check=True)
+
+
+def test_slot_layout_matches_reference_getIndexBlock(slots):
+    # goldens: TComDataCU::getIndexBlock evaluated by the compiled reference for every tabulated PU
+    from hmme import api
+    api.build()
+    for row in slots:
+        slot, ps, depth, pi, z, s, x, y, w, h = (int(v) for v in row)
+        assert api.slot_index(ps, depth, pi, z) == slot
+        assert api.slot_rect(slot) == (x, y, w, h)
+    assert api.slot_index(3, 3, 0, 0) == -1 and api.slot_index(4, 3, 0, 0) == -1 and api.slot_index(0, 1, 0, 1) == -1

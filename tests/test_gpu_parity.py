@@ -98,7 +98,8 @@ def test_ocl_compat_mode_vs_oracle(engine, oracle_lib):
     assert np.array_equal(mv[:, 0], ox) and np.array_equal(mv[:, 1], oy) and np.array_equal(sad, osad)
 
 
-@pytest.mark.parametrize("w,h,sr,fen,use_pred", [(200, 136, 16, 1, True), (320, 192, 64, 1, False), (192, 128, 8, 0, True)])
+@pytest.mark.parametrize("w,h,sr,fen,use_pred", [(64, 64, 8, 1, False),   # BASELINE config 1 shape: one CTU, SR 8
+                                                 (200, 136, 16, 1, True), (320, 192, 64, 1, False), (192, 128, 8, 0, True)])
 def test_search_frame_vs_oracle(engine, oracle_lib, w, h, sr, fen, use_pred):
     """whole-picture path incl. partial edge CTUs and clipped windows == oracle frame search"""
     from hmme import synth
