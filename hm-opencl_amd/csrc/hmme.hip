@@ -102,13 +102,36 @@ int launch_search8(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const uint8
                    int n_jobs, int fen, int16_t* d_mv, uint32_t* d_sad, hipStream_t stream) {
   if (n_jobs <= 0) return HMME_OK;
   if (fen)
-    hipLaunchKernelGGL(hmme::me_search_kernel<1>, dim3(n_jobs), dim3(hmme::kThreads), 0, stream, cur, cur_pitch, ref,
-                       ref_pitch, d_jobs, ctx->lambda_q16, d_mv, d_sad);
+    hipLaunchKernelGGL((hmme::me_search_kernel<1, 0>), dim3(n_jobs), dim3(hmme::kThreads), 0, stream, cur, cur_pitch, ref,
+                       ref_pitch, (const void*)d_jobs, ctx->lambda_q16, d_mv, d_sad, (unsigned long long*)nullptr);
   else
-    hipLaunchKernelGGL(hmme::me_search_kernel<0>, dim3(n_jobs), dim3(hmme::kThreads), 0, stream, cur, cur_pitch, ref,
-                       ref_pitch, d_jobs, ctx->lambda_q16, d_mv, d_sad);
+    hipLaunchKernelGGL((hmme::me_search_kernel<0, 0>), dim3(n_jobs), dim3(hmme::kThreads), 0, stream, cur, cur_pitch, ref,
+                       ref_pitch, (const void*)d_jobs, ctx->lambda_q16, d_mv, d_sad, (unsigned long long*)nullptr);
   HIP_TRY(ctx, hipGetLastError());
   return HMME_OK;
+}
+
+int finalize_best(hmme_ctx* ctx, const MeJob16* d_jobs, const int* d_first_strip, int n_jobs, int16_t* d_mv, uint32_t* d_sad,
+                  hipStream_t stream);
+
+// 8-bit split mode: n_jobs * n_split workgroups, each runs a slice of its CTU's tasks and merges through ctx->d_best
+int launch_search8_split(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const uint8_t* ref, int ref_pitch, const MeJob16* d_jobs,
+                         const int* d_first_strip, int n_jobs, int n_split, int fen, int16_t* d_mv, uint32_t* d_sad,
+                         hipStream_t stream) {
+  if (n_jobs <= 0) return HMME_OK;
+  size_t cap = ctx->best_cap;
+  int rc = ensure(ctx, &ctx->d_best, &cap, sizeof(unsigned long long) * HMME_NUM_CTU_PARTS * (size_t)n_jobs);
+  ctx->best_cap = cap;
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_best, 0xFF, sizeof(unsigned long long) * HMME_NUM_CTU_PARTS * (size_t)n_jobs, stream));
+  if (fen)
+    hipLaunchKernelGGL((hmme::me_search_kernel<1, 1>), dim3(n_jobs * n_split), dim3(hmme::kThreads), 0, stream, cur, cur_pitch,
+                       ref, ref_pitch, (const void*)d_jobs, ctx->lambda_q16, (int16_t*)nullptr, (uint32_t*)nullptr, ctx->d_best);
+  else
+    hipLaunchKernelGGL((hmme::me_search_kernel<0, 1>), dim3(n_jobs * n_split), dim3(hmme::kThreads), 0, stream, cur, cur_pitch,
+                       ref, ref_pitch, (const void*)d_jobs, ctx->lambda_q16, (int16_t*)nullptr, (uint32_t*)nullptr, ctx->d_best);
+  HIP_TRY(ctx, hipGetLastError());
+  return finalize_best(ctx, d_jobs, d_first_strip, n_jobs, d_mv, d_sad, stream);
 }
 
 // ---- 16-bit path -------------------------------------------------------------------------------------
@@ -156,6 +179,11 @@ int launch_search16(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const uint
     rc = fen ? launch16_t<1, kPdw16Large>(ctx, cur, cur_pitch, ref, ref_pitch, d_jobs, n_wg, lds, sh, ctx->d_best, stream)
              : launch16_t<0, kPdw16Large>(ctx, cur, cur_pitch, ref, ref_pitch, d_jobs, n_wg, lds, sh, ctx->d_best, stream);
   if (rc) return rc;
+  return finalize_best(ctx, d_jobs, d_first_strip, n_jobs, d_mv, d_sad, stream);
+}
+
+int finalize_best(hmme_ctx* ctx, const MeJob16* d_jobs, const int* d_first_strip, int n_jobs, int16_t* d_mv, uint32_t* d_sad,
+                  hipStream_t stream) {
   const long total = (long)n_jobs * HMME_NUM_CTU_PARTS;
   hipLaunchKernelGGL(hmme::me_finalize16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, ctx->d_best, d_jobs,
                      d_first_strip, n_jobs, ctx->lambda_q16, d_mv, d_sad);
@@ -260,7 +288,7 @@ int hmme_create(int device, int sr_max, unsigned flags, hmme_ctx** out) {
   CREATE_TRY(hipHostMalloc(&ctx->h_sad, sizeof(uint32_t) * HMME_NUM_CTU_PARTS));
   CREATE_TRY(hipMalloc(&ctx->d_mv1, sizeof(int16_t) * 2 * HMME_NUM_CTU_PARTS));
   CREATE_TRY(hipMalloc(&ctx->d_sad1, sizeof(uint32_t) * HMME_NUM_CTU_PARTS));
-  CREATE_TRY(hipMalloc(&ctx->d_job1, sizeof(MeJob16) * 16));
+  CREATE_TRY(hipMalloc(&ctx->d_job1, sizeof(MeJob16) * 64));
   CREATE_TRY(hipMalloc(&ctx->d_flag, sizeof(int)));
   CREATE_TRY(hipMemset(ctx->d_flag, 0, sizeof(int)));
 #undef CREATE_TRY
@@ -426,8 +454,26 @@ int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
   const uint8_t* ref_base = ctx->d_win - (long)p->lt_y * kWinPitch - (long)p->lt_x * bps;
   int rc;
   if (!wide) {
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_job1, &job, sizeof job, hipMemcpyHostToDevice, s));
-    rc = launch_search8(ctx, ctx->d_ctu, 64, ref_base, kWinPitch, ctx->d_job1, 1, p->fen, ctx->d_mv1, ctx->d_sad1, s);
+    // one CTU alone would keep 1 of 256 CUs busy for ~17 lane-iterations per wave: deal its tasks to many workgroups
+    // (4 tasks each = one per wave) and merge through the 64-bit atomicMin table
+    const int nt = hmme::me_num_tasks(wx, wy);
+    int n_split = (nt + 3) / 4;
+    if (n_split > 64) n_split = 64;
+    MeJob16 js[64];
+    for (int i = 0; i < n_split; ++i) {
+      js[i].j = job; js[i].job = 0;
+      js[i].y0 = (int16_t)((long)nt * i / n_split); js[i].y1 = (int16_t)((long)nt * (i + 1) / n_split);
+    }
+    const int zero = 0;
+    size_t cap = (size_t)ctx->first_strip_cap * sizeof(int);
+    rc = ensure(ctx, &ctx->d_first_strip, &cap, sizeof(int) * 16);
+    ctx->first_strip_cap = (int)(cap / sizeof(int));
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_first_strip, &zero, sizeof zero, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_job1, js, sizeof(MeJob16) * n_split, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));   // js / zero live on this stack frame
+    rc = launch_search8_split(ctx, ctx->d_ctu, 64, ref_base, kWinPitch, (const MeJob16*)ctx->d_job1, ctx->d_first_strip, 1, n_split,
+                              p->fen, ctx->d_mv1, ctx->d_sad1, s);
   } else {
     const int pdw = (wx <= 129 && wy <= 129) ? kPdw16Small : kPdw16Large;
     const int n_strips = strips_for(pdw, wy);
@@ -508,11 +554,27 @@ static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_para
   *pdw = fp->search_range <= 64 ? kPdw16Small : kPdw16Large;
   *n_strips = wide ? strips_for(*pdw, 2 * fp->search_range + 1) : 1;
   *strip_rows = (2 * fp->search_range + 1 + *n_strips - 1) / *n_strips;
+  if (!wide && count < 384) {
+    // fewer CTUs than workgroup slots (256 CUs x 2): cut each CTU's task list so that ~768 workgroups exist,
+    // but never below 4 tasks (one per wave) per workgroup
+    const int nt = hmme::me_num_tasks(2 * fp->search_range + 1, 2 * fp->search_range + 1);
+    int f = (768 + count - 1) / count;
+    if (f > (nt + 3) / 4) f = (nt + 3) / 4;
+    *n_strips = f < 1 ? 1 : f;
+  }
+  const bool split8 = !wide && *n_strips > 1;
   size_t cap = ctx->jobs_bytes;
-  int rc = ensure(ctx, (uint8_t**)&ctx->d_jobs, &cap, wide ? sizeof(MeJob16) * (size_t)count * *n_strips : sizeof(MeJob) * (size_t)count);
+  int rc = ensure(ctx, (uint8_t**)&ctx->d_jobs, &cap, (wide || split8) ? sizeof(MeJob16) * (size_t)count * *n_strips : sizeof(MeJob) * (size_t)count);
   ctx->jobs_bytes = cap;
   if (rc) return rc;
-  if (!wide) {
+  if (split8) {
+    size_t fcap = (size_t)ctx->first_strip_cap * sizeof(int);
+    rc = ensure(ctx, &ctx->d_first_strip, &fcap, sizeof(int) * (size_t)count);
+    ctx->first_strip_cap = (int)(fcap / sizeof(int));
+    if (rc) return rc;
+    hipLaunchKernelGGL(hmme::me_prep_jobs_split_kernel, dim3((count + 255) / 256), dim3(256), 0, s, (MeJob16*)ctx->d_jobs,
+                       ctx->d_first_strip, (const int16_t*)d_pred_q, first, count, cur->width, cur->height, fp->search_range, *n_strips);
+  } else if (!wide) {
     hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, dim3((count + 255) / 256), dim3(256), 0, s, (MeJob*)ctx->d_jobs,
                        (const int16_t*)d_pred_q, first, count, cur->width, cur->height, fp->search_range);
   } else {
@@ -529,6 +591,9 @@ static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_para
 
 static int run_search(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp, int count, int n_strips,
                       int pdw, int strip_rows, int16_t* d_mv, uint32_t* d_sad, hipStream_t s) {
+  if (fp->bit_depth == 8 && n_strips > 1)
+    return launch_search8_split(ctx, cur->origin(), cur->pitch, ref->origin(), ref->pitch, (const MeJob16*)ctx->d_jobs,
+                                ctx->d_first_strip, count, n_strips, fp->fen, d_mv, d_sad, s);
   if (fp->bit_depth == 8)
     return launch_search8(ctx, cur->origin(), cur->pitch, ref->origin(), ref->pitch, (const MeJob*)ctx->d_jobs, count, fp->fen, d_mv, d_sad, s);
   return launch_search16(ctx, cur->origin(), cur->pitch, ref->origin(), ref->pitch, (const MeJob16*)ctx->d_jobs, ctx->d_first_strip, count,

@@ -129,12 +129,38 @@ __device__ __forceinline__ uint32_t me_mv_cost(uint32_t lambda_q16, int x, int y
   return (lambda_q16 * (me_component_bits((x << 2) - pred_x) + me_component_bits((y << 2) - pred_y))) >> 16;
 }
 
+constexpr int kIdxBits16 = 9;              // key = cost << 9 | iter(1) | lane(6) | j(2): 23-bit cost field
+constexpr uint32_t kInvCost16 = 4000000u;  // > any valid cost (bi-pred origins: <= 3 142 656 + 65 535); + max SAD < 2^23
+constexpr int kIterPerTask16 = kIterPerTask < 2 ? kIterPerTask : 2;
+
+// a CTU search cut into several workgroups: the 16-bit path cuts by candidate rows (LDS capacity), the 8-bit path
+// by task range (latency of the per-CTU drop-in call, small pictures)
+struct MeJob16 {
+  MeJob j;
+  int16_t y0, y1;      // 16-bit path: candidate rows [y0, y1); 8-bit split mode: tasks [y0, y1)
+  int32_t job;         // index into the result arrays
+};
+
+// number of tasks me_search_kernel makes out of a wx x wy window (same arithmetic on host and device)
+__host__ __device__ inline int me_num_tasks(int wx, int wy) {
+  const int quads = (wx + 3) >> 2;
+  int n = 0;
+  for (int k = 5; k >= 0; --k)
+    if (quads & (1 << k)) n += ((wy + (64 >> k) - 1) / (64 >> k) + kIterPerTask - 1) / kIterPerTask;
+  return n;
+}
+static_assert(sizeof(MeJob16) == 24, "MeJob16 layout");
+
+
 // ---- the search kernel --------------------------------------------------------------------------
-template <int FEN>
+// SPLIT = 0: one workgroup searches the whole window of jobs[blockIdx.x] (MeJob) and writes its 593 results.
+// SPLIT = 1: jobs are MeJob16; the workgroup runs tasks [y0, y1) only and merges into g_best with 64-bit atomicMin
+//            (decoded afterwards by me_finalize16_kernel) -- used where one CTU must fill many CUs.
+template <int FEN, int SPLIT>
 __global__ void __launch_bounds__(kThreads, 2)
 me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const uint8_t* __restrict__ ref_base,
-                 int ref_pitch, const MeJob* __restrict__ jobs, uint32_t lambda_q16, int16_t* __restrict__ out_mv,
-                 uint32_t* __restrict__ out_sad) {
+                 int ref_pitch, const void* __restrict__ jobs_v, uint32_t lambda_q16, int16_t* __restrict__ out_mv,
+                 uint32_t* __restrict__ out_sad, unsigned long long* __restrict__ g_best) {
   __shared__ uint32_t win[kWinRowsMax * kPDW];
   __shared__ unsigned long long best64[kParts];
   __shared__ uint2 curl[64 * 8];   // the 64x64 current block; read wave-uniformly by the leaves
@@ -142,11 +168,18 @@ me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const uint
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const MeJob job = jobs[blockIdx.x];
+  MeJob job;
+  int t_first = 0, t_end = 0x7fffffff, out_job = blockIdx.x;
+  if constexpr (SPLIT) {
+    const MeJob16 jb = ((const MeJob16*)jobs_v)[blockIdx.x];
+    job = jb.j; t_first = jb.y0; t_end = jb.y1; out_job = jb.job;
+  } else {
+    job = ((const MeJob*)jobs_v)[blockIdx.x];
+  }
   const int wx = job.rb_x - job.lt_x + 1, wy = job.rb_y - job.lt_y + 1;   // candidates per row / rows
 
   for (int s = tid; s < kParts; s += kThreads) best64[s] = ~0ull;
-  if (tid == 0) task_ctr = 0;
+  if (tid == 0) task_ctr = t_first;
 
   // -- 0. current block -> LDS (one 16-byte load per thread)
   {
@@ -172,9 +205,7 @@ me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const uint
   // -- 2. task list: the ceil(wx/4) candidate quads of a row are split into power-of-two parts
   //       (129 -> 32 + 1); part k lays a wave out as 2^k quads x (64 >> k) rows per iteration.
   const int quads = (wx + 3) >> 2;
-  int n_tasks = 0;
-  for (int k = 5; k >= 0; --k)
-    if (quads & (1 << k)) n_tasks += ((wy + (64 >> k) - 1) / (64 >> k) + kIterPerTask - 1) / kIterPerTask;
+  const int n_tasks = min(me_num_tasks(wx, wy), t_end);
 
   const uint32_t mult_a = 1u << kIdxBits;
   const uint32_t mult_e = FEN ? (2u << kIdxBits) : (1u << kIdxBits);
@@ -253,6 +284,10 @@ me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const uint
 
   // -- 4. results: integer MV (TComMv layout) and the pure SAD at the arg-min (ruiSAD, reference
   //       TEncSearch.cpp:3895: best - getCost(best))
+  if constexpr (SPLIT) {
+    for (int s = tid; s < kParts; s += kThreads) atomicMin(&g_best[(long)out_job * kParts + s], best64[s]);
+    return;
+  }
   for (int s = tid; s < kParts; s += kThreads) {
     const unsigned long long v = best64[s];
     const int mvx = job.lt_x + (int)(v & 0xffff), mvy = job.lt_y + (int)((v >> 16) & 0xffff);
@@ -333,17 +368,6 @@ __global__ void me_fill_plane_kernel(uint8_t* __restrict__ dst, int dst_pitch, i
 // lanes packed linearly over the window (candidate pair q = iteration*64 + lane), and the window is cut into
 // horizontal strips of candidate rows so that one strip's reference rows fit LDS (SR 128: 320 x 322 samples);
 // strips of a CTU are separate workgroups that merge through 64-bit atomicMin on a global table.
-constexpr int kIdxBits16 = 9;              // key = cost << 9 | iter(1) | lane(6) | j(2): 23-bit cost field
-constexpr uint32_t kInvCost16 = 4000000u;  // > any valid cost (bi-pred origins: <= 3 142 656 + 65 535); + max SAD < 2^23
-constexpr int kIterPerTask16 = kIterPerTask < 2 ? kIterPerTask : 2;
-
-struct MeJob16 {
-  MeJob j;
-  int16_t y0, y1;      // candidate rows [y0, y1) of the window handled by this workgroup
-  int32_t job;         // index into the result arrays
-};
-static_assert(sizeof(MeJob16) == 24, "MeJob16 layout");
-
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef volatile __attribute__((address_space(3))) uint32_t lds_vu32_t;
 typedef volatile __attribute__((address_space(3))) u32x4_t lds_vu32x4_t;
@@ -486,6 +510,32 @@ __global__ void me_prep_jobs16_kernel(MeJob16* jobs, int* first_strip_of_job, co
     js.y1 = (int16_t)((long)wy * (s + 1) / n_strips);
     js.job = i;
     jobs[i * n_strips + s] = js;
+  }
+}
+
+// 8-bit split mode: each CTU's tasks are dealt to n_split workgroups (4 tasks = one per wave is the useful minimum)
+__global__ void me_prep_jobs_split_kernel(MeJob16* jobs, int* first_strip_of_job, const int16_t* __restrict__ pred_q,
+                                          int ctu_first, int ctu_count, int pic_w, int pic_h, int sr, int n_split) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ctu_count) return;
+  const int ctu = ctu_first + i, ctus_x = (pic_w + 63) >> 6;
+  const int cu_x = (ctu % ctus_x) * 64, cu_y = (ctu / ctus_x) * 64;
+  const int px = pred_q ? pred_q[2 * ctu] : 0, py = pred_q ? pred_q[2 * ctu + 1] : 0;
+  int ltx, lty, rbx, rby;
+  set_search_range(px, py, sr, cu_x, cu_y, pic_w, pic_h, ltx, lty, rbx, rby);
+  MeJob j;
+  j.ctu_x = (int16_t)cu_x; j.ctu_y = (int16_t)cu_y;
+  j.lt_x = (int16_t)ltx; j.lt_y = (int16_t)lty; j.rb_x = (int16_t)rbx; j.rb_y = (int16_t)rby;
+  j.pred_x = (int16_t)px; j.pred_y = (int16_t)py;
+  const int nt = me_num_tasks(rbx - ltx + 1, rby - lty + 1);
+  first_strip_of_job[i] = i * n_split;
+  for (int s = 0; s < n_split; ++s) {
+    MeJob16 js;
+    js.j = j;
+    js.y0 = (int16_t)((long)nt * s / n_split);
+    js.y1 = (int16_t)((long)nt * (s + 1) / n_split);
+    js.job = i;
+    jobs[i * n_split + s] = js;
   }
 }
 
