@@ -501,19 +501,29 @@ def emit_cpp(tree, path, header=None):
             o.append(f"const uint32_t {op[1]} = min((({op[2]}_0 & mask_{f_}) << lsh_{f_}) + c0, (({op[2]}_1 & mask_{f_}) << lsh_{f_}) + c1);")
         else:
             raise ValueError(t)
+    write_if_changed(path, "\n".join(o) + "\n")
+
+
+def write_if_changed(path, text):
+    """keep mtimes stable so that `make` does not rebuild libhmme.so after a no-op regeneration"""
+    try:
+        if open(path).read() == text:
+            return
+    except OSError:
+        pass
     with open(path, "w") as f:
-        f.write("\n".join(o) + "\n")
+        f.write(text)
 
 
 def emit_slotmap(tree, path):
     t = tree.slot_of_lane()
-    with open(path, "w") as f:
-        f.write("// GENERATED by tools/gen_me_tree.py: slot held by lane l of running-minimum register g\n")
-        f.write("// after the butterfly (-1 = padding).  Same for fen=0 and fen=1.\n")
-        f.write("static __device__ const short ME_SLOT_OF[%d][64] = {\n" % N_GROUPS)
-        for g in range(N_GROUPS):
-            f.write("  {" + ", ".join(str(int(v)) for v in t[g]) + "},\n")
-        f.write("};\n")
+    o = ["// GENERATED by tools/gen_me_tree.py: slot held by lane l of running-minimum register g",
+         "// after the butterfly (-1 = padding).  Same for fen=0 and fen=1.",
+         "static __device__ const short ME_SLOT_OF[%d][64] = {" % N_GROUPS]
+    for g in range(N_GROUPS):
+        o.append("  {" + ", ".join(str(int(v)) for v in t[g]) + "},")
+    o.append("};")
+    write_if_changed(path, "\n".join(o) + "\n")
 
 
 # =====================================================================================================
