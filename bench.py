@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--size", default="2160p", choices=sorted(SIZES))
     ap.add_argument("--search-range", type=int, default=64)
     ap.add_argument("--bit-depth", type=int, default=8, help="8 = headline config; 10 + --search-range 128 = BASELINE config 5")
+    ap.add_argument("--refs", type=int, default=1, help="reference pictures searched per step in one launch (lowdelay_P uses 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-gpu: rehearse the N > 1 code path on a one-GPU box (not a measurement)")
@@ -164,13 +165,18 @@ def main():
     pc, pr = eng.plane(w, h, bd), eng.plane(w, h, bd)
     pc.upload_pel(cur, (synth.MARGIN, synth.MARGIN))
     pr.upload_pel(ref, (synth.MARGIN, synth.MARGIN))
+    n_refs = max(1, args.refs)
+    ref_planes = [pr] + [eng.plane(w, h, bd) for _ in range(n_refs - 1)]
+    for i, pl in enumerate(ref_planes[1:]):
+        _, r2, _ = synth.make_pair(w, h, seed=5000 + 17 * i + rank, bit_depth=bd)
+        pl.upload_pel(r2, (synth.MARGIN, synth.MARGIN))
     n_ctu = api.load().hmme_num_ctus(w, h)
     fp = api.FrameParams(sr, 1, bd, 0, n_ctu)
     # one picture pair per rank and step.  Results of step k land in buffer k % 2 ([2, 1, n_ctu, 593] int32: TComMv
     # words and SADs) and are all-gathered asynchronously on RCCL's stream while step k+1 searches into the other
     # buffer: the 9.7 MB per rank per step never stalls the VALU-bound kernel.
-    bufs = [torch.zeros((2, 1, n_ctu, api.NUM_PARTS), dtype=torch.int32, device=dev) for _ in range(2)]
-    gathered = [torch.zeros((world, 2, 1, n_ctu, api.NUM_PARTS), dtype=torch.int32, device=dev) if world > 1 else None
+    bufs = [torch.zeros((2, n_refs, n_ctu, api.NUM_PARTS), dtype=torch.int32, device=dev) for _ in range(2)]
+    gathered = [torch.zeros((world, 2, n_refs, n_ctu, api.NUM_PARTS), dtype=torch.int32, device=dev) if world > 1 else None
                 for _ in range(2)]
     pending = [None, None]
     stream = torch.cuda.current_stream().cuda_stream
@@ -184,7 +190,7 @@ def main():
             pending[b] = None
         if ev:
             ev[0].record()
-        eng.search_frame_device(pc, pr, fp, None, bufs[b][0].data_ptr(), bufs[b][1].data_ptr(), stream)
+        eng.search_frame_multi_device(pc, ref_planes, fp, None, bufs[b][0].data_ptr(), bufs[b][1].data_ptr(), stream)
         if ev:
             ev[1].record()
         if world > 1:   # the one exchange step of the path: tables of all `world` pairs to every rank (RCCL/xGMI)
@@ -219,9 +225,9 @@ def main():
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))   # HIP events on the launch stream
 
     if rank == 0:
-        sads = work_4x4_sads(api, w, h, sr)
+        sads = work_4x4_sads(api, w, h, sr) * n_refs
         total_sads = sads * world * args.steps
-        algo_bytes = algo_bytes_per_ctu(sr, bd) * n_ctu
+        algo_bytes = algo_bytes_per_ctu(sr, bd) * n_ctu * n_refs
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         # sanity: results of the last step vs a freshly computed host call on a few CTUs
         out = {
@@ -229,14 +235,14 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8" if bd == 8 else "u16", "data": "synthetic",
-            "ctus_per_s": round(n_ctu * world * args.steps / elapsed, 1),
+            "ctus_per_s": round(n_ctu * n_refs * world * args.steps / elapsed, 1),
             "config": {"workload": f"{w}x{h} {bd}-bit luma, lowdelay_P_main{'' if bd == 8 else '10'} (FEN=1), SearchRange={sr}, CTU=64, exhaustive "
-                                   f"integer search of all 593 PU shapes, 1 reference picture, {n_ctu} CTUs per frame",
+                                   f"integer search of all 593 PU shapes, {n_refs} reference picture{'s' if n_refs > 1 else ''} per launch, {n_ctu} CTUs per frame",
                        "frames_per_step": world, "parallelism": f"frame-shard x{world}", "lambda": LAMBDA,
                        "sads_4x4_per_frame": sads},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args.size, sr) if bd == 8 else None,
-                         "kernel": "me_search_kernel<1>" if bd == 8 else "me_search16_kernel<1,*> (+ finalize)",
+                         "kernel": "me_search_kernel<1, 0>" if bd == 8 else "me_search16_kernel<1,*> (+ finalize)",
                          "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "kernel is VALU-bound (1664 abs-diff ops per unique input byte, SURVEY 8d); "
@@ -251,7 +257,10 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cur, ref, w, h, sr, lq, bd)
         print(json.dumps(out), flush=True)
-    pc.close(); pr.close(); eng.close()
+    pc.close()
+    for pl in ref_planes:
+        pl.close()
+    eng.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

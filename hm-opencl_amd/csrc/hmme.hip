@@ -15,6 +15,7 @@
 
 using hmme::MeJob;
 using hmme::MeJob16;
+using hmme::RefSet;
 
 namespace {
 constexpr int kMarginX = 128;  // samples; >= 72 needed by clipMv's bounds (+3 for dword staging); keeps CTU rows 64B-aligned
@@ -22,6 +23,7 @@ constexpr int kMarginY = 80;   // TComPicYuv: maxCUHeight + 16 (reference TComPi
 constexpr int kWinPitch = 1024;  // per-CTU path: bytes per packed window row (>= 2 * (257 + 63) + 8)
 constexpr int kWinRows = 2 * 128 + 1 + 63;
 constexpr size_t kLdsBudget16 = 78 * 1024;   // per workgroup of the 16-bit path -> 2 workgroups per CU
+constexpr int kPdw16Small = 97, kPdw16Large = 161;   // 16-bit window pitch in dwords for SR <= 64 / SR <= 128 (odd: no LDS conflicts)
 std::string g_create_error;
 }  // namespace
 
@@ -53,6 +55,7 @@ struct hmme_ctx {
   uint32_t* d_sad = nullptr;
   int out_cap = 0;
   int* d_flag = nullptr;
+  bool lds_optin[4] = {false, false, false, false};
 };
 
 struct hmme_plane {
@@ -98,7 +101,13 @@ int ensure(hmme_ctx* ctx, T** p, size_t* cap_bytes, size_t bytes) {
 }
 
 // ---- 8-bit path --------------------------------------------------------------------------------------
-int launch_search8(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const uint8_t* ref, int ref_pitch, const MeJob* d_jobs,
+RefSet one_ref(const uint8_t* base) {
+  RefSet r;
+  for (int i = 0; i < hmme::kMaxRefs; ++i) r.base[i] = base;
+  return r;
+}
+
+int launch_search8(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const RefSet& ref, int ref_pitch, const MeJob* d_jobs,
                    int n_jobs, int fen, int16_t* d_mv, uint32_t* d_sad, hipStream_t stream) {
   if (n_jobs <= 0) return HMME_OK;
   if (fen)
@@ -115,7 +124,7 @@ int finalize_best(hmme_ctx* ctx, const MeJob16* d_jobs, const int* d_first_strip
                   hipStream_t stream);
 
 // 8-bit split mode: n_jobs * n_split workgroups, each runs a slice of its CTU's tasks and merges through ctx->d_best
-int launch_search8_split(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const uint8_t* ref, int ref_pitch, const MeJob16* d_jobs,
+int launch_search8_split(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const RefSet& ref, int ref_pitch, const MeJob16* d_jobs,
                          const int* d_first_strip, int n_jobs, int n_split, int fen, int16_t* d_mv, uint32_t* d_sad,
                          hipStream_t stream) {
   if (n_jobs <= 0) return HMME_OK;
@@ -135,7 +144,6 @@ int launch_search8_split(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const
 }
 
 // ---- 16-bit path -------------------------------------------------------------------------------------
-constexpr int kPdw16Small = 97, kPdw16Large = 161;   // window pitch in dwords for SR <= 64 / SR <= 128 (odd: no LDS conflicts)
 
 size_t lds_bytes16(int pdw, int strip_rows) { return (size_t)(2 * 594 + 64 * 8 * 4 + 4 + (strip_rows + 63) * pdw) * 4; }
 
@@ -147,10 +155,10 @@ int strips_for(int pdw, int wy_max) {
 }
 
 template <int FEN, int PDW>
-int launch16_t(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const uint8_t* ref, int ref_pitch, const MeJob16* d_jobs, int n_wg,
+int launch16_t(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const RefSet& ref, int ref_pitch, const MeJob16* d_jobs, int n_wg,
                size_t lds, int sh, unsigned long long* d_best, hipStream_t stream) {
-  static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
-  if (!attr_set) {
+  bool& attr_set = ctx->lds_optin[FEN * 2 + (PDW == kPdw16Large ? 1 : 0)];   // > 64 KiB of dynamic LDS: opt in once per
+  if (!attr_set) {                                                            // kernel and device (= per context)
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)hmme::me_search16_kernel<FEN, PDW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
@@ -161,7 +169,7 @@ int launch16_t(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const uint8_t* 
 }
 
 // d_jobs: n_jobs * n_strips MeJob16; results merged in ctx->d_best then decoded into d_mv / d_sad
-int launch_search16(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const uint8_t* ref, int ref_pitch, const MeJob16* d_jobs,
+int launch_search16(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const RefSet& ref, int ref_pitch, const MeJob16* d_jobs,
                     const int* d_first_strip, int n_jobs, int n_strips, int pdw, int strip_rows_max, int fen, int bit_depth,
                     int16_t* d_mv, uint32_t* d_sad, hipStream_t stream) {
   if (n_jobs <= 0) return HMME_OK;
@@ -472,7 +480,7 @@ int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_first_strip, &zero, sizeof zero, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_job1, js, sizeof(MeJob16) * n_split, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));   // js / zero live on this stack frame
-    rc = launch_search8_split(ctx, ctx->d_ctu, 64, ref_base, kWinPitch, (const MeJob16*)ctx->d_job1, ctx->d_first_strip, 1, n_split,
+    rc = launch_search8_split(ctx, ctx->d_ctu, 64, one_ref(ref_base), kWinPitch, (const MeJob16*)ctx->d_job1, ctx->d_first_strip, 1, n_split,
                               p->fen, ctx->d_mv1, ctx->d_sad1, s);
   } else {
     const int pdw = (wx <= 129 && wy <= 129) ? kPdw16Small : kPdw16Large;
@@ -493,7 +501,7 @@ int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_first_strip, &zero, sizeof zero, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_job1, js, sizeof(MeJob16) * n_strips, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));   // js / zero live on this stack frame
-    rc = launch_search16(ctx, ctx->d_ctu, 128, ref_base, kWinPitch, (const MeJob16*)ctx->d_job1, ctx->d_first_strip, 1, n_strips, pdw,
+    rc = launch_search16(ctx, ctx->d_ctu, 128, one_ref(ref_base), kWinPitch, (const MeJob16*)ctx->d_job1, ctx->d_first_strip, 1, n_strips, pdw,
                          smax, p->fen, p->bit_depth, ctx->d_mv1, ctx->d_sad1, s);
   }
   if (rc) return rc;
@@ -547,99 +555,120 @@ int hmme_plane_set_device_u8(hmme_plane* pl, const void* d_src, int src_pitch, v
 }
 
 // ---- frame search --------------------------------------------------------------------------------------------
-// builds the device job table of the picture search on `stream`; 8-bit: MeJob[count]; 16-bit: MeJob16[count * strips]
+// builds the device job table of a picture search against n_refs reference pictures on `s`; job index =
+// ref * count + ctu.  8-bit: MeJob[jobs]; 8-bit split / 16-bit: MeJob16[jobs * strips]
 static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_params* fp, const void* d_pred_q, int first, int count,
-                     hipStream_t s, int* n_strips, int* pdw, int* strip_rows) {
+                     int n_refs, hipStream_t s, int* n_strips, int* pdw, int* strip_rows) {
   const bool wide = fp->bit_depth > 8;
+  const int jobs = count * n_refs;
   *pdw = fp->search_range <= 64 ? kPdw16Small : kPdw16Large;
   *n_strips = wide ? strips_for(*pdw, 2 * fp->search_range + 1) : 1;
   *strip_rows = (2 * fp->search_range + 1 + *n_strips - 1) / *n_strips;
-  if (!wide && count < 384) {
-    // fewer CTUs than workgroup slots (256 CUs x 2): cut each CTU's task list so that ~768 workgroups exist,
+  if (!wide && jobs < 384) {
+    // fewer CTU searches than workgroup slots (256 CUs x 2): cut each one's task list so that ~768 workgroups exist,
     // but never below 4 tasks (one per wave) per workgroup
     const int nt = hmme::me_num_tasks(2 * fp->search_range + 1, 2 * fp->search_range + 1);
-    int f = (768 + count - 1) / count;
+    int f = (768 + jobs - 1) / jobs;
     if (f > (nt + 3) / 4) f = (nt + 3) / 4;
     *n_strips = f < 1 ? 1 : f;
   }
   const bool split8 = !wide && *n_strips > 1;
   size_t cap = ctx->jobs_bytes;
-  int rc = ensure(ctx, (uint8_t**)&ctx->d_jobs, &cap, (wide || split8) ? sizeof(MeJob16) * (size_t)count * *n_strips : sizeof(MeJob) * (size_t)count);
+  int rc = ensure(ctx, (uint8_t**)&ctx->d_jobs, &cap, (wide || split8) ? sizeof(MeJob16) * (size_t)jobs * *n_strips : sizeof(MeJob) * (size_t)jobs);
   ctx->jobs_bytes = cap;
   if (rc) return rc;
-  if (split8) {
+  if (wide || split8) {
     size_t fcap = (size_t)ctx->first_strip_cap * sizeof(int);
-    rc = ensure(ctx, &ctx->d_first_strip, &fcap, sizeof(int) * (size_t)count);
+    rc = ensure(ctx, &ctx->d_first_strip, &fcap, sizeof(int) * (size_t)jobs);
     ctx->first_strip_cap = (int)(fcap / sizeof(int));
     if (rc) return rc;
-    hipLaunchKernelGGL(hmme::me_prep_jobs_split_kernel, dim3((count + 255) / 256), dim3(256), 0, s, (MeJob16*)ctx->d_jobs,
-                       ctx->d_first_strip, (const int16_t*)d_pred_q, first, count, cur->width, cur->height, fp->search_range, *n_strips);
-  } else if (!wide) {
-    hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, dim3((count + 255) / 256), dim3(256), 0, s, (MeJob*)ctx->d_jobs,
-                       (const int16_t*)d_pred_q, first, count, cur->width, cur->height, fp->search_range);
-  } else {
-    size_t fcap = (size_t)ctx->first_strip_cap * sizeof(int);
-    rc = ensure(ctx, &ctx->d_first_strip, &fcap, sizeof(int) * (size_t)count);
-    ctx->first_strip_cap = (int)(fcap / sizeof(int));
-    if (rc) return rc;
-    hipLaunchKernelGGL(hmme::me_prep_jobs16_kernel, dim3((count + 255) / 256), dim3(256), 0, s, (MeJob16*)ctx->d_jobs,
-                       ctx->d_first_strip, (const int16_t*)d_pred_q, first, count, cur->width, cur->height, fp->search_range, *n_strips);
   }
+  const dim3 grid((jobs + 255) / 256), block(256);
+  if (split8)
+    hipLaunchKernelGGL(hmme::me_prep_jobs_split_kernel, grid, block, 0, s, (MeJob16*)ctx->d_jobs, ctx->d_first_strip,
+                       (const int16_t*)d_pred_q, first, count, n_refs, cur->width, cur->height, fp->search_range, *n_strips);
+  else if (!wide)
+    hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, grid, block, 0, s, (MeJob*)ctx->d_jobs, (const int16_t*)d_pred_q, first, count,
+                       n_refs, cur->width, cur->height, fp->search_range);
+  else
+    hipLaunchKernelGGL(hmme::me_prep_jobs16_kernel, grid, block, 0, s, (MeJob16*)ctx->d_jobs, ctx->d_first_strip,
+                       (const int16_t*)d_pred_q, first, count, n_refs, cur->width, cur->height, fp->search_range, *n_strips);
   HIP_TRY(ctx, hipGetLastError());
   return HMME_OK;
 }
 
-static int run_search(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp, int count, int n_strips,
-                      int pdw, int strip_rows, int16_t* d_mv, uint32_t* d_sad, hipStream_t s) {
+static int run_search(hmme_ctx* ctx, const hmme_plane* cur, const RefSet& refs, int ref_pitch, const hmme_frame_params* fp, int jobs,
+                      int n_strips, int pdw, int strip_rows, int16_t* d_mv, uint32_t* d_sad, hipStream_t s) {
   if (fp->bit_depth == 8 && n_strips > 1)
-    return launch_search8_split(ctx, cur->origin(), cur->pitch, ref->origin(), ref->pitch, (const MeJob16*)ctx->d_jobs,
-                                ctx->d_first_strip, count, n_strips, fp->fen, d_mv, d_sad, s);
+    return launch_search8_split(ctx, cur->origin(), cur->pitch, refs, ref_pitch, (const MeJob16*)ctx->d_jobs, ctx->d_first_strip, jobs,
+                                n_strips, fp->fen, d_mv, d_sad, s);
   if (fp->bit_depth == 8)
-    return launch_search8(ctx, cur->origin(), cur->pitch, ref->origin(), ref->pitch, (const MeJob*)ctx->d_jobs, count, fp->fen, d_mv, d_sad, s);
-  return launch_search16(ctx, cur->origin(), cur->pitch, ref->origin(), ref->pitch, (const MeJob16*)ctx->d_jobs, ctx->d_first_strip, count,
-                         n_strips, pdw, strip_rows, fp->fen, fp->bit_depth, d_mv, d_sad, s);
+    return launch_search8(ctx, cur->origin(), cur->pitch, refs, ref_pitch, (const MeJob*)ctx->d_jobs, jobs, fp->fen, d_mv, d_sad, s);
+  return launch_search16(ctx, cur->origin(), cur->pitch, refs, ref_pitch, (const MeJob16*)ctx->d_jobs, ctx->d_first_strip, jobs, n_strips,
+                         pdw, strip_rows, fp->fen, fp->bit_depth, d_mv, d_sad, s);
 }
 
-int hmme_search_frame_device(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp,
-                             const void* d_pred_q, void* d_out_mv, void* d_out_sad, void* stream) {
-  int first, count;
-  int rc = check_frame_args(ctx, cur, ref, fp, &first, &count);
-  if (rc) return rc;
+int hmme_search_frame_multi_device(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* const* refs, int n_refs,
+                                   const hmme_frame_params* fp, const void* d_pred_q, void* d_out_mv, void* d_out_sad, void* stream) {
+  if (!ctx) return HMME_ERR_ARG;
+  if (!refs || n_refs < 1 || n_refs > hmme::kMaxRefs) return fail(ctx, HMME_ERR_ARG, "n_refs %d outside 1..%d", n_refs, hmme::kMaxRefs);
+  int first = 0, count = 0;
+  RefSet set = one_ref(nullptr);
+  for (int r = 0; r < n_refs; ++r) {
+    int rc = check_frame_args(ctx, cur, refs[r], fp, &first, &count);
+    if (rc) return rc;
+    if (refs[r]->pitch != refs[0]->pitch) return fail(ctx, HMME_ERR_ARG, "reference planes differ in pitch");
+    set.base[r] = refs[r]->origin();
+  }
   if (!d_out_mv || !d_out_sad) return fail(ctx, HMME_ERR_ARG, "null output buffer");
   if (count == 0) return HMME_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
   int n_strips, pdw, strip_rows;
-  rc = prep_jobs(ctx, cur, fp, d_pred_q, first, count, s, &n_strips, &pdw, &strip_rows);
+  int rc = prep_jobs(ctx, cur, fp, d_pred_q, first, count, n_refs, s, &n_strips, &pdw, &strip_rows);
   if (rc) return rc;
-  return run_search(ctx, cur, ref, fp, count, n_strips, pdw, strip_rows, (int16_t*)d_out_mv, (uint32_t*)d_out_sad, s);
+  return run_search(ctx, cur, set, refs[0]->pitch, fp, count * n_refs, n_strips, pdw, strip_rows, (int16_t*)d_out_mv, (uint32_t*)d_out_sad, s);
 }
 
-int hmme_search_frame(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp,
-                      const int16_t* pred_q, int16_t* out_mv, uint32_t* out_sad) {
+int hmme_search_frame_device(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp,
+                             const void* d_pred_q, void* d_out_mv, void* d_out_sad, void* stream) {
+  return hmme_search_frame_multi_device(ctx, cur, &ref, 1, fp, d_pred_q, d_out_mv, d_out_sad, stream);
+}
+
+int hmme_search_frame_multi(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* const* refs, int n_refs,
+                            const hmme_frame_params* fp, const int16_t* pred_q, int16_t* out_mv, uint32_t* out_sad) {
+  if (!ctx) return HMME_ERR_ARG;
+  if (!refs || n_refs < 1 || n_refs > hmme::kMaxRefs) return fail(ctx, HMME_ERR_ARG, "n_refs %d outside 1..%d", n_refs, hmme::kMaxRefs);
   int first, count;
-  int rc = check_frame_args(ctx, cur, ref, fp, &first, &count);
+  int rc = check_frame_args(ctx, cur, refs[0], fp, &first, &count);
   if (rc) return rc;
   if (!out_mv || !out_sad) return fail(ctx, HMME_ERR_ARG, "null output buffer");
   if (count == 0) return HMME_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int n_ctu = hmme_num_ctus(cur->width, cur->height);
-  if (ctx->out_cap < n_ctu) {
+  const size_t need = (size_t)n_ctu * n_refs;
+  if ((size_t)ctx->out_cap < need) {
     hipFree(ctx->d_mv); hipFree(ctx->d_sad); hipFree(ctx->d_pred);
     ctx->d_mv = nullptr; ctx->d_sad = nullptr; ctx->d_pred = nullptr; ctx->out_cap = 0;
-    HIP_TRY(ctx, hipMalloc(&ctx->d_mv, sizeof(int16_t) * 2 * HMME_NUM_CTU_PARTS * (size_t)n_ctu));
-    HIP_TRY(ctx, hipMalloc(&ctx->d_sad, sizeof(uint32_t) * HMME_NUM_CTU_PARTS * (size_t)n_ctu));
-    HIP_TRY(ctx, hipMalloc(&ctx->d_pred, sizeof(int16_t) * 2 * (size_t)n_ctu));
-    ctx->out_cap = n_ctu;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_mv, sizeof(int16_t) * 2 * HMME_NUM_CTU_PARTS * need));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_sad, sizeof(uint32_t) * HMME_NUM_CTU_PARTS * need));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_pred, sizeof(int16_t) * 2 * need));
+    ctx->out_cap = (int)need;
   }
   hipStream_t s = ctx->stream;
-  if (pred_q) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pred, pred_q, sizeof(int16_t) * 2 * (size_t)n_ctu, hipMemcpyHostToDevice, s));
-  rc = hmme_search_frame_device(ctx, cur, ref, fp, pred_q ? ctx->d_pred : nullptr, ctx->d_mv, ctx->d_sad, s);
+  if (pred_q) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pred, pred_q, sizeof(int16_t) * 2 * need, hipMemcpyHostToDevice, s));
+  rc = hmme_search_frame_multi_device(ctx, cur, refs, n_refs, fp, pred_q ? ctx->d_pred : nullptr, ctx->d_mv, ctx->d_sad, s);
   if (rc) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(out_mv, ctx->d_mv, sizeof(int16_t) * 2 * HMME_NUM_CTU_PARTS * (size_t)count, hipMemcpyDeviceToHost, s));
-  HIP_TRY(ctx, hipMemcpyAsync(out_sad, ctx->d_sad, sizeof(uint32_t) * HMME_NUM_CTU_PARTS * (size_t)count, hipMemcpyDeviceToHost, s));
+  const size_t res = (size_t)count * n_refs;
+  HIP_TRY(ctx, hipMemcpyAsync(out_mv, ctx->d_mv, sizeof(int16_t) * 2 * HMME_NUM_CTU_PARTS * res, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipMemcpyAsync(out_sad, ctx->d_sad, sizeof(uint32_t) * HMME_NUM_CTU_PARTS * res, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
   return HMME_OK;
+}
+
+int hmme_search_frame(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp,
+                      const int16_t* pred_q, int16_t* out_mv, uint32_t* out_sad) {
+  return hmme_search_frame_multi(ctx, cur, &ref, 1, fp, pred_q, out_mv, out_sad);
 }
 
 int hmme_time_search_kernel(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp,
@@ -652,21 +681,22 @@ int hmme_time_search_kernel(hmme_ctx* ctx, const hmme_plane* cur, const hmme_pla
   hipStream_t s = (hipStream_t)stream;
   // job table once (it is not part of the timed kernel), then `reps` launches of the search kernel(s) alone
   int n_strips, pdw, strip_rows;
-  rc = prep_jobs(ctx, cur, fp, d_pred_q, first, count, s, &n_strips, &pdw, &strip_rows);
+  rc = prep_jobs(ctx, cur, fp, d_pred_q, first, count, 1, s, &n_strips, &pdw, &strip_rows);
   if (rc) return rc;
-  hipEvent_t e0, e1;
+  const RefSet set = one_ref(ref->origin());
+  hipEvent_t e0 = nullptr, e1 = nullptr;
   HIP_TRY(ctx, hipEventCreate(&e0));
-  HIP_TRY(ctx, hipEventCreate(&e1));
-  HIP_TRY(ctx, hipEventRecord(e0, s));
-  for (int i = 0; i < reps; ++i) {
-    rc = run_search(ctx, cur, ref, fp, count, n_strips, pdw, strip_rows, (int16_t*)d_out_mv, (uint32_t*)d_out_sad, s);
-    if (rc) return rc;
-  }
-  HIP_TRY(ctx, hipEventRecord(e1, s));
-  HIP_TRY(ctx, hipEventSynchronize(e1));
+  if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); return fail(ctx, HMME_ERR_DEVICE, "hipEventCreate failed"); }
   float ms = 0.f;
-  HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+  hipError_t e = hipEventRecord(e0, s);
+  for (int i = 0; i < reps && rc == HMME_OK && e == hipSuccess; ++i)
+    rc = run_search(ctx, cur, set, ref->pitch, fp, count, n_strips, pdw, strip_rows, (int16_t*)d_out_mv, (uint32_t*)d_out_sad, s);
+  if (rc == HMME_OK && e == hipSuccess) e = hipEventRecord(e1, s);
+  if (rc == HMME_OK && e == hipSuccess) e = hipEventSynchronize(e1);
+  if (rc == HMME_OK && e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
   hipEventDestroy(e0); hipEventDestroy(e1);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(ctx, HMME_ERR_DEVICE, "timing the search kernel: %s", hipGetErrorString(e));
   *avg_ms = ms / reps;
   return HMME_OK;
 }

@@ -42,6 +42,10 @@ struct MeJob {
   int16_t pred_x, pred_y; // AMVP predictor, quarter pels
 };
 static_assert(sizeof(MeJob) == 16, "MeJob layout");
+// CTU origins are multiples of 64, so the low 6 bits of MeJob::ctu_x carry the index of the reference picture the
+// job searches (several references of one picture in one launch, hmme_search_frame_multi)
+constexpr int kMaxRefs = 16;
+struct RefSet { const uint8_t* base[kMaxRefs]; };
 
 #include "me_slotmap.inc"
 
@@ -158,8 +162,8 @@ static_assert(sizeof(MeJob16) == 24, "MeJob16 layout");
 //            (decoded afterwards by me_finalize16_kernel) -- used where one CTU must fill many CUs.
 template <int FEN, int SPLIT>
 __global__ void __launch_bounds__(kThreads, 2)
-me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const uint8_t* __restrict__ ref_base,
-                 int ref_pitch, const void* __restrict__ jobs_v, uint32_t lambda_q16, int16_t* __restrict__ out_mv,
+me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet refs, int ref_pitch,
+                 const void* __restrict__ jobs_v, uint32_t lambda_q16, int16_t* __restrict__ out_mv,
                  uint32_t* __restrict__ out_sad, unsigned long long* __restrict__ g_best) {
   __shared__ uint32_t win[kWinRowsMax * kPDW];
   __shared__ unsigned long long best64[kParts];
@@ -176,6 +180,8 @@ me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const uint
   } else {
     job = ((const MeJob*)jobs_v)[blockIdx.x];
   }
+  const uint8_t* __restrict__ ref_base = refs.base[job.ctu_x & 63];
+  job.ctu_x &= ~63;
   const int wx = job.rb_x - job.lt_x + 1, wy = job.rb_y - job.lt_y + 1;   // candidates per row / rows
 
   for (int s = tid; s < kParts; s += kThreads) best64[s] = ~0ull;
@@ -321,17 +327,21 @@ __host__ __device__ inline void set_search_range(int pred_x, int pred_y, int sr,
 }
 
 // one job per CTU of the picture from the per-CTU predictors
+// job i = reference (i / ctu_count), CTU ctu_first + (i % ctu_count); pred_q is [n_refs][n_ctu][2]
 __global__ void me_prep_jobs_kernel(MeJob* jobs, const int16_t* __restrict__ pred_q, int ctu_first, int ctu_count,
-                                    int pic_w, int pic_h, int sr) {
+                                    int n_refs, int pic_w, int pic_h, int sr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ctu_count) return;
-  const int ctu = ctu_first + i, ctus_x = (pic_w + 63) >> 6;
+  if (i >= ctu_count * n_refs) return;
+  const int r = i / ctu_count;
+  const int ctus_x = (pic_w + 63) >> 6, n_ctu = ctus_x * ((pic_h + 63) >> 6);
+  const int ctu = ctu_first + (i - r * ctu_count);
   const int cu_x = (ctu % ctus_x) * 64, cu_y = (ctu / ctus_x) * 64;
-  const int px = pred_q ? pred_q[2 * ctu] : 0, py = pred_q ? pred_q[2 * ctu + 1] : 0;
+  const long pq = 2 * ((long)r * n_ctu + ctu);
+  const int px = pred_q ? pred_q[pq] : 0, py = pred_q ? pred_q[pq + 1] : 0;
   int ltx, lty, rbx, rby;
   set_search_range(px, py, sr, cu_x, cu_y, pic_w, pic_h, ltx, lty, rbx, rby);
   MeJob j;
-  j.ctu_x = (int16_t)cu_x; j.ctu_y = (int16_t)cu_y;
+  j.ctu_x = (int16_t)(cu_x | r); j.ctu_y = (int16_t)cu_y;
   j.lt_x = (int16_t)ltx; j.lt_y = (int16_t)lty; j.rb_x = (int16_t)rbx; j.rb_y = (int16_t)rby;
   j.pred_x = (int16_t)px; j.pred_y = (int16_t)py;
   jobs[i] = j;
@@ -375,9 +385,8 @@ typedef volatile __attribute__((address_space(3))) u32x4_t lds_vu32x4_t;
 
 template <int FEN, int PDW>
 __global__ void __launch_bounds__(kThreads, 2)
-me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const uint8_t* __restrict__ ref_base,
-                   int ref_pitch, const MeJob16* __restrict__ jobs, uint32_t lambda_q16, int sh,
-                   unsigned long long* __restrict__ g_best) {
+me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet refs, int ref_pitch,
+                   const MeJob16* __restrict__ jobs, uint32_t lambda_q16, int sh, unsigned long long* __restrict__ g_best) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   unsigned long long* best64 = (unsigned long long*)smem;              // [593] (+1 pad)
   u32x4_t* curl = (u32x4_t*)(smem + 2 * 594);                          // [64][8]: 64x64 u16 current block
@@ -387,7 +396,9 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const ui
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const MeJob16 jb = jobs[blockIdx.x];
-  const MeJob job = jb.j;
+  MeJob job = jb.j;
+  const uint8_t* __restrict__ ref_base = refs.base[job.ctu_x & 63];
+  job.ctu_x &= ~63;
   const int wx = job.rb_x - job.lt_x + 1;
   const int ny = jb.y1 - jb.y0;                                        // candidate rows of this strip
 
@@ -489,16 +500,19 @@ __global__ void me_finalize16_kernel(const unsigned long long* __restrict__ g_be
 
 // one MeJob16 per (CTU, strip) from the per-CTU predictors
 __global__ void me_prep_jobs16_kernel(MeJob16* jobs, int* first_strip_of_job, const int16_t* __restrict__ pred_q,
-                                      int ctu_first, int ctu_count, int pic_w, int pic_h, int sr, int n_strips) {
+                                      int ctu_first, int ctu_count, int n_refs, int pic_w, int pic_h, int sr, int n_strips) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ctu_count) return;
-  const int ctu = ctu_first + i, ctus_x = (pic_w + 63) >> 6;
+  if (i >= ctu_count * n_refs) return;
+  const int r = i / ctu_count;
+  const int ctus_x = (pic_w + 63) >> 6, n_ctu = ctus_x * ((pic_h + 63) >> 6);
+  const int ctu = ctu_first + (i - r * ctu_count);
   const int cu_x = (ctu % ctus_x) * 64, cu_y = (ctu / ctus_x) * 64;
-  const int px = pred_q ? pred_q[2 * ctu] : 0, py = pred_q ? pred_q[2 * ctu + 1] : 0;
+  const long pq = 2 * ((long)r * n_ctu + ctu);
+  const int px = pred_q ? pred_q[pq] : 0, py = pred_q ? pred_q[pq + 1] : 0;
   int ltx, lty, rbx, rby;
   set_search_range(px, py, sr, cu_x, cu_y, pic_w, pic_h, ltx, lty, rbx, rby);
   MeJob j;
-  j.ctu_x = (int16_t)cu_x; j.ctu_y = (int16_t)cu_y;
+  j.ctu_x = (int16_t)(cu_x | r); j.ctu_y = (int16_t)cu_y;
   j.lt_x = (int16_t)ltx; j.lt_y = (int16_t)lty; j.rb_x = (int16_t)rbx; j.rb_y = (int16_t)rby;
   j.pred_x = (int16_t)px; j.pred_y = (int16_t)py;
   const int wy = rby - lty + 1;
@@ -515,16 +529,19 @@ __global__ void me_prep_jobs16_kernel(MeJob16* jobs, int* first_strip_of_job, co
 
 // 8-bit split mode: each CTU's tasks are dealt to n_split workgroups (4 tasks = one per wave is the useful minimum)
 __global__ void me_prep_jobs_split_kernel(MeJob16* jobs, int* first_strip_of_job, const int16_t* __restrict__ pred_q,
-                                          int ctu_first, int ctu_count, int pic_w, int pic_h, int sr, int n_split) {
+                                      int ctu_first, int ctu_count, int n_refs, int pic_w, int pic_h, int sr, int n_split) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ctu_count) return;
-  const int ctu = ctu_first + i, ctus_x = (pic_w + 63) >> 6;
+  if (i >= ctu_count * n_refs) return;
+  const int r = i / ctu_count;
+  const int ctus_x = (pic_w + 63) >> 6, n_ctu = ctus_x * ((pic_h + 63) >> 6);
+  const int ctu = ctu_first + (i - r * ctu_count);
   const int cu_x = (ctu % ctus_x) * 64, cu_y = (ctu / ctus_x) * 64;
-  const int px = pred_q ? pred_q[2 * ctu] : 0, py = pred_q ? pred_q[2 * ctu + 1] : 0;
+  const long pq = 2 * ((long)r * n_ctu + ctu);
+  const int px = pred_q ? pred_q[pq] : 0, py = pred_q ? pred_q[pq + 1] : 0;
   int ltx, lty, rbx, rby;
   set_search_range(px, py, sr, cu_x, cu_y, pic_w, pic_h, ltx, lty, rbx, rby);
   MeJob j;
-  j.ctu_x = (int16_t)cu_x; j.ctu_y = (int16_t)cu_y;
+  j.ctu_x = (int16_t)(cu_x | r); j.ctu_y = (int16_t)cu_y;
   j.lt_x = (int16_t)ltx; j.lt_y = (int16_t)lty; j.rb_x = (int16_t)rbx; j.rb_y = (int16_t)rby;
   j.pred_x = (int16_t)px; j.pred_y = (int16_t)py;
   const int nt = me_num_tasks(rbx - ltx + 1, rby - lty + 1);

@@ -19,7 +19,8 @@ SYMBOLS = ["hmme_create", "hmme_destroy", "hmme_last_error", "hmme_device_info",
            "hmme_set_lambda_q16", "hmme_get_lambda_q16", "hmme_params_ocl_compat", "hmme_set_search_range",
            "hmme_slot_index", "hmme_slot_rect", "hmme_search_ctu", "hmme_plane_create", "hmme_plane_create_ex", "hmme_plane_bit_depth", "hmme_plane_destroy", "hmme_plane_upload_pel",
            "hmme_plane_upload_u8", "hmme_plane_set_device_u8", "hmme_plane_width", "hmme_plane_height",
-           "hmme_num_ctus", "hmme_search_frame", "hmme_search_frame_device", "hmme_time_search_kernel"]
+           "hmme_num_ctus", "hmme_search_frame", "hmme_search_frame_device", "hmme_search_frame_multi",
+           "hmme_search_frame_multi_device", "hmme_time_search_kernel"]
 
 
 class HmmeError(RuntimeError):
@@ -84,6 +85,8 @@ def load():
     L.hmme_num_ctus.argtypes = [i, i]
     L.hmme_search_frame.argtypes = [vp, vp, vp, C.POINTER(FrameParams), vp, vp, vp]
     L.hmme_search_frame_device.argtypes = [vp, vp, vp, C.POINTER(FrameParams), vp, vp, vp, vp]
+    L.hmme_search_frame_multi.argtypes = [vp, vp, C.POINTER(vp), i, C.POINTER(FrameParams), vp, vp, vp]
+    L.hmme_search_frame_multi_device.argtypes = [vp, vp, C.POINTER(vp), i, C.POINTER(FrameParams), vp, vp, vp, vp]
     L.hmme_time_search_kernel.argtypes = [vp, vp, vp, C.POINTER(FrameParams), vp, vp, vp, vp, i, C.POINTER(C.c_float)]
     _lib = L
     return L
@@ -182,6 +185,26 @@ class Engine:
             pq = pred_q.ctypes.data
         self._check(self.L.hmme_search_frame(self.h, cur.h, ref.h, C.byref(fp), pq, mv.ctypes.data, sad.ctypes.data))
         return mv, sad
+
+    def search_frame_multi(self, cur, refs, sr, pred_q=None, fen=1, ctu_first=0, ctu_count=-1):
+        """several reference pictures in one launch -> (mv int16[n_refs,count,593,2], sad uint32[n_refs,count,593])"""
+        n = self.L.hmme_num_ctus(cur.width, cur.height)
+        count = n - ctu_first if ctu_count < 0 else ctu_count
+        fp = FrameParams(sr, int(fen), cur.bit_depth, ctu_first, count)
+        mv = np.zeros((len(refs), count, NUM_PARTS, 2), np.int16)
+        sad = np.zeros((len(refs), count, NUM_PARTS), np.uint32)
+        pq = None
+        if pred_q is not None:
+            pred_q = np.ascontiguousarray(pred_q, dtype=np.int16)
+            assert pred_q.shape == (len(refs), n, 2)
+            pq = pred_q.ctypes.data
+        arr = (C.c_void_p * len(refs))(*[r.h for r in refs])
+        self._check(self.L.hmme_search_frame_multi(self.h, cur.h, arr, len(refs), C.byref(fp), pq, mv.ctypes.data, sad.ctypes.data))
+        return mv, sad
+
+    def search_frame_multi_device(self, cur, refs, fp, d_pred, d_mv, d_sad, stream=0):
+        arr = (C.c_void_p * len(refs))(*[r.h for r in refs])
+        self._check(self.L.hmme_search_frame_multi_device(self.h, cur.h, arr, len(refs), C.byref(fp), d_pred, d_mv, d_sad, stream))
 
     def search_frame_device(self, cur, ref, fp, d_pred, d_mv, d_sad, stream=0):
         self._check(self.L.hmme_search_frame_device(self.h, cur.h, ref.h, C.byref(fp), d_pred, d_mv, d_sad, stream))

@@ -137,6 +137,15 @@ int hmme_search_frame_device(hmme_ctx* ctx, const hmme_plane* cur, const hmme_pl
                              const hmme_frame_params* fp, const void* d_pred_q, void* d_out_mv, void* d_out_sad,
                              void* stream);
 
+/* several reference pictures of one current picture in ONE launch (HM's low-delay P configuration searches 4 per
+ * picture, cfg/encoder_lowdelay_P_main.cfg:24-27).  refs: n_refs (<= 16) planes of the picture size.
+ * pred_q: int16[n_refs][n_ctu][2] or NULL; out_mv: int16[n_refs][count][593][2]; out_sad: uint32[n_refs][count][593] */
+int hmme_search_frame_multi(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* const* refs, int n_refs,
+                            const hmme_frame_params* fp, const int16_t* pred_q, int16_t* out_mv, uint32_t* out_sad);
+int hmme_search_frame_multi_device(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* const* refs, int n_refs,
+                                   const hmme_frame_params* fp, const void* d_pred_q, void* d_out_mv, void* d_out_sad,
+                                   void* stream);
+
 /* ---- measurement helpers (bench.py) ------------------------------------------------------ */
 /* average device time in ms of the search kernel over `reps` back-to-back launches on `stream`,
  * measured with hipEvents recorded on that stream */

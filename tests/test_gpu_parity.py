@@ -386,3 +386,32 @@ def test_sequence_driver_single_gpu(tmp_path):
     assert d["pairs"] == 9 and d["gpus"] == 1
     # frame t is the texture shifted by (3t, 2t): pair (4, 0) -> MV (-12, -8) for cur(x) = ref(x + mv) ... sign per synth.make_pair
     assert d["first_pairs"][0] == [4, 0] and [abs(v) for v in d["median_mv_64x64_of_first_pairs"][0]] == [12, 8]
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_multi_reference_launch_equals_per_reference_searches(engine, bd):
+    """hmme_search_frame_multi: the low-delay P structure searches 4 references per picture (reference
+    cfg/encoder_lowdelay_P_main.cfg:24-27); one launch must equal four single-reference searches"""
+    from hmme import synth
+    w, h, sr = 256, 192, 16
+    m = synth.MARGIN
+    engine.set_lambda(57.9)
+    cur, _, _ = synth.make_pair(w, h, seed=1, bit_depth=bd, max_mv=0, shift=(0, 0), pad=40)
+    pc = engine.plane(w, h, bd)
+    pc.upload_pel(cur, (m, m))
+    refs = []
+    for t in range(1, 5):
+        r, _, _ = synth.make_pair(w, h, seed=1, bit_depth=bd, max_mv=0, shift=(3 * t, -2 * t), pad=40)
+        pl = engine.plane(w, h, bd)
+        pl.upload_pel(r, (m, m))
+        refs.append(pl)
+    n_ctu = 4 * 3
+    pred = np.stack([synth.random_predictors(n_ctu, seed=10 + t, max_pel=8) for t in range(4)])
+    mv, sad = engine.search_frame_multi(pc, refs, sr, pred)
+    for t in range(4):
+        mv1, sad1 = engine.search_frame(pc, refs[t], sr, pred[t])
+        assert np.array_equal(mv[t], mv1) and np.array_equal(sad[t], sad1), t
+    assert len({tuple(mv[t, 5, 592]) for t in range(4)}) == 4      # the four references really differ
+    for pl in refs:
+        pl.close()
+    pc.close()
