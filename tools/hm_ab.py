@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""A/B run of the reference's own encoder (oracle/_ref/TAppEncoder_hmme, built by `make -C oracle dropin`)
+with its CPU searches and with the HIP engine behind TEncOpenCL: bits / PSNR / wall time per configuration.
+SURVEY.md 8f row 4.  Usage: python tools/hm_ab.py [--size 416x240] [--frames 5] [--search-range 64]"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "hm-opencl_amd"))
+from hmme import synth, yuv  # noqa: E402
+
+EXE = os.path.join(ROOT, "oracle", "_ref", "TAppEncoder_hmme")
+CFG = os.path.join(ROOT, "tests", "hm", "lowdelay_P_small.cfg")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", default="416x240")
+    ap.add_argument("--frames", type=int, default=5)
+    ap.add_argument("--search-range", type=int, default=64)
+    args = ap.parse_args()
+    w, h = (int(v) for v in args.size.split("x"))
+    tmp = tempfile.mkdtemp()
+    src = os.path.join(tmp, "in.yuv")
+    pics = []
+    for t in range(args.frames):   # textured content with per-region motion that grows over time + noise
+        cur, _, _ = synth.make_pair(w, h, seed=11, max_mv=2, region=96, noise_sigma=1.5, shift=(3 * t, -2 * t),
+                                    pad=3 * args.frames + 8, margin=0)
+        pics.append(cur.astype(np.uint8))
+    yuv.write_luma_420(src, pics)
+    rows = []
+    for name, extra in (("CPU TZ search (FastSearch=1)", ["--OpenCL=0", "--FastSearch=1"]),
+                        ("CPU full search (FastSearch=0)", ["--OpenCL=0", "--FastSearch=0"]),
+                        ("hmme behind TEncOpenCL (OpenCL=1)", ["--OpenCL=1", "--FastSearch=1", "--KernelOpenCL=embedded"])):
+        t0 = time.time()
+        r = subprocess.run([EXE, "-c", CFG, "-i", src, "-wdt", str(w), "-hgt", str(h), "-fr", "30", "-f", str(args.frames),
+                            f"--SearchRange={args.search_range}", "-b", os.path.join(tmp, "s.bin"), *extra],
+                           capture_output=True, text=True, env=dict(os.environ, HMME_TRACE="1"), cwd=tmp)
+        dt = time.time() - t0
+        if r.returncode != 0:
+            rows.append({"config": name, "error": r.stderr[-300:]})
+            continue
+        pocs = re.findall(r"POC\s+(\d+).*?(\d+) bits \[Y ([0-9.]+) dB", r.stdout)
+        p_bits = sum(int(b) for p, b, y in pocs if int(p) > 0)
+        p_psnr = float(np.mean([float(y) for p, b, y in pocs if int(p) > 0]))
+        m = re.search(r"(\d+) calcMotionVectors calls, (\d+) failed", r.stderr)
+        rows.append({"config": name, "P_bits": p_bits, "P_psnr_y": round(p_psnr, 3), "wall_s": round(dt, 2),
+                     "engine_calls": int(m.group(1)) if m else 0})
+    print(json.dumps({"clip": f"{w}x{h} x {args.frames} synthetic", "search_range": args.search_range, "runs": rows}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
