@@ -119,6 +119,12 @@ class Plane:
             self.engine.L.hmme_plane_destroy(self.h)
             self.h = None
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
 
 class Engine:
     """one context = one GPU (reference: one TEncOpenCL object, TEncTop.h:82)"""
@@ -139,6 +145,12 @@ class Engine:
         if self.h:
             self.L.hmme_destroy(self.h)
             self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     @property
     def device_info(self):

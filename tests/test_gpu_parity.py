@@ -415,3 +415,34 @@ def test_multi_reference_launch_equals_per_reference_searches(engine, bd):
     for pl in refs:
         pl.close()
     pc.close()
+
+
+def test_device_resident_producer_and_async_api(engine, oracle_lib):
+    """planes filled from device memory (a torch tensor) and the asynchronous, all-device entry point that
+    bench.py uses, with per-CTU predictors living on the device"""
+    import torch
+    from hmme import api, synth
+    w, h, sr = 320, 192, 24
+    cur, ref, _ = synth.make_pair(w, h, seed=21, max_mv=9, region=64)
+    m = synth.MARGIN
+    dev = torch.device("cuda", 0)
+    t_cur = torch.from_numpy(cur[m:m + h, m:m + w].astype(np.uint8)).to(dev)
+    t_ref = torch.from_numpy(np.ascontiguousarray(ref[m:m + h, m:m + w].astype(np.uint8))).to(dev)
+    n_ctu = 5 * 3
+    pred = synth.random_predictors(n_ctu, seed=2, max_pel=10)
+    d_pred = torch.from_numpy(pred).to(dev)
+    d_mv = torch.zeros((n_ctu, 593, 2), dtype=torch.int16, device=dev)
+    d_sad = torch.zeros((n_ctu, 593), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    engine.set_lambda(57.9)
+    with engine.plane(w, h) as pc, engine.plane(w, h) as pr:
+        pc.set_device_u8(t_cur.data_ptr(), t_cur.stride(0), stream)
+        pr.set_device_u8(t_ref.data_ptr(), t_ref.stride(0), stream)
+        fp = api.FrameParams(sr, 1, 8, 0, n_ctu)
+        engine.search_frame_device(pc, pr, fp, d_pred.data_ptr(), d_mv.data_ptr(), d_sad.data_ptr(), stream)
+        torch.cuda.synchronize()
+        ms = engine.time_search_kernel(pc, pr, fp, d_pred.data_ptr(), d_mv.data_ptr(), d_sad.data_ptr(), stream, reps=2)
+    assert ms > 0
+    ox, oy, osad = oracle_lib.search_frame(cur, ref, (m, m), w, h, sr, pred, engine.lambda_q16, 1, 8, n_threads=4)
+    assert np.array_equal(d_mv.cpu().numpy()[:, :, 0], ox) and np.array_equal(d_mv.cpu().numpy()[:, :, 1], oy)
+    assert np.array_equal(d_sad.cpu().numpy().astype(np.uint32), osad)
