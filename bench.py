@@ -103,7 +103,14 @@ def cpu_baseline(cur, ref, w, h, sr, lq, bd=8, budget_s=14.0):
     n_tz = cores * 4
     t0 = time.time(); O.tz_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, bd, first, n_tz, cores, True); dt = time.time() - t0
     n_tz = max(cores, min(ctus_x * 28, int(n_tz * (budget_s * 0.3) / max(dt, 1e-3)) // cores * cores))
-    t0 = time.time(); probes, s4 = O.tz_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, bd, first, n_tz, cores, True); dt_tz = time.time() - t0
+    probes = s4 = 0
+    passes = 0
+    t0 = time.time()
+    while passes == 0 or (time.time() - t0 < 3.0 and passes < 200):   # repeat the sample until it is long enough to time
+        p_, s_ = O.tz_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, bd, first, n_tz, cores, True)
+        probes += p_; s4 += s_; passes += 1
+    dt_tz = time.time() - t0
+    n_tz *= passes
     return {
         "value": round(sads_full / dt_full / 1e9, 4), "unit": "GSAD/s", "cores": cores, "kind": "port",
         "sample": f"oracle exhaustive search (xPatternSearch restatement, all 593 PUs) of {n_full} interior CTUs of the "
