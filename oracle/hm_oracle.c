@@ -634,3 +634,138 @@ int hmo_tz_frame(const hmo_pel* cur, int cur_stride, const hmo_pel* ref, int ref
   for (int t = 0; t < n_threads; ++t) { *probes += jobs[t].probes; *sad4x4 += jobs[t].sad4x4; }
   return ctu_count;
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* fractional-pel refinement: the step after the integer search                          */
+/*   TEncSearch::xPatternSearchFracDIF (TEncSearch.cpp:4294-4331), xPatternRefinement      */
+/*   (:816-875, tables :51-75), xExtDIFUpSamplingH/Q (:5386-5600) over                     */
+/*   TComInterpolationFilter (TComInterpolationFilter.cpp:57-63, :170-260) and             */
+/*   TComRdCost::xGetHADs / xCalcHADs4x4 / xCalcHADs8x8 (TComRdCost.cpp:1343-1604)         */
+/* ------------------------------------------------------------------------------------ */
+
+/* luma filter taps, TComInterpolationFilter.cpp:57-63 */
+static const int k_luma_filter[4][8] = {
+    {0, 0, 0, 64, 0, 0, 0, 0}, {-1, 4, -10, 58, 17, -5, 1, 0}, {-1, 4, -11, 40, 40, -11, 4, -1}, {0, 1, -5, 17, 58, -10, 4, -1}};
+
+/* Predicted w x h luma block at the quarter-pel displacement (qx, qy) from `ref` (the PU origin in the
+ * reference plane).  What the search's m_filteredBlock tables hold: horizontal pass into 14-bit
+ * intermediates (filter<8,false,true,false>), vertical pass with final rounding and clip
+ * (filter<8,true,false,true>); fraction 0 = filterCopy, which is the same formula with taps {64}. */
+void hmo_pred_block_qpel(const hmo_pel* ref, int ref_stride, int w, int h, int qx, int qy, int bit_depth,
+                         hmo_pel* dst, int dst_stride) {
+  const int ix = qx >> 2, fx = qx & 3, iy = qy >> 2, fy = qy & 3;
+  const int head = (14 - bit_depth) > 2 ? (14 - bit_depth) : 2;   /* headRoom */
+  const int sh1 = 6 - head;
+  const int off1 = -(8192 << sh1);
+  const int sh2 = 6 + head;
+  const int off2 = (1 << (sh2 - 1)) + (8192 << 6);
+  const int maxv = (1 << bit_depth) - 1;
+  const int* ch = k_luma_filter[fx];
+  const int* cv = k_luma_filter[fy];
+  static __thread hmo_pel tmp[(64 + 7) * 64];
+  const hmo_pel* src = ref + (ptrdiff_t)(iy - 3) * ref_stride + ix;
+  for (int r = 0; r < h + 7; ++r) {
+    for (int c = 0; c < w; ++c) {
+      int sum = 0;
+      for (int k = 0; k < 8; ++k) sum += ch[k] * src[c + k - 3];
+      tmp[r * 64 + c] = (hmo_pel)((sum + off1) >> sh1);
+    }
+    src += ref_stride;
+  }
+  for (int r = 0; r < h; ++r)
+    for (int c = 0; c < w; ++c) {
+      int sum = 0;
+      for (int k = 0; k < 8; ++k) sum += cv[k] * tmp[(r + k) * 64 + c];
+      int v = (sum + off2) >> sh2;
+      v = v < 0 ? 0 : (v > maxv ? maxv : v);
+      dst[r * dst_stride + c] = (hmo_pel)v;
+    }
+}
+
+/* TComRdCost::xCalcHADs4x4 (TComRdCost.cpp:1343-1437): sum |4x4 Hadamard(org - cur)|, (satd + 1) >> 1 */
+static uint32_t had4x4(const hmo_pel* o, int os, const hmo_pel* c, int cs) {
+  int d[16], m[16];
+  for (int r = 0; r < 4; ++r)
+    for (int k = 0; k < 4; ++k) d[4 * r + k] = o[r * os + k] - c[r * cs + k];
+  for (int r = 0; r < 4; ++r) {   /* rows */
+    const int a = d[4 * r] + d[4 * r + 3], b = d[4 * r + 1] + d[4 * r + 2], e = d[4 * r + 1] - d[4 * r + 2], f = d[4 * r] - d[4 * r + 3];
+    m[4 * r] = a + b; m[4 * r + 1] = a - b; m[4 * r + 2] = f + e; m[4 * r + 3] = f - e;
+  }
+  uint32_t satd = 0;
+  for (int k = 0; k < 4; ++k) {   /* columns */
+    const int a = m[k] + m[12 + k], b = m[4 + k] + m[8 + k], e = m[4 + k] - m[8 + k], f = m[k] - m[12 + k];
+    satd += (uint32_t)(abs(a + b) + abs(a - b) + abs(f + e) + abs(f - e));
+  }
+  return (satd + 1) >> 1;
+}
+
+/* TComRdCost::xCalcHADs8x8 (TComRdCost.cpp:1439-1534): sum |8x8 Hadamard(org - cur)|, (sad + 2) >> 2 */
+static uint32_t had8x8(const hmo_pel* o, int os, const hmo_pel* c, int cs) {
+  int m[64];
+  for (int r = 0; r < 8; ++r)
+    for (int k = 0; k < 8; ++k) m[8 * r + k] = o[r * os + k] - c[r * cs + k];
+  for (int pass = 0; pass < 2; ++pass) {          /* unnormalised Walsh-Hadamard along rows, then columns */
+    const int stride_e = pass ? 8 : 1, stride_v = pass ? 1 : 8;
+    for (int v = 0; v < 8; ++v)
+      for (int len = 1; len < 8; len <<= 1)
+        for (int i = 0; i < 8; i += 2 * len)
+          for (int j = i; j < i + len; ++j) {
+            int* a = &m[v * stride_v + j * stride_e];
+            int* b = &m[v * stride_v + (j + len) * stride_e];
+            const int x = *a, y = *b;
+            *a = x + y; *b = x - y;
+          }
+  }
+  uint32_t sad = 0;
+  for (int i = 0; i < 64; ++i) sad += (uint32_t)abs(m[i]);
+  return (sad + 2) >> 2;
+}
+
+/* TComRdCost::xGetHADs (TComRdCost.cpp:1537-1604) for iStep == 1 */
+uint32_t hmo_had(const hmo_pel* org, int org_stride, const hmo_pel* cur, int cur_stride, int w, int h, int bit_depth) {
+  uint32_t sum = 0;
+  if ((h % 8 == 0) && (w % 8 == 0)) {
+    for (int y = 0; y < h; y += 8)
+      for (int x = 0; x < w; x += 8) sum += had8x8(org + y * org_stride + x, org_stride, cur + y * cur_stride + x, cur_stride);
+  } else {
+    for (int y = 0; y < h; y += 4)
+      for (int x = 0; x < w; x += 4) sum += had4x4(org + y * org_stride + x, org_stride, cur + y * cur_stride + x, cur_stride);
+  }
+  return sum >> (bit_depth - 8);
+}
+
+/* refinement point orders, TEncSearch.cpp:51-75 */
+static const int k_refine_h[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};
+static const int k_refine_q[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {1, 1}};
+
+/* xPatternSearchFracDIF for one PU.  `ref` = reference plane at the PU origin; (int_x, int_y) = the integer MV.
+ * out: half-pel offset (-1..1), quarter-pel offset (-1..1), cost of the winner (distortion + MV cost at scale 0).
+ * The final quarter-pel MV is (int << 2) + (half << 1) + qter (TEncSearch.cpp:3800-3803). */
+void hmo_frac_refine(const hmo_pel* org, int org_stride, int w, int h, const hmo_pel* ref, int ref_stride, int int_x,
+                     int int_y, int pred_x, int pred_y, uint32_t lambda_q16, int use_had, int bit_depth, int* half_x,
+                     int* half_y, int* qter_x, int* qter_y, uint32_t* cost) {
+  hmo_pel blk[64 * 64];
+  uint32_t best = UINT_MAX;
+  int bi = 0;
+  /* half-pel stage: xPatternRefinement(iFrac = 2), MV cost at scale 1 around rcMvHalf = int << 1 */
+  for (int i = 0; i < 9; ++i) {
+    const int hx = k_refine_h[i][0], hy = k_refine_h[i][1];
+    hmo_pred_block_qpel(ref, ref_stride, w, h, 4 * int_x + 2 * hx, 4 * int_y + 2 * hy, bit_depth, blk, 64);
+    uint32_t d = use_had ? hmo_had(org, org_stride, blk, 64, w, h, bit_depth) : hmo_sad(org, org_stride, blk, 64, w, h, 0, bit_depth);
+    d += hmo_mv_cost(lambda_q16, 2 * int_x + hx, 2 * int_y + hy, pred_x, pred_y, 1);
+    if (d < best) { best = d; bi = i; }
+  }
+  *half_x = k_refine_h[bi][0]; *half_y = k_refine_h[bi][1];
+  /* quarter-pel stage: xPatternRefinement(iFrac = 1), cost scale 0 around rcMvQter = ((int << 1) + half) << 1 */
+  const int bx = 4 * int_x + 2 * *half_x, by = 4 * int_y + 2 * *half_y;
+  best = UINT_MAX; bi = 0;
+  for (int i = 0; i < 9; ++i) {
+    const int qx = k_refine_q[i][0], qy = k_refine_q[i][1];
+    hmo_pred_block_qpel(ref, ref_stride, w, h, bx + qx, by + qy, bit_depth, blk, 64);
+    uint32_t d = use_had ? hmo_had(org, org_stride, blk, 64, w, h, bit_depth) : hmo_sad(org, org_stride, blk, 64, w, h, 0, bit_depth);
+    d += hmo_mv_cost(lambda_q16, bx + qx, by + qy, pred_x, pred_y, 0);
+    if (d < best) { best = d; bi = i; }
+  }
+  *qter_x = k_refine_q[bi][0]; *qter_y = k_refine_q[bi][1];
+  *cost = best;
+}

@@ -107,6 +107,16 @@ int hmo_search_frame(const hmo_pel* cur, int cur_stride, const hmo_pel* ref, int
                      uint32_t lambda_q16, int fen, int bit_depth, int ctu_first, int ctu_count,
                      int n_threads, int32_t* out_x, int32_t* out_y, uint32_t* out_sad);
 
+/* ---- fractional-pel refinement (the step after the integer search) -------------
+ * canonical luma prediction block at a quarter-pel displacement (what TEncSearch's m_filteredBlock tables
+ * hold), xGetHADs, and xPatternSearchFracDIF for one PU */
+void hmo_pred_block_qpel(const hmo_pel* ref, int ref_stride, int w, int h, int qx, int qy, int bit_depth,
+                         hmo_pel* dst, int dst_stride);
+uint32_t hmo_had(const hmo_pel* org, int org_stride, const hmo_pel* cur, int cur_stride, int w, int h, int bit_depth);
+void hmo_frac_refine(const hmo_pel* org, int org_stride, int w, int h, const hmo_pel* ref, int ref_stride, int int_x,
+                     int int_y, int pred_x, int pred_y, uint32_t lambda_q16, int use_had, int bit_depth, int* half_x,
+                     int* half_y, int* qter_x, int* qter_y, uint32_t* cost);
+
 /* CPU baseline leg of bench.py: xTZSearch for the 64x64 PU (all_slots=0) or for all 593 PU
  * rectangles (all_slots=1) of every CTU in [ctu_first, ctu_first+ctu_count), threaded over CTUs.
  * probes = SAD evaluations; sad4x4 = the same work in 4x4-block-SAD equivalents (w*h/16 per probe,

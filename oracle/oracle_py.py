@@ -90,6 +90,12 @@ def oracle():
         L.hmo_search_frame.argtypes = [C.POINTER(C.c_int16), C.c_int, C.POINTER(C.c_int16), C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_int, _i32p, _i32p, _u32p]
+        L.hmo_frac_refine.restype = None
+        L.hmo_frac_refine.argtypes = ([C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int16), C.c_int]
+                                      + [C.c_int] * 4 + [C.c_uint32, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4
+                                      + [C.POINTER(C.c_uint32)])
+        L.hmo_had.restype = C.c_uint32
+        L.hmo_had.argtypes = [C.POINTER(C.c_int16), C.c_int, C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int, C.c_int]
         L.hmo_tz_frame.restype = C.c_int
         L.hmo_tz_frame.argtypes = [C.POINTER(C.c_int16), C.c_int, C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -128,6 +134,10 @@ def ref():
         L.ref_tz_search.argtypes = ([C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int16), C.c_int]
                                     + [C.c_int] * 6 + [C.c_double, C.c_int, C.c_int] + [C.c_int] * 9
                                     + [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint32)])
+        L.ref_frac_refine.restype = None
+        L.ref_frac_refine.argtypes = ([C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int16), C.c_int]
+                                      + [C.c_int] * 4 + [C.c_double, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4
+                                      + [C.POINTER(C.c_uint32)])
         _ref = L
     return _ref
 
@@ -223,3 +233,20 @@ def tz_frame(cur, ref_plane, origin, pic_w, pic_h, sr, pred_q, lambda_q16, fen, 
     if want_results:
         return probes.value, s4.value, ox, oy, osad
     return probes.value, s4.value
+
+
+def frac_refine(plane_cur, cur_xy, plane_ref, ref_xy, w, h, int_mv, pred, lam_or_q16, use_had, bit_depth, use_ref=False):
+    """xPatternSearchFracDIF for one PU: the oracle (lam_or_q16 = lambda_q16) or the reference (lam_or_q16 = lambda).
+    -> (half_x, half_y, qter_x, qter_y, cost)"""
+    cs, rs = plane_cur.shape[1], plane_ref.shape[1]
+    org = _addr(plane_cur, cur_xy[1] * cs + cur_xy[0])
+    rf = _addr(plane_ref, ref_xy[1] * rs + ref_xy[0])
+    o = [C.c_int() for _ in range(4)]
+    cost = C.c_uint32()
+    if use_ref:
+        ref().ref_frac_refine(org, cs, w, h, rf, rs, int_mv[0], int_mv[1], pred[0], pred[1], float(lam_or_q16), int(use_had),
+                              bit_depth, *[C.byref(v) for v in o], C.byref(cost))
+    else:
+        oracle().hmo_frac_refine(org, cs, w, h, rf, rs, int_mv[0], int_mv[1], pred[0], pred[1], int(lam_or_q16), int(use_had),
+                                 bit_depth, *[C.byref(v) for v in o], C.byref(cost))
+    return tuple(v.value for v in o) + (cost.value,)

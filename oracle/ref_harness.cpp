@@ -170,4 +170,23 @@ void ref_tz_search(int16_t* org, int org_stride, int w, int h, int16_t* ref_at_p
   *mvx = mv.getHor(); *mvy = mv.getVer(); *sad = d;
 }
 
+// TEncSearch::xPatternSearchFracDIF for one PU, set up like xMotionEstimation does (TEncSearch.cpp:3792-3798):
+// getMotionCost(true, 0, ...), cost scale 1; the function itself switches to scale 0 for the quarter stage.
+void ref_frac_refine(int16_t* org, int org_stride, int w, int h, int16_t* ref_at_pu, int ref_stride, int int_x, int int_y,
+                     int pred_x, int pred_y, double lambda, int use_had, int bit_depth, int* half_x, int* half_y,
+                     int* qter_x, int* qter_y, uint32_t* cost) {
+  Rig& r = rig();
+  static bool buffers = false;
+  if (!buffers) { r.search->initTempBuff(CHROMA_420); buffers = true; }
+  setup_cost(lambda, pred_x, pred_y, bit_depth);
+  r.rd->setCostScale(1);
+  r.cfg->setUseHADME(use_had != 0);
+  TComPattern pat;
+  pat.initPattern(org, w, h, org_stride, bit_depth);
+  TComMv mv((Short)int_x, (Short)int_y), half, qter;
+  Distortion d = 0;
+  r.search->xPatternSearchFracDIF(false, &pat, ref_at_pu, ref_stride, &mv, half, qter, d, false);
+  *half_x = half.getHor(); *half_y = half.getVer(); *qter_x = qter.getHor(); *qter_y = qter.getVer(); *cost = d;
+}
+
 }  // extern "C"

@@ -12,6 +12,7 @@ Every .npz holds inputs and the reference's outputs -- data only.
   search_sr8.npz   G1  xPatternSearch on all 593 PU rectangles of a CTU, SR 8, many parameter mixes
   search_sr64.npz  G1  same at SR 64 (two cases)
   tz.npz           G5  xTZSearch for a set of PUs
+  frac.npz             xPatternSearchFracDIF (half + quarter-pel refinement, HAD or SAD) for a set of PUs
 """
 import ctypes as C
 import os
@@ -237,6 +238,38 @@ def gen_tz(table):
     print("tz:", len(rows))
 
 
+def gen_frac(table):
+    """xPatternSearchFracDIF: (PU, integer MV, predictor, lambda, HAD on/off, bit depth) -> (half, quarter, cost)"""
+    rng = np.random.default_rng(23)
+    planes = {}
+    for bd in (8, 10):
+        cur_p, ref_p, _ = synth.make_pair(192, 192, seed=50 + bd, bit_depth=bd, max_mv=3, region=64, margin=16, noise_sigma=2.0)
+        planes[bd] = (cur_p, ref_p)
+    rows, outs = [], []
+    for it in range(160):
+        bd = 10 if it % 4 == 3 else 8
+        cur_p, ref_p = planes[bd]
+        slot = int(rng.integers(0, 593)) if it >= 20 else [592, 588, 590, 576, 512, 544, 448, 256, 300, 340, 384, 0, 128, 130, 584, 560, 568, 520, 530, 480][it]
+        x, y, w, h = (int(v) for v in table[table[:, 0] == slot][0, 6:10])
+        mv = [int(v) for v in rng.integers(-6, 7, size=2)]
+        pred = [int(v) for v in rng.integers(-40, 41, size=2)]
+        lam = float(rng.choice([0.0, 4.7, 57.9, 900.0]))
+        had = int(it % 5 != 4)
+        o = 16 + 64
+        cs = cur_p.shape[1]
+        off = (o + y) * cs + o + x
+        h_ = [C.c_int() for _ in range(4)]
+        cost = C.c_uint32()
+        R.ref_frac_refine(O._addr(cur_p, off), cs, w, h, O._addr(ref_p, off), cs, mv[0], mv[1], pred[0], pred[1], lam, had, bd,
+                          *[C.byref(v) for v in h_], C.byref(cost))
+        rows.append((slot, x, y, w, h, mv[0], mv[1], pred[0], pred[1], had, bd, R.ref_lambda_q16(lam), o))
+        outs.append(tuple(v.value for v in h_) + (cost.value,))
+    np.savez_compressed(os.path.join(HERE, "frac.npz"), rows=np.array(rows, np.int64), out=np.array(outs, np.int64),
+                        cur8=planes[8][0], ref8=planes[8][1], cur10=planes[10][0], ref10=planes[10][1],
+                        columns=np.array("slot x y w h int_x int_y pred_x pred_y had bit_depth lambda_q16 origin".split()))
+    print("frac:", len(rows))
+
+
 def main():
     global R
     O.build(ref=True)
@@ -271,6 +304,7 @@ def main():
     ]
     gen_search(table, "search_sr64.npz", sr64)
     gen_tz(table)
+    gen_frac(table)
 
 
 if __name__ == "__main__":

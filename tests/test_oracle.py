@@ -144,3 +144,15 @@ def test_search_frame_matches_per_ctu(oracle_lib):
                                    (int(pred[ctu, 0]), int(pred[ctu, 1])), lq, 1, 8)
         x1, y1, s1 = oracle_lib.search_ctu(cur, (80 + cx, 80 + cy), ref, (80 + cx, 80 + cy), p)
         assert np.array_equal(x1, ox[ctu]) and np.array_equal(y1, oy[ctu]) and np.array_equal(s1, osad[ctu])
+
+
+def test_fractional_refinement(oracle_lib):
+    # reference: TEncSearch::xPatternSearchFracDIF (TEncSearch.cpp:4294-4331) incl. interpolation and Hadamard cost
+    d = g("frac.npz")
+    planes = {8: (np.ascontiguousarray(d["cur8"]), np.ascontiguousarray(d["ref8"])),
+              10: (np.ascontiguousarray(d["cur10"]), np.ascontiguousarray(d["ref10"]))}
+    for row, want in zip(d["rows"], d["out"]):
+        slot, x, y, w, h, ix, iy, px, py, had, bd, lq, o = (int(v) for v in row)
+        cur, ref = planes[bd]
+        got = oracle_lib.frac_refine(cur, (o + x, o + y), ref, (o + x, o + y), w, h, (ix, iy), (px, py), lq, had, bd)
+        assert got == tuple(int(v) for v in want), row

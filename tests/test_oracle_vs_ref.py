@@ -48,3 +48,22 @@ def test_cost_and_bits_match_reference(oracle_lib):
         for _ in range(100):
             x, y, px, py = (int(v) for v in rng.integers(-300, 301, size=4))
             assert L.hmo_mv_cost(lq, x, y, px, py, 2) == R.ref_mv_cost(lam, x, y, px, py)
+
+
+def test_fractional_refinement_matches_reference(oracle_lib):
+    from hmme import synth
+    rng = np.random.default_rng(99)
+    table = oracle_lib.slot_table()
+    for it in range(40):
+        bd = 8 if it % 3 else 10
+        cur, ref, _ = synth.make_pair(160, 160, seed=200 + it, bit_depth=bd, max_mv=3, region=64, margin=16, noise_sigma=3.0)
+        x, y, w, h = (int(v) for v in table[int(rng.integers(0, 593))])
+        mv = (int(rng.integers(-5, 6)), int(rng.integers(-5, 6)))
+        pred = (int(rng.integers(-50, 51)), int(rng.integers(-50, 51)))
+        lam = float(rng.choice([0.0, 12.0, 57.9, 3000.0]))
+        had = int(rng.integers(0, 2))
+        lq = oracle_lib.oracle().hmo_lambda_q16(lam)
+        o = 16 + 48
+        a = oracle_lib.frac_refine(cur, (o + x, o + y), ref, (o + x, o + y), w, h, mv, pred, lq, had, bd)
+        b = oracle_lib.frac_refine(cur, (o + x, o + y), ref, (o + x, o + y), w, h, mv, pred, lam, had, bd, use_ref=True)
+        assert a == b, (it, w, h, mv, pred, lam, had, bd)
