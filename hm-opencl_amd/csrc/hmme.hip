@@ -56,6 +56,12 @@ struct hmme_ctx {
   int out_cap = 0;
   int* d_flag = nullptr;
   bool lds_optin[4] = {false, false, false, false};
+  uint32_t* d_frac_items = nullptr;   // fractional refinement: (slot, 4x4 sub-block) work list, same for every CTU
+  bool frac_optin[2] = {false, false};
+  int16_t* d_imv = nullptr;           // host-facing refine call: integer MVs / quarter-pel MVs / costs on the device
+  int16_t* d_qmv = nullptr;
+  uint32_t* d_fcost = nullptr;
+  size_t refine_cap = 0;
 };
 
 struct hmme_plane {
@@ -311,6 +317,7 @@ void hmme_destroy(hmme_ctx* ctx) {
   hipFree(ctx->d_ctu); hipFree(ctx->d_win); hipFree(ctx->d_mv1); hipFree(ctx->d_sad1); hipFree(ctx->d_job1);
   hipFree(ctx->d_jobs); hipFree(ctx->d_first_strip); hipFree(ctx->d_best);
   hipFree(ctx->d_pred); hipFree(ctx->d_mv); hipFree(ctx->d_sad); hipFree(ctx->d_flag);
+  hipFree(ctx->d_frac_items); hipFree(ctx->d_imv); hipFree(ctx->d_qmv); hipFree(ctx->d_fcost);
   if (ctx->h_stage) hipHostFree(ctx->h_stage);
   if (ctx->h_mv) hipHostFree(ctx->h_mv);
   if (ctx->h_sad) hipHostFree(ctx->h_sad);
@@ -669,6 +676,124 @@ int hmme_search_frame_multi(hmme_ctx* ctx, const hmme_plane* cur, const hmme_pla
 int hmme_search_frame(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp,
                       const int16_t* pred_q, int16_t* out_mv, uint32_t* out_sad) {
   return hmme_search_frame_multi(ctx, cur, &ref, 1, fp, pred_q, out_mv, out_sad);
+}
+
+// ---- fractional-pel refinement -------------------------------------------------------------------------------
+namespace {
+// work list of me_frac_kernel: every slot cut into 4x4 sub-blocks; slots whose width and height are multiples of 8
+// (8x8 Hadamard blocks, xGetHADs) first, quadrant by quadrant (TL, TR, BL, BR on 4 consecutive lanes), then the rest
+int build_frac_items(hmme_ctx* ctx) {
+  if (ctx->d_frac_items) return HMME_OK;
+  std::vector<uint32_t> items;
+  for (int pass = 0; pass < 2; ++pass)
+    for (int slot = 0; slot < HMME_NUM_CTU_PARTS; ++slot) {
+      int x, y, w, h;
+      hmme_slot_rect(slot, &x, &y, &w, &h);
+      const bool kind8 = (w % 8 == 0) && (h % 8 == 0);
+      if (kind8 != (pass == 0)) continue;
+      if (kind8) {
+        for (int by = 0; by < h; by += 8)
+          for (int bx = 0; bx < w; bx += 8)
+            for (int q = 0; q < 4; ++q)
+              items.push_back((uint32_t)slot | (uint32_t)((x + bx) / 4 + (q & 1)) << 10 | (uint32_t)((y + by) / 4 + (q >> 1)) << 14 | 1u << 18);
+      } else {
+        for (int by = 0; by < h; by += 4)
+          for (int bx = 0; bx < w; bx += 4) items.push_back((uint32_t)slot | (uint32_t)((x + bx) / 4) << 10 | (uint32_t)((y + by) / 4) << 14);
+      }
+    }
+  if ((int)items.size() != hmme::kFracItems) return fail(ctx, HMME_ERR_DEVICE, "internal: %zu refinement items", items.size());
+  HIP_TRY(ctx, hipMalloc(&ctx->d_frac_items, sizeof(uint32_t) * items.size()));
+  HIP_TRY(ctx, hipMemcpy(ctx->d_frac_items, items.data(), sizeof(uint32_t) * items.size(), hipMemcpyHostToDevice));
+  return HMME_OK;
+}
+}  // namespace
+
+int hmme_refine_frame_multi_device(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* const* refs, int n_refs,
+                                   const hmme_frame_params* fp, const void* d_pred_q, const void* d_int_mv, int use_hadamard,
+                                   void* d_out_qmv, void* d_out_cost, void* stream) {
+  if (!ctx) return HMME_ERR_ARG;
+  if (!refs || n_refs < 1 || n_refs > hmme::kMaxRefs) return fail(ctx, HMME_ERR_ARG, "n_refs %d outside 1..%d", n_refs, hmme::kMaxRefs);
+  int first = 0, count = 0;
+  RefSet set = one_ref(nullptr);
+  for (int r = 0; r < n_refs; ++r) {
+    int rc = check_frame_args(ctx, cur, refs[r], fp, &first, &count);
+    if (rc) return rc;
+    if (refs[r]->pitch != refs[0]->pitch) return fail(ctx, HMME_ERR_ARG, "reference planes differ in pitch");
+    set.base[r] = refs[r]->origin();
+  }
+  if (fp->bit_depth != 8 || fp->search_range > 64)
+    return fail(ctx, HMME_ERR_UNSUPPORTED, "fractional refinement: 8-bit planes and search range <= 64 only in this build");
+  if (!d_int_mv || !d_out_qmv || !d_out_cost) return fail(ctx, HMME_ERR_ARG, "null buffer");
+  if (count == 0) return HMME_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = build_frac_items(ctx);
+  if (rc) return rc;
+  const int jobs = count * n_refs;
+  size_t cap = ctx->jobs_bytes;
+  rc = ensure(ctx, (uint8_t**)&ctx->d_jobs, &cap, sizeof(MeJob) * (size_t)jobs);
+  ctx->jobs_bytes = cap;
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, dim3((jobs + 255) / 256), dim3(256), 0, s, (MeJob*)ctx->d_jobs, (const int16_t*)d_pred_q,
+                     first, count, n_refs, cur->width, cur->height, fp->search_range);
+  HIP_TRY(ctx, hipGetLastError());
+  const int had = use_hadamard ? 1 : 0;
+  if (!ctx->frac_optin[had]) {
+    HIP_TRY(ctx, hipFuncSetAttribute(had ? (const void*)hmme::me_frac_kernel<1> : (const void*)hmme::me_frac_kernel<0>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ctx->frac_optin[had] = true;
+  }
+  if (had)
+    hipLaunchKernelGGL(hmme::me_frac_kernel<1>, dim3(jobs), dim3(hmme::kThreads), hmme::kFracLdsBytes, s, cur->origin(), cur->pitch, set,
+                       refs[0]->pitch, (const MeJob*)ctx->d_jobs, ctx->d_frac_items, (const int16_t*)d_int_mv, ctx->lambda_q16,
+                       (int16_t*)d_out_qmv, (uint32_t*)d_out_cost);
+  else
+    hipLaunchKernelGGL(hmme::me_frac_kernel<0>, dim3(jobs), dim3(hmme::kThreads), hmme::kFracLdsBytes, s, cur->origin(), cur->pitch, set,
+                       refs[0]->pitch, (const MeJob*)ctx->d_jobs, ctx->d_frac_items, (const int16_t*)d_int_mv, ctx->lambda_q16,
+                       (int16_t*)d_out_qmv, (uint32_t*)d_out_cost);
+  HIP_TRY(ctx, hipGetLastError());
+  return HMME_OK;
+}
+
+int hmme_refine_frame(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp, const int16_t* pred_q,
+                      const int16_t* int_mv, int use_hadamard, int16_t* out_qmv, uint32_t* out_cost) {
+  int first, count;
+  int rc = check_frame_args(ctx, cur, ref, fp, &first, &count);
+  if (rc) return rc;
+  if (!int_mv || !out_qmv || !out_cost) return fail(ctx, HMME_ERR_ARG, "null buffer");
+  if (count == 0) return HMME_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int n_ctu = hmme_num_ctus(cur->width, cur->height);
+  const size_t slots = (size_t)HMME_NUM_CTU_PARTS * n_ctu;
+  if (ctx->refine_cap < slots) {
+    hipFree(ctx->d_imv); hipFree(ctx->d_qmv); hipFree(ctx->d_fcost);
+    ctx->d_imv = nullptr; ctx->d_qmv = nullptr; ctx->d_fcost = nullptr; ctx->refine_cap = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_imv, sizeof(int16_t) * 2 * slots));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_qmv, sizeof(int16_t) * 2 * slots));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_fcost, sizeof(uint32_t) * slots));
+    ctx->refine_cap = slots;
+  }
+  size_t pcap = 0;   // predictors share the search path's buffer sizing
+  if (ctx->out_cap < n_ctu) {
+    hipFree(ctx->d_mv); hipFree(ctx->d_sad); hipFree(ctx->d_pred);
+    ctx->d_mv = nullptr; ctx->d_sad = nullptr; ctx->d_pred = nullptr; ctx->out_cap = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_mv, sizeof(int16_t) * 2 * slots));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_sad, sizeof(uint32_t) * slots));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_pred, sizeof(int16_t) * 2 * (size_t)n_ctu));
+    ctx->out_cap = n_ctu;
+  }
+  (void)pcap;
+  hipStream_t s = ctx->stream;
+  const size_t res = (size_t)HMME_NUM_CTU_PARTS * count;
+  if (pred_q) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pred, pred_q, sizeof(int16_t) * 2 * (size_t)n_ctu, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_imv, int_mv, sizeof(int16_t) * 2 * res, hipMemcpyHostToDevice, s));
+  rc = hmme_refine_frame_multi_device(ctx, cur, &ref, 1, fp, pred_q ? ctx->d_pred : nullptr, ctx->d_imv, use_hadamard, ctx->d_qmv,
+                                      ctx->d_fcost, s);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(out_qmv, ctx->d_qmv, sizeof(int16_t) * 2 * res, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipMemcpyAsync(out_cost, ctx->d_fcost, sizeof(uint32_t) * res, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  return HMME_OK;
 }
 
 int hmme_time_search_kernel(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp,

@@ -556,4 +556,231 @@ __global__ void me_prep_jobs_split_kernel(MeJob16* jobs, int* first_strip_of_job
   }
 }
 
+
+// ---- fractional-pel refinement of the integer winners ---------------------------------------------------------
+// The step after the path: TEncSearch::xPatternSearchFracDIF (reference TEncSearch.cpp:4294-4331) for all 593
+// slots of a CTU -- half-pel then quarter-pel refinement around each slot's integer MV with HM's 8-tap luma
+// interpolation (TComInterpolationFilter.cpp:57-63, :170-260) and Hadamard (xGetHADs, TComRdCost.cpp:1537-1604)
+// or SAD distortion.  Work item = one 4x4 sub-block of one slot (6 144 per CTU); one lane per item.  An 8x8
+// Hadamard is assembled from the four 4x4 transforms of its quadrants (H8 = [[H4, H4], [H4, -H4]]) with two
+// quad_perm DPP butterflies, so slots whose size is a multiple of 8 (8x8 Hadamard blocks) and the others (4x4
+// blocks) run the same code.  Per-slot distortions accumulate in LDS (ds_add_u32); 593 threads then add the MV cost
+// and pick the winner in HM's point order (strict '<', tables TEncSearch.cpp:51-75).
+constexpr int kFracItems = 6144;           // sum over slots of w*h/16
+constexpr int kFracPDW = 51;               // window + 4-sample halo: 129 + 63 + 8 = 200 bytes <= 204
+constexpr int kFracRowsMax = 200;
+constexpr int kFracAcc = 593 * 9;
+constexpr size_t kFracLdsBytes = (size_t)(5344 + 600 + 1024 + kFracRowsMax * kFracPDW) * 4;
+
+__device__ __forceinline__ uint32_t me_mv_cost_q(uint32_t lambda_q16, int vx_q, int vy_q, int pred_x, int pred_y) {
+  return (lambda_q16 * (me_component_bits(vx_q - pred_x) + me_component_bits(vy_q - pred_y))) >> 16;
+}
+
+// luma taps of fraction f (0..3), tap t (0..7): TComInterpolationFilter::m_lumaFilter
+__device__ __forceinline__ int me_luma_tap(int f, int t) {
+  constexpr int k1[8] = {-1, 4, -10, 58, 17, -5, 1, 0}, k2[8] = {-1, 4, -11, 40, 40, -11, 4, -1}, k3[8] = {0, 1, -5, 17, 58, -10, 4, -1};
+  const int k0 = t == 3 ? 64 : 0;
+  return f == 0 ? k0 : (f == 1 ? k1[t] : (f == 2 ? k2[t] : k3[t]));
+}
+// the 8 taps of quarter position q (relative, -3..3) as a 9-tap window that starts one sample earlier when the
+// integer part of q is -1: keeps every register index static although q differs from lane to lane
+__device__ __forceinline__ void me_taps9(int q, int (&c9)[9]) {
+  const int f = q & 3, b = (q >> 2) + 1;   // b = 0 or 1
+  int c8[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) c8[t] = me_luma_tap(f, t);
+#pragma unroll
+  for (int j = 0; j < 9; ++j) c9[j] = b ? (j >= 1 ? c8[j - 1] : 0) : (j < 8 ? c8[j] : 0);
+}
+
+// STAGE 0: half-pel points (step 2 quarter units around the integer MV); STAGE 1: quarter-pel points around the
+// slot's half-pel winner (cqx, cqy).  P: 12 patch rows x 12 bytes (3 dwords), patch (0,0) = block (-4,-4).
+template <int STAGE, int HAD>
+__device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3], const int (&org)[16], int cqx, int cqy, bool kind8,
+                                             int role, uint32_t* acc_slot) {
+  constexpr int step = STAGE == 0 ? 2 : 1;
+  // point index of (dx, dy) in s_acMvRefineH / s_acMvRefineQ order (reference TEncSearch.cpp:51-75)
+  constexpr int idxH[3][3] = {{5, 1, 6}, {3, 0, 4}, {7, 2, 8}}, idxQ[3][3] = {{3, 1, 4}, {5, 0, 6}, {7, 2, 8}};   // [dy+1][dx+1]
+  const int s1 = (role & 1) ? -1 : 1, s2 = (role & 2) ? -1 : 1;
+#pragma unroll
+  for (int dxi = 0; dxi < 3; ++dxi) {
+    int ch[9];
+    me_taps9(cqx + step * (dxi - 1), ch);
+    int tmp[12][4];   // horizontal pass into 14-bit intermediates (8-bit video: shift 0, offset -8192)
+#pragma unroll
+    for (int r = 0; r < 12; ++r) {
+      int px[12];
+#pragma unroll
+      for (int j = 0; j < 12; ++j) px[j] = (int)__builtin_amdgcn_ubfe(P[r][j >> 2], 8 * (j & 3), 8);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        int sum = -8192;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) sum += ch[j] * px[c + j];
+        tmp[r][c] = sum;
+      }
+    }
+#pragma unroll
+    for (int dyi = 0; dyi < 3; ++dyi) {
+      int cv[9];
+      me_taps9(cqy + step * (dyi - 1), cv);
+      int d[16];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          int sum = 526336;   // (1 << 11) + (8192 << 6): second pass, shift 12 (TComInterpolationFilter.cpp:195-212)
+#pragma unroll
+          for (int j = 0; j < 9; ++j) sum += cv[j] * tmp[r + j][c];
+          int v = sum >> 12;
+          v = v < 0 ? 0 : (v > 255 ? 255 : v);
+          d[4 * r + c] = org[4 * r + c] - v;
+        }
+      uint32_t contrib;
+      if (!HAD) {
+        uint32_t sad = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sad += (uint32_t)abs(d[i]);
+        contrib = sad;
+      } else {
+        int m[16];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {   // 4x4 Walsh-Hadamard: rows, then columns (xCalcHADs4x4)
+          const int a = d[4 * r] + d[4 * r + 3], b = d[4 * r + 1] + d[4 * r + 2], e = d[4 * r + 1] - d[4 * r + 2], f = d[4 * r] - d[4 * r + 3];
+          m[4 * r] = a + b; m[4 * r + 1] = a - b; m[4 * r + 2] = f + e; m[4 * r + 3] = f - e;
+        }
+        int z[16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int a = m[k] + m[12 + k], b = m[4 + k] + m[8 + k], e = m[4 + k] - m[8 + k], f = m[k] - m[12 + k];
+          z[k] = a + b; z[4 + k] = a - b; z[8 + k] = f + e; z[12 + k] = f - e;
+        }
+        uint32_t sum = 0;
+        if (kind8) {   // wave-uniform: combine the quad's four 4x4 transforms into the 8x8 transform (xCalcHADs8x8)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int p1 = __builtin_amdgcn_update_dpp(0, z[i], 0xB1, 0xf, 0xf, false);   // horizontal neighbour
+            const int y = p1 + s1 * z[i];
+            const int p2 = __builtin_amdgcn_update_dpp(0, y, 0x4E, 0xf, 0xf, false);      // vertical neighbour
+            sum += (uint32_t)abs(p2 + s2 * y);
+          }
+          sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0xB1, 0xf, 0xf, false);
+          sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0x4E, 0xf, 0xf, false);
+          contrib = (sum + 2) >> 2;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) sum += (uint32_t)abs(z[i]);
+          contrib = (sum + 1) >> 1;
+        }
+      }
+      const int point = STAGE == 0 ? idxH[dyi][dxi] : idxQ[dyi][dxi];
+      if (!(HAD && kind8) || role == 0) atomicAdd(&acc_slot[point], contrib);
+    }
+  }
+}
+
+template <int HAD>
+__global__ void __launch_bounds__(kThreads)
+me_frac_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet refs, int ref_pitch,
+               const MeJob* __restrict__ jobs, const uint32_t* __restrict__ items, const int16_t* __restrict__ int_mv,
+               uint32_t lambda_q16, int16_t* __restrict__ out_qmv, uint32_t* __restrict__ out_cost) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  uint32_t* acc = smem;                 // [593][9] distortion sums of the current stage
+  int* half = (int*)(smem + 5344);      // [593] half-pel winner, packed (hx & 0xffff) | (hy << 16)
+  uint32_t* curl = smem + 5344 + 600;   // 64 x 64 current block
+  uint32_t* win = curl + 1024;          // reference window with a 4-sample halo, pitch kFracPDW dwords
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  MeJob job = jobs[blockIdx.x];
+  const uint8_t* __restrict__ ref_base = refs.base[job.ctu_x & 63];
+  job.ctu_x &= ~63;
+  const int wy = job.rb_y - job.lt_y + 1;
+  const int16_t* mvs = int_mv + (long)blockIdx.x * kParts * 2;
+
+  for (int i = tid; i < kFracAcc; i += kThreads) acc[i] = 0;
+  {
+    const int r = tid >> 2, q = tid & 3;
+    *(uint4*)&curl[r * 16 + 4 * q] = *(const uint4*)(cur_base + (long)(job.ctu_y + r) * cur_pitch + job.ctu_x + 16 * q);
+  }
+  {
+    const uint8_t* src = ref_base + (long)(job.ctu_y + job.lt_y - 4) * ref_pitch + (job.ctu_x + job.lt_x - 4);
+    const uint32_t mis = (uint32_t)(uintptr_t)src & 3u;
+    const uint32_t* src_al = (const uint32_t*)(src - mis);
+    const int pitch_dw = ref_pitch >> 2;
+    const int n = (wy + 63 + 8) * kFracPDW;
+    for (int i = tid; i < n; i += kThreads) {
+      const int r = i / kFracPDW, k = i - r * kFracPDW;
+      const uint32_t lo = src_al[(long)r * pitch_dw + k], hi = src_al[(long)r * pitch_dw + k + 1];
+      win[i] = __builtin_amdgcn_alignbyte(hi, lo, mis);
+    }
+  }
+  __syncthreads();
+
+#pragma unroll 1
+  for (int stage = 0; stage < 2; ++stage) {
+#pragma unroll 1
+    for (int base = 0; base < kFracItems; base += kThreads) {
+      const uint32_t it = items[base + tid];
+      const int slot = it & 1023, bx = (it >> 10) & 15, by = (it >> 14) & 15;
+      const bool kind8 = (it >> 18) & 1;
+      const int mx = mvs[2 * slot], my = mvs[2 * slot + 1];
+      // patch (0,0) = block sample (-4,-4) = window row (by*4 + my - lt_y), byte (bx*4 + mx - lt_x) (halo offsets cancel)
+      const int prow = by * 4 + (my - job.lt_y), pcol = bx * 4 + (mx - job.lt_x);
+      const uint32_t* rowp = win + prow * kFracPDW + (pcol >> 2);
+      const uint32_t o = (uint32_t)pcol & 3u;
+      uint32_t P[12][3];
+#pragma unroll
+      for (int r = 0; r < 12; ++r) {
+        const uint32_t q0 = rowp[r * kFracPDW], q1 = rowp[r * kFracPDW + 1], q2 = rowp[r * kFracPDW + 2], q3 = rowp[r * kFracPDW + 3];
+        P[r][0] = __builtin_amdgcn_alignbyte(q1, q0, o);
+        P[r][1] = __builtin_amdgcn_alignbyte(q2, q1, o);
+        P[r][2] = __builtin_amdgcn_alignbyte(q3, q2, o);
+      }
+      int org[16];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t w = curl[(by * 4 + r) * 16 + bx];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) org[4 * r + c] = (int)((w >> (8 * c)) & 0xff);
+      }
+      if (stage == 0) {
+        me_frac_eval<0, HAD>(P, org, 0, 0, kind8, lane & 3, acc + slot * 9);
+      } else {
+        const int hv = half[slot];
+        me_frac_eval<1, HAD>(P, org, 2 * (int)(short)(hv & 0xffff), 2 * (hv >> 16), kind8, lane & 3, acc + slot * 9);
+      }
+    }
+    __syncthreads();
+    for (int s = tid; s < kParts; s += kThreads) {
+      const int mx = mvs[2 * s], my = mvs[2 * s + 1];
+      const int hv = stage ? half[s] : 0;
+      const int hx = (int)(short)(hv & 0xffff), hy = hv >> 16;
+      const int bxq = 4 * mx + 2 * hx, byq = 4 * my + 2 * hy;   // centre of this stage in quarter units
+      constexpr int ph[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};
+      constexpr int pq[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {1, 1}};
+      uint32_t best = 0xffffffffu;
+      int bi = 0;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const int ox = stage ? pq[i][0] : 2 * ph[i][0], oy = stage ? pq[i][1] : 2 * ph[i][1];
+        const uint32_t d = acc[s * 9 + i] + me_mv_cost_q(lambda_q16, bxq + ox, byq + oy, job.pred_x, job.pred_y);
+        if (d < best) { best = d; bi = i; }
+      }
+      if (stage == 0) {
+        half[s] = (ph[bi][0] & 0xffff) | (ph[bi][1] << 16);
+      } else {
+        const long o = (long)blockIdx.x * kParts + s;
+        out_qmv[2 * o] = (int16_t)(bxq + pq[bi][0]);
+        out_qmv[2 * o + 1] = (int16_t)(byq + pq[bi][1]);
+        out_cost[o] = best;
+      }
+    }
+    __syncthreads();
+    if (stage == 0) {
+      for (int i = tid; i < kFracAcc; i += kThreads) acc[i] = 0;
+      __syncthreads();
+    }
+  }
+}
+
 }  // namespace hmme

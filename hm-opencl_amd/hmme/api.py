@@ -20,7 +20,8 @@ SYMBOLS = ["hmme_create", "hmme_destroy", "hmme_last_error", "hmme_device_info",
            "hmme_slot_index", "hmme_slot_rect", "hmme_search_ctu", "hmme_plane_create", "hmme_plane_create_ex", "hmme_plane_bit_depth", "hmme_plane_destroy", "hmme_plane_upload_pel",
            "hmme_plane_upload_u8", "hmme_plane_set_device_u8", "hmme_plane_width", "hmme_plane_height",
            "hmme_num_ctus", "hmme_search_frame", "hmme_search_frame_device", "hmme_search_frame_multi",
-           "hmme_search_frame_multi_device", "hmme_time_search_kernel"]
+           "hmme_search_frame_multi_device", "hmme_refine_frame", "hmme_refine_frame_multi_device",
+           "hmme_time_search_kernel"]
 
 
 class HmmeError(RuntimeError):
@@ -87,6 +88,8 @@ def load():
     L.hmme_search_frame_device.argtypes = [vp, vp, vp, C.POINTER(FrameParams), vp, vp, vp, vp]
     L.hmme_search_frame_multi.argtypes = [vp, vp, C.POINTER(vp), i, C.POINTER(FrameParams), vp, vp, vp]
     L.hmme_search_frame_multi_device.argtypes = [vp, vp, C.POINTER(vp), i, C.POINTER(FrameParams), vp, vp, vp, vp]
+    L.hmme_refine_frame.argtypes = [vp, vp, vp, C.POINTER(FrameParams), vp, vp, i, vp, vp]
+    L.hmme_refine_frame_multi_device.argtypes = [vp, vp, C.POINTER(vp), i, C.POINTER(FrameParams), vp, vp, i, vp, vp, vp]
     L.hmme_time_search_kernel.argtypes = [vp, vp, vp, C.POINTER(FrameParams), vp, vp, vp, vp, i, C.POINTER(C.c_float)]
     _lib = L
     return L
@@ -213,6 +216,28 @@ class Engine:
         arr = (C.c_void_p * len(refs))(*[r.h for r in refs])
         self._check(self.L.hmme_search_frame_multi(self.h, cur.h, arr, len(refs), C.byref(fp), pq, mv.ctypes.data, sad.ctypes.data))
         return mv, sad
+
+    def refine_frame(self, cur, ref, sr, int_mv, pred_q=None, use_hadamard=True, ctu_first=0, ctu_count=-1):
+        """fractional-pel refinement of integer winners -> (qmv int16[count,593,2] quarter-pel, cost uint32[count,593])"""
+        n = self.L.hmme_num_ctus(cur.width, cur.height)
+        count = n - ctu_first if ctu_count < 0 else ctu_count
+        fp = FrameParams(sr, 1, cur.bit_depth, ctu_first, count)
+        int_mv = np.ascontiguousarray(int_mv, dtype=np.int16)
+        assert int_mv.shape == (count, NUM_PARTS, 2)
+        qmv = np.zeros((count, NUM_PARTS, 2), np.int16)
+        cost = np.zeros((count, NUM_PARTS), np.uint32)
+        pq = None
+        if pred_q is not None:
+            pred_q = np.ascontiguousarray(pred_q, dtype=np.int16)
+            pq = pred_q.ctypes.data
+        self._check(self.L.hmme_refine_frame(self.h, cur.h, ref.h, C.byref(fp), pq, int_mv.ctypes.data, int(use_hadamard),
+                                             qmv.ctypes.data, cost.ctypes.data))
+        return qmv, cost
+
+    def refine_frame_multi_device(self, cur, refs, fp, d_pred, d_int_mv, use_hadamard, d_qmv, d_cost, stream=0):
+        arr = (C.c_void_p * len(refs))(*[r.h for r in refs])
+        self._check(self.L.hmme_refine_frame_multi_device(self.h, cur.h, arr, len(refs), C.byref(fp), d_pred, d_int_mv,
+                                                          int(use_hadamard), d_qmv, d_cost, stream))
 
     def search_frame_multi_device(self, cur, refs, fp, d_pred, d_mv, d_sad, stream=0):
         arr = (C.c_void_p * len(refs))(*[r.h for r in refs])

@@ -146,6 +146,18 @@ int hmme_search_frame_multi_device(hmme_ctx* ctx, const hmme_plane* cur, const h
                                    const hmme_frame_params* fp, const void* d_pred_q, void* d_out_mv, void* d_out_sad,
                                    void* stream);
 
+/* ---- fractional-pel refinement: the step after the integer search ------------------------------------------
+ * TEncSearch::xPatternSearchFracDIF (TEncSearch.cpp:4294-4331) for every slot of every CTU: half- then quarter-pel
+ * refinement around the slot's integer MV with HM's 8-tap interpolation, Hadamard (HadamardME = 1, xGetHADs) or SAD
+ * distortion plus the MV cost.  int_mv: int16[n_refs][count][593][2] as produced by hmme_search_frame*.
+ * out_qmv: quarter-pel MV (int << 2) + (half << 1) + quarter; out_cost: distortion + MV cost of the winner (the
+ * ruiCost xPatternSearchFracDIF returns).  8-bit planes, search range <= 64 in this build. */
+int hmme_refine_frame(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp,
+                      const int16_t* pred_q, const int16_t* int_mv, int use_hadamard, int16_t* out_qmv, uint32_t* out_cost);
+int hmme_refine_frame_multi_device(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* const* refs, int n_refs,
+                                   const hmme_frame_params* fp, const void* d_pred_q, const void* d_int_mv, int use_hadamard,
+                                   void* d_out_qmv, void* d_out_cost, void* stream);
+
 /* ---- measurement helpers (bench.py) ------------------------------------------------------ */
 /* average device time in ms of the search kernel over `reps` back-to-back launches on `stream`,
  * measured with hipEvents recorded on that stream */

@@ -446,3 +446,37 @@ def test_device_resident_producer_and_async_api(engine, oracle_lib):
     ox, oy, osad = oracle_lib.search_frame(cur, ref, (m, m), w, h, sr, pred, engine.lambda_q16, 1, 8, n_threads=4)
     assert np.array_equal(d_mv.cpu().numpy()[:, :, 0], ox) and np.array_equal(d_mv.cpu().numpy()[:, :, 1], oy)
     assert np.array_equal(d_sad.cpu().numpy().astype(np.uint32), osad)
+
+
+@pytest.mark.parametrize("use_had,sr,use_pred", [(1, 16, True), (0, 16, True), (1, 64, False)])
+def test_fractional_refinement_vs_oracle(engine, oracle_lib, use_had, sr, use_pred):
+    """the step after the path: xPatternSearchFracDIF for all 593 slots of every CTU (half + quarter-pel, HM's
+    8-tap interpolation, Hadamard or SAD), fed with the engine's own integer MVs"""
+    from hmme import synth
+    w, h = 200, 136                                   # 4 x 3 CTUs, partial right column and bottom row
+    cur, ref, _ = synth.make_pair(w, h, seed=31 + sr, max_mv=min(sr, 9), region=64, noise_sigma=2.5)
+    m = synth.MARGIN
+    n_ctu = 4 * 3
+    pred = synth.random_predictors(n_ctu, seed=8, max_pel=6) if use_pred else None
+    engine.set_lambda(57.9)
+    lq = engine.lambda_q16
+    with engine.plane(w, h) as pc, engine.plane(w, h) as pr:
+        pc.upload_pel(cur, (m, m)); pr.upload_pel(ref, (m, m))
+        mv, sad = engine.search_frame(pc, pr, sr, pred)
+        qmv, cost = engine.refine_frame(pc, pr, sr, mv, pred, use_hadamard=bool(use_had))
+    table = oracle_lib.slot_table()
+    rng = np.random.default_rng(5)
+    checked = 0
+    for ctu in range(n_ctu):
+        cx, cy = (ctu % 4) * 64, (ctu // 4) * 64
+        px, py = (int(pred[ctu, 0]), int(pred[ctu, 1])) if use_pred else (0, 0)
+        for s in list(rng.choice(593, size=90, replace=False)) + [592, 588, 576, 0, 128, 256, 300]:
+            x, y, bw, bh = (int(v) for v in table[s])
+            imv = (int(mv[ctu, s, 0]), int(mv[ctu, s, 1]))
+            hx, hy, qx, qy, c = oracle_lib.frac_refine(cur, (m + cx + x, m + cy + y), ref, (m + cx + x, m + cy + y), bw, bh, imv,
+                                                        (px, py), lq, use_had, 8)
+            want = (4 * imv[0] + 2 * hx + qx, 4 * imv[1] + 2 * hy + qy, c)
+            got = (int(qmv[ctu, s, 0]), int(qmv[ctu, s, 1]), int(cost[ctu, s]))
+            assert got == want, (ctu, s, (bw, bh), imv, got, want)
+            checked += 1
+    assert checked > 1000
