@@ -680,7 +680,7 @@ __device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3], const i
 }
 
 template <int HAD>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kThreads, 2)
 me_frac_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet refs, int ref_pitch,
                const MeJob* __restrict__ jobs, const uint32_t* __restrict__ items, const int16_t* __restrict__ int_mv,
                uint32_t lambda_q16, int16_t* __restrict__ out_qmv, uint32_t* __restrict__ out_cost) {
