@@ -480,3 +480,40 @@ def test_fractional_refinement_vs_oracle(engine, oracle_lib, use_had, sr, use_pr
             assert got == want, (ctu, s, (bw, bh), imv, got, want)
             checked += 1
     assert checked > 1000
+
+
+def test_refinement_multi_reference_and_errors(engine):
+    """device entry point with two references in one launch == two single-reference calls; unsupported inputs fail loudly"""
+    import torch
+    from hmme import api, synth
+    w, h, sr = 192, 128, 12
+    m = synth.MARGIN
+    engine.set_lambda(57.9)
+    cur, _, _ = synth.make_pair(w, h, seed=2, max_mv=0, pad=30)
+    planes = []
+    for t in range(3):
+        f, _, _ = synth.make_pair(w, h, seed=2, max_mv=0, shift=(2 * t, -t), pad=30, noise_sigma=1.0 + t)
+        pl = engine.plane(w, h)
+        pl.upload_pel(f, (m, m))
+        planes.append(pl)
+    pc, refs = planes[0], planes[1:]
+    n = 3 * 2
+    mv, _ = engine.search_frame_multi(pc, refs, sr)
+    dev = torch.device("cuda", 0)
+    d_mv = torch.from_numpy(mv).to(dev)
+    d_q = torch.zeros((2, n, 593, 2), dtype=torch.int16, device=dev)
+    d_c = torch.zeros((2, n, 593), dtype=torch.int32, device=dev)
+    fp = api.FrameParams(sr, 1, 8, 0, n)
+    engine.refine_frame_multi_device(pc, refs, fp, None, d_mv.data_ptr(), 1, d_q.data_ptr(), d_c.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for r in range(2):
+        q1, c1 = engine.refine_frame(pc, refs[r], sr, mv[r])
+        assert np.array_equal(d_q[r].cpu().numpy(), q1) and np.array_equal(d_c[r].cpu().numpy().astype(np.uint32), c1)
+        assert np.abs(q1.astype(np.int32) - 4 * mv[r].astype(np.int32)).max() <= 3
+    with engine.plane(w, h, 10) as p10:
+        p10.upload_pel(np.zeros((h, w), np.int16), (0, 0))
+        with pytest.raises(api.HmmeError, match="8-bit"):
+            engine.refine_frame(p10, p10, sr, np.zeros((n, 593, 2), np.int16))
+    for pl in planes:
+        pl.close()
