@@ -57,7 +57,7 @@ struct hmme_ctx {
   int* d_flag = nullptr;
   bool lds_optin[4] = {false, false, false, false};
   uint32_t* d_frac_items = nullptr;   // fractional refinement: (slot, 4x4 sub-block) work list, same for every CTU
-  bool frac_optin[2] = {false, false};
+  bool frac_optin[2][2] = {{false, false}, {false, false}};
   int16_t* d_imv = nullptr;           // host-facing refine call: integer MVs / quarter-pel MVs / costs on the device
   int16_t* d_qmv = nullptr;
   uint32_t* d_fcost = nullptr;
@@ -721,8 +721,8 @@ int hmme_refine_frame_multi_device(hmme_ctx* ctx, const hmme_plane* cur, const h
     if (refs[r]->pitch != refs[0]->pitch) return fail(ctx, HMME_ERR_ARG, "reference planes differ in pitch");
     set.base[r] = refs[r]->origin();
   }
-  if (fp->bit_depth != 8 || fp->search_range > 64)
-    return fail(ctx, HMME_ERR_UNSUPPORTED, "fractional refinement: 8-bit planes and search range <= 64 only in this build");
+  if (fp->search_range > 64)
+    return fail(ctx, HMME_ERR_UNSUPPORTED, "fractional refinement: search range <= 64 only in this build (window must fit the LDS)");
   if (!d_int_mv || !d_out_qmv || !d_out_cost) return fail(ctx, HMME_ERR_ARG, "null buffer");
   if (count == 0) return HMME_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -737,20 +737,19 @@ int hmme_refine_frame_multi_device(hmme_ctx* ctx, const hmme_plane* cur, const h
   hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, dim3((jobs + 255) / 256), dim3(256), 0, s, (MeJob*)ctx->d_jobs, (const int16_t*)d_pred_q,
                      first, count, n_refs, cur->width, cur->height, fp->search_range);
   HIP_TRY(ctx, hipGetLastError());
-  const int had = use_hadamard ? 1 : 0;
-  if (!ctx->frac_optin[had]) {
-    HIP_TRY(ctx, hipFuncSetAttribute(had ? (const void*)hmme::me_frac_kernel<1> : (const void*)hmme::me_frac_kernel<0>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    ctx->frac_optin[had] = true;
+  const int had = use_hadamard ? 1 : 0, wide = cur->bps == 2 ? 1 : 0;
+  using frac_fn = void (*)(const uint8_t*, int, const RefSet, int, const MeJob*, const uint32_t*, const int16_t*, uint32_t, int, int16_t*,
+                           uint32_t*);
+  static const frac_fn fns[2][2] = {{hmme::me_frac_kernel<0, 1>, hmme::me_frac_kernel<1, 1>},
+                                    {hmme::me_frac_kernel<0, 2>, hmme::me_frac_kernel<1, 2>}};
+  const frac_fn fn = fns[wide][had];
+  if (!ctx->frac_optin[wide][had]) {
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ctx->frac_optin[wide][had] = true;
   }
-  if (had)
-    hipLaunchKernelGGL(hmme::me_frac_kernel<1>, dim3(jobs), dim3(hmme::kThreads), hmme::kFracLdsBytes, s, cur->origin(), cur->pitch, set,
-                       refs[0]->pitch, (const MeJob*)ctx->d_jobs, ctx->d_frac_items, (const int16_t*)d_int_mv, ctx->lambda_q16,
-                       (int16_t*)d_out_qmv, (uint32_t*)d_out_cost);
-  else
-    hipLaunchKernelGGL(hmme::me_frac_kernel<0>, dim3(jobs), dim3(hmme::kThreads), hmme::kFracLdsBytes, s, cur->origin(), cur->pitch, set,
-                       refs[0]->pitch, (const MeJob*)ctx->d_jobs, ctx->d_frac_items, (const int16_t*)d_int_mv, ctx->lambda_q16,
-                       (int16_t*)d_out_qmv, (uint32_t*)d_out_cost);
+  hipLaunchKernelGGL(fn, dim3(jobs), dim3(hmme::kThreads), hmme::frac_lds_bytes(wide ? 2 : 1), s, cur->origin(), cur->pitch, set,
+                     refs[0]->pitch, (const MeJob*)ctx->d_jobs, ctx->d_frac_items, (const int16_t*)d_int_mv, ctx->lambda_q16,
+                     fp->bit_depth, (int16_t*)d_out_qmv, (uint32_t*)d_out_cost);
   HIP_TRY(ctx, hipGetLastError());
   return HMME_OK;
 }

@@ -567,10 +567,11 @@ __global__ void me_prep_jobs_split_kernel(MeJob16* jobs, int* first_strip_of_job
 // blocks) run the same code.  Per-slot distortions accumulate in LDS (ds_add_u32); 593 threads then add the MV cost
 // and pick the winner in HM's point order (strict '<', tables TEncSearch.cpp:51-75).
 constexpr int kFracItems = 6144;           // sum over slots of w*h/16
-constexpr int kFracPDW = 51;               // window + 4-sample halo: 129 + 63 + 8 = 200 bytes <= 204
-constexpr int kFracRowsMax = 200;
+constexpr int kFracRowsMax = 200;          // window + 4-sample halo: 129 + 63 + 8 = 200 rows of 200 samples
 constexpr int kFracAcc = 593 * 9;
-constexpr size_t kFracLdsBytes = (size_t)(5344 + 600 + 1024 + kFracRowsMax * kFracPDW) * 4;
+// BPS = bytes per sample of the planes (1: 8-bit video, 2: 9..12 bit).  Window pitch in dwords (odd), LDS bytes.
+constexpr int frac_pdw(int bps) { return bps == 1 ? 51 : 101; }
+constexpr size_t frac_lds_bytes(int bps) { return (size_t)(5344 + 600 + 1024 * bps + kFracRowsMax * frac_pdw(bps)) * 4; }
 
 __device__ __forceinline__ uint32_t me_mv_cost_q(uint32_t lambda_q16, int vx_q, int vy_q, int pred_x, int pred_y) {
   return (lambda_q16 * (me_component_bits(vx_q - pred_x) + me_component_bits(vy_q - pred_y))) >> 16;
@@ -594,30 +595,35 @@ __device__ __forceinline__ void me_taps9(int q, int (&c9)[9]) {
 }
 
 // STAGE 0: half-pel points (step 2 quarter units around the integer MV); STAGE 1: quarter-pel points around the
-// slot's half-pel winner (cqx, cqy).  P: 12 patch rows x 12 bytes (3 dwords), patch (0,0) = block (-4,-4).
-template <int STAGE, int HAD>
-__device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3], const int (&org)[16], int cqx, int cqy, bool kind8,
-                                             int role, uint32_t* acc_slot) {
+// slot's half-pel winner (cqx, cqy).  P: 12 patch rows x 12 samples (3 * BPS dwords), patch (0,0) = block (-4,-4).
+// bd = bit depth of the video (8 when BPS == 1): the two filter passes shift by bd-8 and 20-bd around the 14-bit
+// intermediate (TComInterpolationFilter.cpp:170-212: headRoom = 14 - bd).
+template <int STAGE, int HAD, int BPS>
+__device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3 * BPS], const int (&org)[16], int cqx, int cqy, bool kind8,
+                                             int role, int bd, uint32_t* acc_slot) {
   constexpr int step = STAGE == 0 ? 2 : 1;
   // point index of (dx, dy) in s_acMvRefineH / s_acMvRefineQ order (reference TEncSearch.cpp:51-75)
   constexpr int idxH[3][3] = {{5, 1, 6}, {3, 0, 4}, {7, 2, 8}}, idxQ[3][3] = {{3, 1, 4}, {5, 0, 6}, {7, 2, 8}};   // [dy+1][dx+1]
   const int s1 = (role & 1) ? -1 : 1, s2 = (role & 2) ? -1 : 1;
+  const int sh1 = BPS == 1 ? 0 : bd - 8, sh2 = BPS == 1 ? 12 : 20 - bd;
+  const int off1 = -(8192 << sh1), off2 = (1 << (sh2 - 1)) + (8192 << 6), maxv = BPS == 1 ? 255 : (1 << bd) - 1;
 #pragma unroll
   for (int dxi = 0; dxi < 3; ++dxi) {
     int ch[9];
     me_taps9(cqx + step * (dxi - 1), ch);
-    int tmp[12][4];   // horizontal pass into 14-bit intermediates (8-bit video: shift 0, offset -8192)
+    int tmp[12][4];   // horizontal pass into 14-bit intermediates
 #pragma unroll
     for (int r = 0; r < 12; ++r) {
       int px[12];
 #pragma unroll
-      for (int j = 0; j < 12; ++j) px[j] = (int)__builtin_amdgcn_ubfe(P[r][j >> 2], 8 * (j & 3), 8);
+      for (int j = 0; j < 12; ++j)
+        px[j] = BPS == 1 ? (int)__builtin_amdgcn_ubfe(P[r][j >> 2], 8 * (j & 3), 8) : (int)__builtin_amdgcn_ubfe(P[r][j >> 1], 16 * (j & 1), 16);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        int sum = -8192;
+        int sum = off1;
 #pragma unroll
         for (int j = 0; j < 9; ++j) sum += ch[j] * px[c + j];
-        tmp[r][c] = sum;
+        tmp[r][c] = BPS == 1 ? sum : sum >> sh1;
       }
     }
 #pragma unroll
@@ -629,11 +635,11 @@ __device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3], const i
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          int sum = 526336;   // (1 << 11) + (8192 << 6): second pass, shift 12 (TComInterpolationFilter.cpp:195-212)
+          int sum = off2;   // second pass (TComInterpolationFilter.cpp:195-212)
 #pragma unroll
           for (int j = 0; j < 9; ++j) sum += cv[j] * tmp[r + j][c];
-          int v = sum >> 12;
-          v = v < 0 ? 0 : (v > 255 ? 255 : v);
+          int v = sum >> sh2;
+          v = v < 0 ? 0 : (v > maxv ? maxv : v);
           d[4 * r + c] = org[4 * r + c] - v;
         }
       uint32_t contrib;
@@ -679,37 +685,39 @@ __device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3], const i
   }
 }
 
-template <int HAD>
-__global__ void __launch_bounds__(kThreads, 2)
+template <int HAD, int BPS>
+__global__ void __launch_bounds__(kThreads, BPS == 1 ? 2 : 1)
 me_frac_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet refs, int ref_pitch,
                const MeJob* __restrict__ jobs, const uint32_t* __restrict__ items, const int16_t* __restrict__ int_mv,
-               uint32_t lambda_q16, int16_t* __restrict__ out_qmv, uint32_t* __restrict__ out_cost) {
+               uint32_t lambda_q16, int bit_depth, int16_t* __restrict__ out_qmv, uint32_t* __restrict__ out_cost) {
+  constexpr int PDW = frac_pdw(BPS), PW = 3 * BPS;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t* acc = smem;                 // [593][9] distortion sums of the current stage
   int* half = (int*)(smem + 5344);      // [593] half-pel winner, packed (hx & 0xffff) | (hy << 16)
   uint32_t* curl = smem + 5344 + 600;   // 64 x 64 current block
-  uint32_t* win = curl + 1024;          // reference window with a 4-sample halo, pitch kFracPDW dwords
+  uint32_t* win = curl + 1024 * BPS;    // reference window with a 4-sample halo, pitch PDW dwords
 
   const int tid = threadIdx.x, lane = tid & 63;
   MeJob job = jobs[blockIdx.x];
   const uint8_t* __restrict__ ref_base = refs.base[job.ctu_x & 63];
   job.ctu_x &= ~63;
   const int wy = job.rb_y - job.lt_y + 1;
+  const int bd = BPS == 1 ? 8 : bit_depth;
   const int16_t* mvs = int_mv + (long)blockIdx.x * kParts * 2;
 
   for (int i = tid; i < kFracAcc; i += kThreads) acc[i] = 0;
-  {
-    const int r = tid >> 2, q = tid & 3;
-    *(uint4*)&curl[r * 16 + 4 * q] = *(const uint4*)(cur_base + (long)(job.ctu_y + r) * cur_pitch + job.ctu_x + 16 * q);
+  for (int i = tid; i < 256 * BPS; i += kThreads) {
+    const int r = i / (4 * BPS), q = i - r * (4 * BPS);
+    *(uint4*)&curl[r * 16 * BPS + 4 * q] = *(const uint4*)(cur_base + (long)(job.ctu_y + r) * cur_pitch + job.ctu_x * BPS + 16 * q);
   }
   {
-    const uint8_t* src = ref_base + (long)(job.ctu_y + job.lt_y - 4) * ref_pitch + (job.ctu_x + job.lt_x - 4);
+    const uint8_t* src = ref_base + (long)(job.ctu_y + job.lt_y - 4) * ref_pitch + (job.ctu_x + job.lt_x - 4) * BPS;
     const uint32_t mis = (uint32_t)(uintptr_t)src & 3u;
     const uint32_t* src_al = (const uint32_t*)(src - mis);
     const int pitch_dw = ref_pitch >> 2;
-    const int n = (wy + 63 + 8) * kFracPDW;
+    const int n = (wy + 63 + 8) * PDW;
     for (int i = tid; i < n; i += kThreads) {
-      const int r = i / kFracPDW, k = i - r * kFracPDW;
+      const int r = i / PDW, k = i - r * PDW;
       const uint32_t lo = src_al[(long)r * pitch_dw + k], hi = src_al[(long)r * pitch_dw + k + 1];
       win[i] = __builtin_amdgcn_alignbyte(hi, lo, mis);
     }
@@ -724,30 +732,37 @@ me_frac_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet
       const int slot = it & 1023, bx = (it >> 10) & 15, by = (it >> 14) & 15;
       const bool kind8 = (it >> 18) & 1;
       const int mx = mvs[2 * slot], my = mvs[2 * slot + 1];
-      // patch (0,0) = block sample (-4,-4) = window row (by*4 + my - lt_y), byte (bx*4 + mx - lt_x) (halo offsets cancel)
-      const int prow = by * 4 + (my - job.lt_y), pcol = bx * 4 + (mx - job.lt_x);
-      const uint32_t* rowp = win + prow * kFracPDW + (pcol >> 2);
+      // patch (0,0) = block sample (-4,-4) = window row (by*4 + my - lt_y), sample (bx*4 + mx - lt_x) (halo offsets cancel)
+      const int prow = by * 4 + (my - job.lt_y), pcol = (bx * 4 + (mx - job.lt_x)) * BPS;   // pcol in bytes
+      const uint32_t* rowp = win + prow * PDW + (pcol >> 2);
       const uint32_t o = (uint32_t)pcol & 3u;
-      uint32_t P[12][3];
+      uint32_t P[12][PW];
 #pragma unroll
       for (int r = 0; r < 12; ++r) {
-        const uint32_t q0 = rowp[r * kFracPDW], q1 = rowp[r * kFracPDW + 1], q2 = rowp[r * kFracPDW + 2], q3 = rowp[r * kFracPDW + 3];
-        P[r][0] = __builtin_amdgcn_alignbyte(q1, q0, o);
-        P[r][1] = __builtin_amdgcn_alignbyte(q2, q1, o);
-        P[r][2] = __builtin_amdgcn_alignbyte(q3, q2, o);
+        uint32_t q[PW + 1];
+#pragma unroll
+        for (int k = 0; k <= PW; ++k) q[k] = rowp[r * PDW + k];
+#pragma unroll
+        for (int k = 0; k < PW; ++k) P[r][k] = __builtin_amdgcn_alignbyte(q[k + 1], q[k], o);
       }
       int org[16];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const uint32_t w = curl[(by * 4 + r) * 16 + bx];
+        if (BPS == 1) {
+          const uint32_t w = curl[(by * 4 + r) * 16 + bx];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) org[4 * r + c] = (int)((w >> (8 * c)) & 0xff);
+          for (int c = 0; c < 4; ++c) org[4 * r + c] = (int)((w >> (8 * c)) & 0xff);
+        } else {
+          const uint2 w = *(const uint2*)&curl[(by * 4 + r) * 32 + bx * 2];
+          org[4 * r] = (int)(w.x & 0xffff); org[4 * r + 1] = (int)(w.x >> 16);
+          org[4 * r + 2] = (int)(w.y & 0xffff); org[4 * r + 3] = (int)(w.y >> 16);
+        }
       }
       if (stage == 0) {
-        me_frac_eval<0, HAD>(P, org, 0, 0, kind8, lane & 3, acc + slot * 9);
+        me_frac_eval<0, HAD, BPS>(P, org, 0, 0, kind8, lane & 3, bd, acc + slot * 9);
       } else {
         const int hv = half[slot];
-        me_frac_eval<1, HAD>(P, org, 2 * (int)(short)(hv & 0xffff), 2 * (hv >> 16), kind8, lane & 3, acc + slot * 9);
+        me_frac_eval<1, HAD, BPS>(P, org, 2 * (int)(short)(hv & 0xffff), 2 * (hv >> 16), kind8, lane & 3, bd, acc + slot * 9);
       }
     }
     __syncthreads();
@@ -763,7 +778,8 @@ me_frac_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
         const int ox = stage ? pq[i][0] : 2 * ph[i][0], oy = stage ? pq[i][1] : 2 * ph[i][1];
-        const uint32_t d = acc[s * 9 + i] + me_mv_cost_q(lambda_q16, bxq + ox, byq + oy, job.pred_x, job.pred_y);
+        // whole-PU distortion >> (bitDepth - 8) (TComRdCost.cpp:520-521, :1604), then the MV cost
+        const uint32_t d = (acc[s * 9 + i] >> (bd - 8)) + me_mv_cost_q(lambda_q16, bxq + ox, byq + oy, job.pred_x, job.pred_y);
         if (d < best) { best = d; bi = i; }
       }
       if (stage == 0) {

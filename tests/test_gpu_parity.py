@@ -448,19 +448,20 @@ def test_device_resident_producer_and_async_api(engine, oracle_lib):
     assert np.array_equal(d_sad.cpu().numpy().astype(np.uint32), osad)
 
 
-@pytest.mark.parametrize("use_had,sr,use_pred", [(1, 16, True), (0, 16, True), (1, 64, False)])
-def test_fractional_refinement_vs_oracle(engine, oracle_lib, use_had, sr, use_pred):
+@pytest.mark.parametrize("use_had,sr,use_pred,bd", [(1, 16, True, 8), (0, 16, True, 8), (1, 64, False, 8), (1, 16, True, 10),
+                                                      (0, 64, False, 12), (1, 24, True, 9)])
+def test_fractional_refinement_vs_oracle(engine, oracle_lib, use_had, sr, use_pred, bd):
     """the step after the path: xPatternSearchFracDIF for all 593 slots of every CTU (half + quarter-pel, HM's
     8-tap interpolation, Hadamard or SAD), fed with the engine's own integer MVs"""
     from hmme import synth
     w, h = 200, 136                                   # 4 x 3 CTUs, partial right column and bottom row
-    cur, ref, _ = synth.make_pair(w, h, seed=31 + sr, max_mv=min(sr, 9), region=64, noise_sigma=2.5)
+    cur, ref, _ = synth.make_pair(w, h, seed=31 + sr, bit_depth=bd, max_mv=min(sr, 9), region=64, noise_sigma=2.5)
     m = synth.MARGIN
     n_ctu = 4 * 3
     pred = synth.random_predictors(n_ctu, seed=8, max_pel=6) if use_pred else None
     engine.set_lambda(57.9)
     lq = engine.lambda_q16
-    with engine.plane(w, h) as pc, engine.plane(w, h) as pr:
+    with engine.plane(w, h, bd) as pc, engine.plane(w, h, bd) as pr:
         pc.upload_pel(cur, (m, m)); pr.upload_pel(ref, (m, m))
         mv, sad = engine.search_frame(pc, pr, sr, pred)
         qmv, cost = engine.refine_frame(pc, pr, sr, mv, pred, use_hadamard=bool(use_had))
@@ -474,7 +475,7 @@ def test_fractional_refinement_vs_oracle(engine, oracle_lib, use_had, sr, use_pr
             x, y, bw, bh = (int(v) for v in table[s])
             imv = (int(mv[ctu, s, 0]), int(mv[ctu, s, 1]))
             hx, hy, qx, qy, c = oracle_lib.frac_refine(cur, (m + cx + x, m + cy + y), ref, (m + cx + x, m + cy + y), bw, bh, imv,
-                                                        (px, py), lq, use_had, 8)
+                                                        (px, py), lq, use_had, bd)
             want = (4 * imv[0] + 2 * hx + qx, 4 * imv[1] + 2 * hy + qy, c)
             got = (int(qmv[ctu, s, 0]), int(qmv[ctu, s, 1]), int(cost[ctu, s]))
             assert got == want, (ctu, s, (bw, bh), imv, got, want)
@@ -511,9 +512,7 @@ def test_refinement_multi_reference_and_errors(engine):
         q1, c1 = engine.refine_frame(pc, refs[r], sr, mv[r])
         assert np.array_equal(d_q[r].cpu().numpy(), q1) and np.array_equal(d_c[r].cpu().numpy().astype(np.uint32), c1)
         assert np.abs(q1.astype(np.int32) - 4 * mv[r].astype(np.int32)).max() <= 3
-    with engine.plane(w, h, 10) as p10:
-        p10.upload_pel(np.zeros((h, w), np.int16), (0, 0))
-        with pytest.raises(api.HmmeError, match="8-bit"):
-            engine.refine_frame(p10, p10, sr, np.zeros((n, 593, 2), np.int16))
+    with pytest.raises(api.HmmeError, match="search range"):
+        engine.refine_frame(pc, refs[0], 65, np.zeros((n, 593, 2), np.int16))
     for pl in planes:
         pl.close()

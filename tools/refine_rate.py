@@ -7,16 +7,17 @@ import torch
 from hmme import api, synth
 w, h, sr = 3840, 2160, 64
 if len(sys.argv) > 1: w, h = (int(v) for v in sys.argv[1].split("x"))
-cur, ref, _ = synth.make_pair(w, h, seed=1234)
+bd = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+cur, ref, _ = synth.make_pair(w, h, seed=1234, bit_depth=bd)
 m = synth.MARGIN
 eng = api.Engine(0, 64); eng.set_lambda(57.9)
-pc, pr = eng.plane(w, h), eng.plane(w, h)
+pc, pr = eng.plane(w, h, bd), eng.plane(w, h, bd)
 pc.upload_pel(cur, (m, m)); pr.upload_pel(ref, (m, m))
 n = api.load().hmme_num_ctus(w, h)
 dev = torch.device("cuda", 0)
 d_mv = torch.zeros((n, 593, 2), dtype=torch.int16, device=dev); d_sad = torch.zeros((n, 593), dtype=torch.int32, device=dev)
 d_q = torch.zeros_like(d_mv); d_c = torch.zeros_like(d_sad)
-fp = api.FrameParams(sr, 1, 8, 0, n)
+fp = api.FrameParams(sr, 1, bd, 0, n)
 st = torch.cuda.current_stream().cuda_stream
 eng.search_frame_device(pc, pr, fp, None, d_mv.data_ptr(), d_sad.data_ptr(), st)
 out = {}
@@ -30,4 +31,4 @@ for had in (1, 0):
     e1.record(); torch.cuda.synchronize()
     out["hadamard" if had else "sad"] = round(e0.elapsed_time(e1) / 5, 3)
 frac = (d_q.to(torch.int32) - 4 * d_mv.to(torch.int32)).abs().amax().item()
-print(json.dumps({"size": f"{w}x{h}", "refine_ms": out, "slots_per_s_hadamard": round(n * 593 / (out["hadamard"] * 1e-3)), "max_frac_offset_qpel": frac}))
+print(json.dumps({"size": f"{w}x{h}", "bit_depth": bd, "refine_ms": out, "slots_per_s_hadamard": round(n * 593 / (out["hadamard"] * 1e-3)), "max_frac_offset_qpel": frac}))
