@@ -154,7 +154,9 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # HMME_BENCH_FORCE_DIST=1: run the collective path with world size 1 too (rehearses the RCCL calls on a 1-GPU box)
+    use_dist = world > 1 or (os.environ.get("HMME_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -183,7 +185,7 @@ def main():
     # words and SADs) and are all-gathered asynchronously on RCCL's stream while step k+1 searches into the other
     # buffer: the 9.7 MB per rank per step never stalls the VALU-bound kernel.
     bufs = [torch.zeros((2, n_refs, n_ctu, api.NUM_PARTS), dtype=torch.int32, device=dev) for _ in range(2)]
-    gathered = [torch.zeros((world, 2, n_refs, n_ctu, api.NUM_PARTS), dtype=torch.int32, device=dev) if world > 1 else None
+    gathered = [torch.zeros((world, 2, n_refs, n_ctu, api.NUM_PARTS), dtype=torch.int32, device=dev) if use_dist else None
                 for _ in range(2)]
     pending = [None, None]
     stream = torch.cuda.current_stream().cuda_stream
@@ -200,7 +202,7 @@ def main():
         eng.search_frame_multi_device(pc, ref_planes, fp, None, bufs[b][0].data_ptr(), bufs[b][1].data_ptr(), stream)
         if ev:
             ev[1].record()
-        if world > 1:   # the one exchange step of the path: tables of all `world` pairs to every rank (RCCL/xGMI)
+        if use_dist:   # the one exchange step of the path: tables of all `world` pairs to every rank (RCCL/xGMI)
             _, pending[b] = shard.gather_packed(bufs[b], gathered[b], async_op=(args.backend == "nccl"))
 
     def drain():
@@ -213,7 +215,7 @@ def main():
         step()
     drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     torch.cuda.synchronize()
@@ -222,10 +224,10 @@ def main():
         step(events[k])
     drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -268,7 +270,7 @@ def main():
     for pl in ref_planes:
         pl.close()
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
