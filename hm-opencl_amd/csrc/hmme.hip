@@ -642,6 +642,18 @@ int hmme_search_frame_device(hmme_ctx* ctx, const hmme_plane* cur, const hmme_pl
   return hmme_search_frame_multi_device(ctx, cur, &ref, 1, fp, d_pred_q, d_out_mv, d_out_sad, stream);
 }
 
+// host-facing frame calls: device staging for `need` (CTU, reference) result tables and their predictors
+static int ensure_frame_buffers(hmme_ctx* ctx, size_t need) {
+  if ((size_t)ctx->out_cap >= need) return HMME_OK;
+  hipFree(ctx->d_mv); hipFree(ctx->d_sad); hipFree(ctx->d_pred);
+  ctx->d_mv = nullptr; ctx->d_sad = nullptr; ctx->d_pred = nullptr; ctx->out_cap = 0;
+  HIP_TRY(ctx, hipMalloc(&ctx->d_mv, sizeof(int16_t) * 2 * HMME_NUM_CTU_PARTS * need));
+  HIP_TRY(ctx, hipMalloc(&ctx->d_sad, sizeof(uint32_t) * HMME_NUM_CTU_PARTS * need));
+  HIP_TRY(ctx, hipMalloc(&ctx->d_pred, sizeof(int16_t) * 2 * need));
+  ctx->out_cap = (int)need;
+  return HMME_OK;
+}
+
 int hmme_search_frame_multi(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* const* refs, int n_refs,
                             const hmme_frame_params* fp, const int16_t* pred_q, int16_t* out_mv, uint32_t* out_sad) {
   if (!ctx) return HMME_ERR_ARG;
@@ -654,14 +666,8 @@ int hmme_search_frame_multi(hmme_ctx* ctx, const hmme_plane* cur, const hmme_pla
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int n_ctu = hmme_num_ctus(cur->width, cur->height);
   const size_t need = (size_t)n_ctu * n_refs;
-  if ((size_t)ctx->out_cap < need) {
-    hipFree(ctx->d_mv); hipFree(ctx->d_sad); hipFree(ctx->d_pred);
-    ctx->d_mv = nullptr; ctx->d_sad = nullptr; ctx->d_pred = nullptr; ctx->out_cap = 0;
-    HIP_TRY(ctx, hipMalloc(&ctx->d_mv, sizeof(int16_t) * 2 * HMME_NUM_CTU_PARTS * need));
-    HIP_TRY(ctx, hipMalloc(&ctx->d_sad, sizeof(uint32_t) * HMME_NUM_CTU_PARTS * need));
-    HIP_TRY(ctx, hipMalloc(&ctx->d_pred, sizeof(int16_t) * 2 * need));
-    ctx->out_cap = (int)need;
-  }
+  rc = ensure_frame_buffers(ctx, need);
+  if (rc) return rc;
   hipStream_t s = ctx->stream;
   if (pred_q) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pred, pred_q, sizeof(int16_t) * 2 * need, hipMemcpyHostToDevice, s));
   rc = hmme_search_frame_multi_device(ctx, cur, refs, n_refs, fp, pred_q ? ctx->d_pred : nullptr, ctx->d_mv, ctx->d_sad, s);
@@ -747,7 +753,7 @@ int hmme_refine_frame_multi_device(hmme_ctx* ctx, const hmme_plane* cur, const h
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     ctx->frac_optin[wide][had] = true;
   }
-  hipLaunchKernelGGL(fn, dim3(jobs), dim3(hmme::kThreads), hmme::frac_lds_bytes(wide ? 2 : 1), s, cur->origin(), cur->pitch, set,
+  hipLaunchKernelGGL(fn, dim3(jobs), dim3(hmme::frac_threads(wide ? 2 : 1)), hmme::frac_lds_bytes(wide ? 2 : 1), s, cur->origin(), cur->pitch, set,
                      refs[0]->pitch, (const MeJob*)ctx->d_jobs, ctx->d_frac_items, (const int16_t*)d_int_mv, ctx->lambda_q16,
                      fp->bit_depth, (int16_t*)d_out_qmv, (uint32_t*)d_out_cost);
   HIP_TRY(ctx, hipGetLastError());
@@ -772,16 +778,8 @@ int hmme_refine_frame(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* re
     HIP_TRY(ctx, hipMalloc(&ctx->d_fcost, sizeof(uint32_t) * slots));
     ctx->refine_cap = slots;
   }
-  size_t pcap = 0;   // predictors share the search path's buffer sizing
-  if (ctx->out_cap < n_ctu) {
-    hipFree(ctx->d_mv); hipFree(ctx->d_sad); hipFree(ctx->d_pred);
-    ctx->d_mv = nullptr; ctx->d_sad = nullptr; ctx->d_pred = nullptr; ctx->out_cap = 0;
-    HIP_TRY(ctx, hipMalloc(&ctx->d_mv, sizeof(int16_t) * 2 * slots));
-    HIP_TRY(ctx, hipMalloc(&ctx->d_sad, sizeof(uint32_t) * slots));
-    HIP_TRY(ctx, hipMalloc(&ctx->d_pred, sizeof(int16_t) * 2 * (size_t)n_ctu));
-    ctx->out_cap = n_ctu;
-  }
-  (void)pcap;
+  rc = ensure_frame_buffers(ctx, (size_t)n_ctu);   // the predictors travel in the search path's staging buffer
+  if (rc) return rc;
   hipStream_t s = ctx->stream;
   const size_t res = (size_t)HMME_NUM_CTU_PARTS * count;
   if (pred_q) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pred, pred_q, sizeof(int16_t) * 2 * (size_t)n_ctu, hipMemcpyHostToDevice, s));

@@ -571,112 +571,187 @@ constexpr int kFracRowsMax = 200;          // window + 4-sample halo: 129 + 63 +
 constexpr int kFracAcc = 593 * 9;
 // BPS = bytes per sample of the planes (1: 8-bit video, 2: 9..12 bit).  Window pitch in dwords (odd), LDS bytes.
 constexpr int frac_pdw(int bps) { return bps == 1 ? 51 : 101; }
-constexpr size_t frac_lds_bytes(int bps) { return (size_t)(5344 + 600 + 1024 * bps + kFracRowsMax * frac_pdw(bps)) * 4; }
+// u16 planes: the window leaves room for one workgroup per CU, so that one has 8 waves (2 per SIMD) instead of 4
+constexpr int frac_threads(int bps) { return bps == 1 ? 256 : 512; }
+constexpr size_t frac_lds_bytes(int bps) { return (size_t)(5344 + 600 + 160 + 1024 * bps + kFracRowsMax * frac_pdw(bps)) * 4; }
 
 __device__ __forceinline__ uint32_t me_mv_cost_q(uint32_t lambda_q16, int vx_q, int vy_q, int pred_x, int pred_y) {
   return (lambda_q16 * (me_component_bits(vx_q - pred_x) + me_component_bits(vy_q - pred_y))) >> 16;
 }
 
 // luma taps of fraction f (0..3), tap t (0..7): TComInterpolationFilter::m_lumaFilter
-__device__ __forceinline__ int me_luma_tap(int f, int t) {
+__host__ __device__ constexpr int me_luma_tap(int f, int t) {
   constexpr int k1[8] = {-1, 4, -10, 58, 17, -5, 1, 0}, k2[8] = {-1, 4, -11, 40, 40, -11, 4, -1}, k3[8] = {0, 1, -5, 17, 58, -10, 4, -1};
   const int k0 = t == 3 ? 64 : 0;
   return f == 0 ? k0 : (f == 1 ? k1[t] : (f == 2 ? k2[t] : k3[t]));
 }
-// the 8 taps of quarter position q (relative, -3..3) as a 9-tap window that starts one sample earlier when the
-// integer part of q is -1: keeps every register index static although q differs from lane to lane
-__device__ __forceinline__ void me_taps9(int q, int (&c9)[9]) {
-  const int f = q & 3, b = (q >> 2) + 1;   // b = 0 or 1
-  int c8[8];
-#pragma unroll
-  for (int t = 0; t < 8; ++t) c8[t] = me_luma_tap(f, t);
-#pragma unroll
-  for (int j = 0; j < 9; ++j) c9[j] = b ? (j >= 1 ? c8[j - 1] : 0) : (j < 8 ? c8[j] : 0);
+// the 8 taps of quarter position q (-3..3, relative to the integer MV) as a 9-tap window that starts one sample
+// earlier when the integer part of q is -1: tap j (0..8) multiplies patch sample (output column + j)
+__host__ __device__ constexpr int me_tap9(int q, int j) {
+  const int t = j - ((q >> 2) + 1);
+  return (t < 0 || t > 7) ? 0 : me_luma_tap(q & 3, t);
+}
+// horizontal taps packed for the dot-product instructions: dword k of the tap window of output column c over the
+// 12-sample patch row (BPS 1: four i8 per dword, v_dot4c_i32_i8; BPS 2: two i16 per dword, v_dot2c_i32_i16)
+template <int BPS>
+__host__ __device__ constexpr uint32_t me_htap_dw(int q, int c, int k) {
+  uint32_t w = 0;
+  for (int i = 0; i < 4 / BPS; ++i) {
+    const int j = (4 / BPS) * k + i - c;
+    const int t = (j < 0 || j > 8) ? 0 : me_tap9(q, j);
+    w |= BPS == 1 ? (uint32_t)(t & 0xff) << (8 * i) : (uint32_t)(t & 0xffff) << (16 * i);
+  }
+  return w;
+}
+constexpr int kFracTabH = 8, kFracTabV = 12;   // LDS tap tables: 7 rows (q = -3..3) of packed horizontal / float vertical taps
+
+#define ME_FRAC_BFLY(R, T, PERM) "v_fmac_f32_dpp " #R ", " #R ", " #T " quad_perm:" PERM " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ float me_dpp_f(float v, const int ctrl_b1) {
+  return ctrl_b1 ? __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false))
+                 : __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));
 }
 
 // STAGE 0: half-pel points (step 2 quarter units around the integer MV); STAGE 1: quarter-pel points around the
-// slot's half-pel winner (cqx, cqy).  P: 12 patch rows x 12 samples (3 * BPS dwords), patch (0,0) = block (-4,-4).
-// bd = bit depth of the video (8 when BPS == 1): the two filter passes shift by bd-8 and 20-bd around the 14-bit
-// intermediate (TComInterpolationFilter.cpp:170-212: headRoom = 14 - bd).
+// slot's half-pel winner (cqx, cqy).  P: 12 patch rows x 12 samples (3 * BPS dwords), patch (0,0) = block (-4,-4);
+// 8-bit samples arrive XORed with 0x80 (signed bytes p - 128: the 128 * 64 this removes IS the -8192 offset of the
+// first pass).  orgM: current samples + kRoundMagic.
+// Arithmetic: first pass in integer dot products (v_dot4c_i32_i8 / v_dot2c_i32_i16, shift bd-8), second pass,
+// rounding, clipping and the Hadamard transform in fp32 -- every value is an integer (or an integer + 0.5) below
+// 2^23, so fp32 is exact and v_fmac_f32 issues at the full VALU rate where v_mad_i32_i24 does not
+// (tools/ubench/valu_rates3).  bd = bit depth of the video (8 when BPS == 1): the two passes shift by bd-8 and
+// 20-bd around the 14-bit intermediate (TComInterpolationFilter.cpp:170-212: headRoom = 14 - bd).
+constexpr float kRoundMagic = 12582912.0f;   // 1.5 * 2^23: x + magic rounds x to the nearest integer (ties to even)
 template <int STAGE, int HAD, int BPS>
-__device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3 * BPS], const int (&org)[16], int cqx, int cqy, bool kind8,
-                                             int role, int bd, uint32_t* acc_slot) {
-  constexpr int step = STAGE == 0 ? 2 : 1;
+__device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3 * BPS], const float (&orgM)[16], int cqx, int cqy, bool kind8,
+                                             int role, int bd, const uint32_t* tab_h, const float* tab_v, uint32_t* acc_slot) {
+  constexpr int step = STAGE == 0 ? 2 : 1, PW = 3 * BPS;
   // point index of (dx, dy) in s_acMvRefineH / s_acMvRefineQ order (reference TEncSearch.cpp:51-75)
   constexpr int idxH[3][3] = {{5, 1, 6}, {3, 0, 4}, {7, 2, 8}}, idxQ[3][3] = {{3, 1, 4}, {5, 0, 6}, {7, 2, 8}};   // [dy+1][dx+1]
-  const int s1 = (role & 1) ? -1 : 1, s2 = (role & 2) ? -1 : 1;
-  const int sh1 = BPS == 1 ? 0 : bd - 8, sh2 = BPS == 1 ? 12 : 20 - bd;
-  const int off1 = -(8192 << sh1), off2 = (1 << (sh2 - 1)) + (8192 << 6), maxv = BPS == 1 ? 255 : (1 << bd) - 1;
+  const float s1 = (role & 1) ? -1.f : 1.f, s2 = (role & 2) ? -1.f : 1.f;
+  const int sh1 = BPS == 1 ? 0 : bd - 8;
+  const int off1 = BPS == 1 ? 0 : -(8192 << sh1);
+  // second pass: floor((S + 2^(sh2-1) + (8192 << 6)) >> sh2) = nearest integer of (S + 524288 + 0.5) * 2^-sh2 (never a tie)
+  const float sc2 = BPS == 1 ? 1.f / 4096.f : __int_as_float((127 - (20 - bd)) << 23);
+  const float maxv = BPS == 1 ? 255.f : (float)((1 << bd) - 1);
 #pragma unroll
   for (int dxi = 0; dxi < 3; ++dxi) {
-    int ch[9];
-    me_taps9(cqx + step * (dxi - 1), ch);
-    int tmp[12][4];   // horizontal pass into 14-bit intermediates
+    uint32_t T[4][PW];
+    if (STAGE == 0) {
 #pragma unroll
-    for (int r = 0; r < 12; ++r) {
-      int px[12];
+      for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int j = 0; j < 12; ++j)
-        px[j] = BPS == 1 ? (int)__builtin_amdgcn_ubfe(P[r][j >> 2], 8 * (j & 3), 8) : (int)__builtin_amdgcn_ubfe(P[r][j >> 1], 16 * (j & 1), 16);
+        for (int k = 0; k < PW; ++k) T[c][k] = me_htap_dw<BPS>(step * (dxi - 1), c, k);
+    } else {
+      const uint32_t* row = tab_h + (cqx + step * (dxi - 1) + 3) * kFracTabH;
+      if constexpr (BPS == 1) {
+        const uint32_t w0 = row[0], w1 = row[1], w2 = row[2];
+        T[0][0] = w0; T[0][1] = w1; T[0][2] = w2;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        int sum = off1;
+        for (int c = 1; c < 4; ++c) {
+          T[c][0] = w0 << (8 * c);
+          T[c][1] = __builtin_amdgcn_alignbyte(w1, w0, 4 - c);
+          T[c][2] = __builtin_amdgcn_alignbyte(w2, w1, 4 - c);
+        }
+      } else {
+        uint32_t w[5], h[6];   // h: the row shifted up by one sample
 #pragma unroll
-        for (int j = 0; j < 9; ++j) sum += ch[j] * px[c + j];
-        tmp[r][c] = BPS == 1 ? sum : sum >> sh1;
+        for (int k = 0; k < 5; ++k) w[k] = row[k];
+        h[0] = w[0] << 16;
+#pragma unroll
+        for (int k = 1; k < 5; ++k) h[k] = __builtin_amdgcn_alignbyte(w[k], w[k - 1], 2);
+        h[5] = 0;   // tap 9 does not exist
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          T[0][k] = k < 5 ? w[k] : 0;
+          T[1][k] = h[k];
+          T[2][k] = k >= 1 ? w[k - 1] : 0;
+          T[3][k] = k >= 1 ? h[k - 1] : 0;
+        }
       }
     }
+    float tmp[12][4];   // first pass into the 14-bit intermediates
+#pragma unroll
+    for (int r = 0; r < 12; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        int a = off1;
+#pragma unroll
+        for (int k = 0; k < PW; ++k) {
+          if (STAGE == 0 && me_htap_dw<BPS>(step * (dxi - 1), c, k) == 0) continue;
+          if constexpr (BPS == 1) {
+            a = __builtin_amdgcn_sdot4((int)P[r][k], (int)T[c][k], a, false);
+          } else {
+            typedef short v2s __attribute__((ext_vector_type(2)));
+            a = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, P[r][k]), __builtin_bit_cast(v2s, T[c][k]), a, false);
+          }
+        }
+        tmp[r][c] = (float)(BPS == 1 ? a : a >> sh1);
+      }
 #pragma unroll
     for (int dyi = 0; dyi < 3; ++dyi) {
-      int cv[9];
-      me_taps9(cqy + step * (dyi - 1), cv);
-      int d[16];
+      float cv[9];   // taps * 2^-sh2 (exact): the accumulator is the sample value with its fraction
+#pragma unroll
+      for (int j = 0; j < 9; ++j)
+        cv[j] = STAGE == 0 ? (float)me_tap9(step * (dyi - 1), j) * sc2 : tab_v[(cqy + step * (dyi - 1) + 3) * kFracTabV + j];
+      float d[16];
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          int sum = off2;   // second pass (TComInterpolationFilter.cpp:195-212)
+          float a = 524288.5f * sc2;   // second pass (TComInterpolationFilter.cpp:195-212)
 #pragma unroll
-          for (int j = 0; j < 9; ++j) sum += cv[j] * tmp[r + j][c];
-          int v = sum >> sh2;
-          v = v < 0 ? 0 : (v > maxv ? maxv : v);
-          d[4 * r + c] = org[4 * r + c] - v;
+          for (int j = 0; j < 9; ++j) {
+            if (STAGE == 0 && me_tap9(step * (dyi - 1), j) == 0) continue;
+            a = __builtin_fmaf(cv[j], tmp[r + j][c], a);
+          }
+          const float y = __builtin_amdgcn_fmed3f(a, 0.f, maxv);   // clip, then round (the bounds are integers)
+          d[4 * r + c] = orgM[4 * r + c] - (y + kRoundMagic);
         }
       uint32_t contrib;
       if (!HAD) {
-        uint32_t sad = 0;
+        float sad = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sad += (uint32_t)abs(d[i]);
-        contrib = sad;
+        for (int i = 0; i < 16; ++i) sad += __builtin_fabsf(d[i]);
+        contrib = (uint32_t)sad;
       } else {
-        int m[16];
+        float m[16];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {   // 4x4 Walsh-Hadamard: rows, then columns (xCalcHADs4x4)
-          const int a = d[4 * r] + d[4 * r + 3], b = d[4 * r + 1] + d[4 * r + 2], e = d[4 * r + 1] - d[4 * r + 2], f = d[4 * r] - d[4 * r + 3];
+          const float a = d[4 * r] + d[4 * r + 3], b = d[4 * r + 1] + d[4 * r + 2], e = d[4 * r + 1] - d[4 * r + 2], f = d[4 * r] - d[4 * r + 3];
           m[4 * r] = a + b; m[4 * r + 1] = a - b; m[4 * r + 2] = f + e; m[4 * r + 3] = f - e;
         }
-        int z[16];
+        float z[16];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const int a = m[k] + m[12 + k], b = m[4 + k] + m[8 + k], e = m[4 + k] - m[8 + k], f = m[k] - m[12 + k];
+          const float a = m[k] + m[12 + k], b = m[4 + k] + m[8 + k], e = m[4 + k] - m[8 + k], f = m[k] - m[12 + k];
           z[k] = a + b; z[4 + k] = a - b; z[8 + k] = f + e; z[12 + k] = f - e;
         }
-        uint32_t sum = 0;
+        float sum = 0.f;
         if (kind8) {   // wave-uniform: combine the quad's four 4x4 transforms into the 8x8 transform (xCalcHADs8x8)
+          // two butterflies across the quad, each one v_fmac_f32 with a DPP source: z += t * z[neighbour], t = +-1 by
+          // role.  Odd roles hold the negated difference, which the absolute sum does not see.  One asm block keeps
+          // 16 instructions between a register's write and its DPP read (the hazard the assembler does not pad for).
+          asm("s_nop 1\n\t"
+              ME_FRAC_BFLY(%0, %16, "[1,0,3,2]") ME_FRAC_BFLY(%1, %16, "[1,0,3,2]") ME_FRAC_BFLY(%2, %16, "[1,0,3,2]") ME_FRAC_BFLY(%3, %16, "[1,0,3,2]")
+              ME_FRAC_BFLY(%4, %16, "[1,0,3,2]") ME_FRAC_BFLY(%5, %16, "[1,0,3,2]") ME_FRAC_BFLY(%6, %16, "[1,0,3,2]") ME_FRAC_BFLY(%7, %16, "[1,0,3,2]")
+              ME_FRAC_BFLY(%8, %16, "[1,0,3,2]") ME_FRAC_BFLY(%9, %16, "[1,0,3,2]") ME_FRAC_BFLY(%10, %16, "[1,0,3,2]") ME_FRAC_BFLY(%11, %16, "[1,0,3,2]")
+              ME_FRAC_BFLY(%12, %16, "[1,0,3,2]") ME_FRAC_BFLY(%13, %16, "[1,0,3,2]") ME_FRAC_BFLY(%14, %16, "[1,0,3,2]") ME_FRAC_BFLY(%15, %16, "[1,0,3,2]")
+              ME_FRAC_BFLY(%0, %17, "[2,3,0,1]") ME_FRAC_BFLY(%1, %17, "[2,3,0,1]") ME_FRAC_BFLY(%2, %17, "[2,3,0,1]") ME_FRAC_BFLY(%3, %17, "[2,3,0,1]")
+              ME_FRAC_BFLY(%4, %17, "[2,3,0,1]") ME_FRAC_BFLY(%5, %17, "[2,3,0,1]") ME_FRAC_BFLY(%6, %17, "[2,3,0,1]") ME_FRAC_BFLY(%7, %17, "[2,3,0,1]")
+              ME_FRAC_BFLY(%8, %17, "[2,3,0,1]") ME_FRAC_BFLY(%9, %17, "[2,3,0,1]") ME_FRAC_BFLY(%10, %17, "[2,3,0,1]") ME_FRAC_BFLY(%11, %17, "[2,3,0,1]")
+              ME_FRAC_BFLY(%12, %17, "[2,3,0,1]") ME_FRAC_BFLY(%13, %17, "[2,3,0,1]") ME_FRAC_BFLY(%14, %17, "[2,3,0,1]") ME_FRAC_BFLY(%15, %17, "[2,3,0,1]")
+              : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(z[4]), "+v"(z[5]), "+v"(z[6]), "+v"(z[7]), "+v"(z[8]), "+v"(z[9]),
+                "+v"(z[10]), "+v"(z[11]), "+v"(z[12]), "+v"(z[13]), "+v"(z[14]), "+v"(z[15])
+              : "v"(s1), "v"(s2));
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int p1 = __builtin_amdgcn_update_dpp(0, z[i], 0xB1, 0xf, 0xf, false);   // horizontal neighbour
-            const int y = p1 + s1 * z[i];
-            const int p2 = __builtin_amdgcn_update_dpp(0, y, 0x4E, 0xf, 0xf, false);      // vertical neighbour
-            sum += (uint32_t)abs(p2 + s2 * y);
-          }
-          sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0xB1, 0xf, 0xf, false);
-          sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0x4E, 0xf, 0xf, false);
-          contrib = (sum + 2) >> 2;
+          for (int i = 0; i < 16; ++i) sum += __builtin_fabsf(z[i]);
+          sum += me_dpp_f(sum, 1);
+          sum += me_dpp_f(sum, 0);
+          contrib = ((uint32_t)sum + 2) >> 2;
         } else {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) sum += (uint32_t)abs(z[i]);
-          contrib = (sum + 1) >> 1;
+          for (int i = 0; i < 16; ++i) sum += __builtin_fabsf(z[i]);
+          contrib = ((uint32_t)sum + 1) >> 1;
         }
       }
       const int point = STAGE == 0 ? idxH[dyi][dxi] : idxQ[dyi][dxi];
@@ -686,16 +761,18 @@ __device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3 * BPS], c
 }
 
 template <int HAD, int BPS>
-__global__ void __launch_bounds__(kThreads, BPS == 1 ? 2 : 1)
+__global__ void __launch_bounds__(frac_threads(BPS), BPS == 1 ? 2 : 1)
 me_frac_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet refs, int ref_pitch,
                const MeJob* __restrict__ jobs, const uint32_t* __restrict__ items, const int16_t* __restrict__ int_mv,
                uint32_t lambda_q16, int bit_depth, int16_t* __restrict__ out_qmv, uint32_t* __restrict__ out_cost) {
-  constexpr int PDW = frac_pdw(BPS), PW = 3 * BPS;
+  constexpr int PDW = frac_pdw(BPS), PW = 3 * BPS, NT = frac_threads(BPS);
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t* acc = smem;                 // [593][9] distortion sums of the current stage
   int* half = (int*)(smem + 5344);      // [593] half-pel winner, packed (hx & 0xffff) | (hy << 16)
-  uint32_t* curl = smem + 5344 + 600;   // 64 x 64 current block
-  uint32_t* win = curl + 1024 * BPS;    // reference window with a 4-sample halo, pitch PDW dwords
+  uint32_t* tab_h = smem + 5344 + 600;  // [7][kFracTabH] packed horizontal taps of q = -3..3
+  float* tab_v = (float*)(tab_h + 7 * kFracTabH);   // [7][kFracTabV] vertical taps
+  uint32_t* curl = smem + 5344 + 600 + 160;   // 64 x 64 current block
+  uint32_t* win = curl + 1024 * BPS;    // reference window with a 4-sample halo, pitch PDW dwords (8-bit samples XOR 0x80)
 
   const int tid = threadIdx.x, lane = tid & 63;
   MeJob job = jobs[blockIdx.x];
@@ -705,8 +782,13 @@ me_frac_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet
   const int bd = BPS == 1 ? 8 : bit_depth;
   const int16_t* mvs = int_mv + (long)blockIdx.x * kParts * 2;
 
-  for (int i = tid; i < kFracAcc; i += kThreads) acc[i] = 0;
-  for (int i = tid; i < 256 * BPS; i += kThreads) {
+  for (int i = tid; i < kFracAcc; i += NT) acc[i] = 0;
+  if (tid < 7 * kFracTabH) tab_h[tid] = (tid & 7) < 3 * BPS ? me_htap_dw<BPS>((tid >> 3) - 3, 0, tid & 7) : 0u;
+  if (tid >= 64 && tid < 64 + 7 * kFracTabV) {
+    const int i = tid - 64, row = i / kFracTabV, j = i - row * kFracTabV;
+    tab_v[i] = j < 9 ? (float)me_tap9(row - 3, j) * (BPS == 1 ? 1.f / 4096.f : __int_as_float((127 - (20 - bd)) << 23)) : 0.f;
+  }
+  for (int i = tid; i < 256 * BPS; i += NT) {
     const int r = i / (4 * BPS), q = i - r * (4 * BPS);
     *(uint4*)&curl[r * 16 * BPS + 4 * q] = *(const uint4*)(cur_base + (long)(job.ctu_y + r) * cur_pitch + job.ctu_x * BPS + 16 * q);
   }
@@ -716,10 +798,10 @@ me_frac_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet
     const uint32_t* src_al = (const uint32_t*)(src - mis);
     const int pitch_dw = ref_pitch >> 2;
     const int n = (wy + 63 + 8) * PDW;
-    for (int i = tid; i < n; i += kThreads) {
+    for (int i = tid; i < n; i += NT) {
       const int r = i / PDW, k = i - r * PDW;
       const uint32_t lo = src_al[(long)r * pitch_dw + k], hi = src_al[(long)r * pitch_dw + k + 1];
-      win[i] = __builtin_amdgcn_alignbyte(hi, lo, mis);
+      win[i] = __builtin_amdgcn_alignbyte(hi, lo, mis) ^ (BPS == 1 ? 0x80808080u : 0u);
     }
   }
   __syncthreads();
@@ -727,11 +809,12 @@ me_frac_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet
 #pragma unroll 1
   for (int stage = 0; stage < 2; ++stage) {
 #pragma unroll 1
-    for (int base = 0; base < kFracItems; base += kThreads) {
+    for (int base = 0; base < kFracItems; base += NT) {
       const uint32_t it = items[base + tid];
       const int slot = it & 1023, bx = (it >> 10) & 15, by = (it >> 14) & 15;
       const bool kind8 = (it >> 18) & 1;
-      const int mx = mvs[2 * slot], my = mvs[2 * slot + 1];
+      // integer MVs outside the CTU's window (not produced by the search) are clamped to it: the patch stays inside the LDS window
+      const int mx = min(max((int)mvs[2 * slot], job.lt_x), job.rb_x), my = min(max((int)mvs[2 * slot + 1], job.lt_y), job.rb_y);
       // patch (0,0) = block sample (-4,-4) = window row (by*4 + my - lt_y), sample (bx*4 + mx - lt_x) (halo offsets cancel)
       const int prow = by * 4 + (my - job.lt_y), pcol = (bx * 4 + (mx - job.lt_x)) * BPS;   // pcol in bytes
       const uint32_t* rowp = win + prow * PDW + (pcol >> 2);
@@ -745,29 +828,29 @@ me_frac_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet
 #pragma unroll
         for (int k = 0; k < PW; ++k) P[r][k] = __builtin_amdgcn_alignbyte(q[k + 1], q[k], o);
       }
-      int org[16];
+      float orgM[16];   // current samples + kRoundMagic (exact: integers below 2^24)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (BPS == 1) {
+        if constexpr (BPS == 1) {
           const uint32_t w = curl[(by * 4 + r) * 16 + bx];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) org[4 * r + c] = (int)((w >> (8 * c)) & 0xff);
+          for (int c = 0; c < 4; ++c) orgM[4 * r + c] = (float)((w >> (8 * c)) & 0xff) + kRoundMagic;
         } else {
           const uint2 w = *(const uint2*)&curl[(by * 4 + r) * 32 + bx * 2];
-          org[4 * r] = (int)(w.x & 0xffff); org[4 * r + 1] = (int)(w.x >> 16);
-          org[4 * r + 2] = (int)(w.y & 0xffff); org[4 * r + 3] = (int)(w.y >> 16);
+          orgM[4 * r] = (float)(w.x & 0xffff) + kRoundMagic; orgM[4 * r + 1] = (float)(w.x >> 16) + kRoundMagic;
+          orgM[4 * r + 2] = (float)(w.y & 0xffff) + kRoundMagic; orgM[4 * r + 3] = (float)(w.y >> 16) + kRoundMagic;
         }
       }
       if (stage == 0) {
-        me_frac_eval<0, HAD, BPS>(P, org, 0, 0, kind8, lane & 3, bd, acc + slot * 9);
+        me_frac_eval<0, HAD, BPS>(P, orgM, 0, 0, kind8, lane & 3, bd, tab_h, tab_v, acc + slot * 9);
       } else {
         const int hv = half[slot];
-        me_frac_eval<1, HAD, BPS>(P, org, 2 * (int)(short)(hv & 0xffff), 2 * (hv >> 16), kind8, lane & 3, bd, acc + slot * 9);
+        me_frac_eval<1, HAD, BPS>(P, orgM, 2 * (int)(short)(hv & 0xffff), 2 * (hv >> 16), kind8, lane & 3, bd, tab_h, tab_v, acc + slot * 9);
       }
     }
     __syncthreads();
-    for (int s = tid; s < kParts; s += kThreads) {
-      const int mx = mvs[2 * s], my = mvs[2 * s + 1];
+    for (int s = tid; s < kParts; s += NT) {
+      const int mx = min(max((int)mvs[2 * s], job.lt_x), job.rb_x), my = min(max((int)mvs[2 * s + 1], job.lt_y), job.rb_y);
       const int hv = stage ? half[s] : 0;
       const int hx = (int)(short)(hv & 0xffff), hy = hv >> 16;
       const int bxq = 4 * mx + 2 * hx, byq = 4 * my + 2 * hy;   // centre of this stage in quarter units
@@ -793,7 +876,7 @@ me_frac_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet
     }
     __syncthreads();
     if (stage == 0) {
-      for (int i = tid; i < kFracAcc; i += kThreads) acc[i] = 0;
+      for (int i = tid; i < kFracAcc; i += NT) acc[i] = 0;
       __syncthreads();
     }
   }
