@@ -516,3 +516,23 @@ def test_refinement_multi_reference_and_errors(engine):
         engine.refine_frame(pc, refs[0], 65, np.zeros((n, 593, 2), np.int16))
     for pl in planes:
         pl.close()
+
+
+@pytest.mark.parametrize("w,h,sr,bd", [(40, 24, 16, 8), (8, 8, 8, 8), (72, 8, 32, 8), (8, 200, 64, 8), (40, 24, 16, 10), (136, 72, 128, 10)])
+def test_tiny_and_sliver_pictures(engine, oracle_lib, w, h, sr, bd):
+    """pictures smaller than a CTU and one-CU-wide slivers: the window is clipped on every side at once (clipMv,
+    TComDataCU.cpp:2907-2920) and most of each CTU lies in the padded border"""
+    from hmme import api, synth
+    cur, ref, _ = synth.make_pair(w, h, seed=w + h, bit_depth=bd, max_mv=min(4, sr))
+    m = synth.MARGIN
+    n = api.load().hmme_num_ctus(w, h)
+    pred = synth.random_predictors(n, seed=3, max_pel=5)
+    engine.set_lambda(57.9)
+    with engine.plane(w, h, bd) as pc, engine.plane(w, h, bd) as pr:
+        pc.upload_pel(cur, (m, m)); pr.upload_pel(ref, (m, m))
+        mv, sad = engine.search_frame(pc, pr, sr, pred)
+        if sr <= 64:
+            qmv, _ = engine.refine_frame(pc, pr, sr, mv, pred)
+            assert np.abs(qmv.astype(np.int32) - 4 * mv.astype(np.int32)).max() <= 3
+    ox, oy, osad = oracle_lib.search_frame(cur, ref, (m, m), w, h, sr, pred, engine.lambda_q16, 1, bd, n_threads=4)
+    assert np.array_equal(mv[:, :, 0], ox) and np.array_equal(mv[:, :, 1], oy) and np.array_equal(sad, osad)
