@@ -56,7 +56,7 @@ struct hmme_ctx {
   int out_cap = 0;
   int* d_flag = nullptr;
   bool lds_optin[4] = {false, false, false, false};
-  uint32_t* d_frac_items = nullptr;   // fractional refinement: (slot, 4x4 sub-block) work list, same for every CTU
+  uint16_t* d_frac_cover = nullptr;   // fractional refinement: slots covering each 8x8 / 4x4 position, same for every CTU
   bool frac_optin[2][2] = {{false, false}, {false, false}};
   int16_t* d_imv = nullptr;           // host-facing refine call: integer MVs / quarter-pel MVs / costs on the device
   int16_t* d_qmv = nullptr;
@@ -317,7 +317,7 @@ void hmme_destroy(hmme_ctx* ctx) {
   hipFree(ctx->d_ctu); hipFree(ctx->d_win); hipFree(ctx->d_mv1); hipFree(ctx->d_sad1); hipFree(ctx->d_job1);
   hipFree(ctx->d_jobs); hipFree(ctx->d_first_strip); hipFree(ctx->d_best);
   hipFree(ctx->d_pred); hipFree(ctx->d_mv); hipFree(ctx->d_sad); hipFree(ctx->d_flag);
-  hipFree(ctx->d_frac_items); hipFree(ctx->d_imv); hipFree(ctx->d_qmv); hipFree(ctx->d_fcost);
+  hipFree(ctx->d_frac_cover); hipFree(ctx->d_imv); hipFree(ctx->d_qmv); hipFree(ctx->d_fcost);
   if (ctx->h_stage) hipHostFree(ctx->h_stage);
   if (ctx->h_mv) hipHostFree(ctx->h_mv);
   if (ctx->h_sad) hipHostFree(ctx->h_sad);
@@ -686,30 +686,28 @@ int hmme_search_frame(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* re
 
 // ---- fractional-pel refinement -------------------------------------------------------------------------------
 namespace {
-// work list of me_frac_kernel: every slot cut into 4x4 sub-blocks; slots whose width and height are multiples of 8
-// (8x8 Hadamard blocks, xGetHADs) first, quadrant by quadrant (TL, TR, BL, BR on 4 consecutive lanes), then the rest
-int build_frac_items(hmme_ctx* ctx) {
-  if (ctx->d_frac_items) return HMME_OK;
-  std::vector<uint32_t> items;
-  for (int pass = 0; pass < 2; ++pass)
-    for (int slot = 0; slot < HMME_NUM_CTU_PARTS; ++slot) {
-      int x, y, w, h;
-      hmme_slot_rect(slot, &x, &y, &w, &h);
-      const bool kind8 = (w % 8 == 0) && (h % 8 == 0);
-      if (kind8 != (pass == 0)) continue;
-      if (kind8) {
-        for (int by = 0; by < h; by += 8)
-          for (int bx = 0; bx < w; bx += 8)
-            for (int q = 0; q < 4; ++q)
-              items.push_back((uint32_t)slot | (uint32_t)((x + bx) / 4 + (q & 1)) << 10 | (uint32_t)((y + by) / 4 + (q >> 1)) << 14 | 1u << 18);
-      } else {
-        for (int by = 0; by < h; by += 4)
-          for (int bx = 0; bx < w; bx += 4) items.push_back((uint32_t)slot | (uint32_t)((x + bx) / 4) << 10 | (uint32_t)((y + by) / 4) << 14);
+// cover table of me_frac_kernel: for each of the 64 8x8 positions of the CTU the 18 kind-8 slots (width and height
+// multiples of 8: 8x8 Hadamard blocks, xGetHADs) that contain it, then for each of the 256 4x4 positions the 6 other
+// slots that contain it; ascending slot ids
+int build_frac_cover(hmme_ctx* ctx) {
+  if (ctx->d_frac_cover) return HMME_OK;
+  std::vector<uint16_t> cover;
+  for (int kind8 = 1; kind8 >= 0; --kind8) {
+    const int step = kind8 ? 8 : 4, per = kind8 ? hmme::kFracCover8 : hmme::kFracCover4;
+    for (int py = 0; py < 64; py += step)
+      for (int px = 0; px < 64; px += step) {
+        int n = 0;
+        for (int slot = 0; slot < HMME_NUM_CTU_PARTS; ++slot) {
+          int x, y, w, h;
+          hmme_slot_rect(slot, &x, &y, &w, &h);
+          if (((w % 8 == 0) && (h % 8 == 0)) != (kind8 == 1)) continue;
+          if (px >= x && px < x + w && py >= y && py < y + h) { cover.push_back((uint16_t)slot); ++n; }
+        }
+        if (n != per) return fail(ctx, HMME_ERR_DEVICE, "internal: %d slots cover a %dx%d position, expected %d", n, step, step, per);
       }
-    }
-  if ((int)items.size() != hmme::kFracItems) return fail(ctx, HMME_ERR_DEVICE, "internal: %zu refinement items", items.size());
-  HIP_TRY(ctx, hipMalloc(&ctx->d_frac_items, sizeof(uint32_t) * items.size()));
-  HIP_TRY(ctx, hipMemcpy(ctx->d_frac_items, items.data(), sizeof(uint32_t) * items.size(), hipMemcpyHostToDevice));
+  }
+  HIP_TRY(ctx, hipMalloc(&ctx->d_frac_cover, sizeof(uint16_t) * cover.size()));
+  HIP_TRY(ctx, hipMemcpy(ctx->d_frac_cover, cover.data(), sizeof(uint16_t) * cover.size(), hipMemcpyHostToDevice));
   return HMME_OK;
 }
 }  // namespace
@@ -732,7 +730,7 @@ int hmme_refine_frame_multi_device(hmme_ctx* ctx, const hmme_plane* cur, const h
   if (!d_int_mv || !d_out_qmv || !d_out_cost) return fail(ctx, HMME_ERR_ARG, "null buffer");
   if (count == 0) return HMME_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  int rc = build_frac_items(ctx);
+  int rc = build_frac_cover(ctx);
   if (rc) return rc;
   const int jobs = count * n_refs;
   size_t cap = ctx->jobs_bytes;
@@ -744,7 +742,7 @@ int hmme_refine_frame_multi_device(hmme_ctx* ctx, const hmme_plane* cur, const h
                      first, count, n_refs, cur->width, cur->height, fp->search_range);
   HIP_TRY(ctx, hipGetLastError());
   const int had = use_hadamard ? 1 : 0, wide = cur->bps == 2 ? 1 : 0;
-  using frac_fn = void (*)(const uint8_t*, int, const RefSet, int, const MeJob*, const uint32_t*, const int16_t*, uint32_t, int, int16_t*,
+  using frac_fn = void (*)(const uint8_t*, int, const RefSet, int, const MeJob*, const uint16_t*, const int16_t*, uint32_t, int, int16_t*,
                            uint32_t*);
   static const frac_fn fns[2][2] = {{hmme::me_frac_kernel<0, 1>, hmme::me_frac_kernel<1, 1>},
                                     {hmme::me_frac_kernel<0, 2>, hmme::me_frac_kernel<1, 2>}};
@@ -754,7 +752,7 @@ int hmme_refine_frame_multi_device(hmme_ctx* ctx, const hmme_plane* cur, const h
     ctx->frac_optin[wide][had] = true;
   }
   hipLaunchKernelGGL(fn, dim3(jobs), dim3(hmme::frac_threads(wide ? 2 : 1)), hmme::frac_lds_bytes(wide ? 2 : 1), s, cur->origin(), cur->pitch, set,
-                     refs[0]->pitch, (const MeJob*)ctx->d_jobs, ctx->d_frac_items, (const int16_t*)d_int_mv, ctx->lambda_q16,
+                     refs[0]->pitch, (const MeJob*)ctx->d_jobs, ctx->d_frac_cover, (const int16_t*)d_int_mv, ctx->lambda_q16,
                      fp->bit_depth, (int16_t*)d_out_qmv, (uint32_t*)d_out_cost);
   HIP_TRY(ctx, hipGetLastError());
   return HMME_OK;

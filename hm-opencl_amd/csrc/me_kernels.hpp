@@ -566,14 +566,13 @@ __global__ void me_prep_jobs_split_kernel(MeJob16* jobs, int* first_strip_of_job
 // quad_perm DPP butterflies, so slots whose size is a multiple of 8 (8x8 Hadamard blocks) and the others (4x4
 // blocks) run the same code.  Per-slot distortions accumulate in LDS (ds_add_u32); 593 threads then add the MV cost
 // and pick the winner in HM's point order (strict '<', tables TEncSearch.cpp:51-75).
-constexpr int kFracItems = 6144;           // sum over slots of w*h/16
 constexpr int kFracRowsMax = 200;          // window + 4-sample halo: 129 + 63 + 8 = 200 rows of 200 samples
 constexpr int kFracAcc = 593 * 9;
 // BPS = bytes per sample of the planes (1: 8-bit video, 2: 9..12 bit).  Window pitch in dwords (odd), LDS bytes.
 constexpr int frac_pdw(int bps) { return bps == 1 ? 51 : 101; }
 // u16 planes: the window leaves room for one workgroup per CU, so that one has 8 waves (2 per SIMD) instead of 4
 constexpr int frac_threads(int bps) { return bps == 1 ? 256 : 512; }
-constexpr size_t frac_lds_bytes(int bps) { return (size_t)(5344 + 600 + 160 + 1024 * bps + kFracRowsMax * frac_pdw(bps)) * 4; }
+constexpr size_t frac_lds_bytes(int bps) { return (size_t)(5344 + 600 + 160 + (64 * 18 + 256 * 6) / 2 + 1024 * bps + kFracRowsMax * frac_pdw(bps)) * 4; }
 
 __device__ __forceinline__ uint32_t me_mv_cost_q(uint32_t lambda_q16, int vx_q, int vy_q, int pred_x, int pred_y) {
   return (lambda_q16 * (me_component_bits(vx_q - pred_x) + me_component_bits(vy_q - pred_y))) >> 16;
@@ -621,9 +620,11 @@ __device__ __forceinline__ float me_dpp_f(float v, const int ctrl_b1) {
 // (tools/ubench/valu_rates3).  bd = bit depth of the video (8 when BPS == 1): the two passes shift by bd-8 and
 // 20-bd around the 14-bit intermediate (TComInterpolationFilter.cpp:170-212: headRoom = 14 - bd).
 constexpr float kRoundMagic = 12582912.0f;   // 1.5 * 2^23: x + magic rounds x to the nearest integer (ties to even)
-template <int STAGE, int HAD, int BPS>
-__device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3 * BPS], const float (&orgM)[16], int cqx, int cqy, bool kind8,
-                                             int role, int bd, const uint32_t* tab_h, const float* tab_v, uint32_t* acc_slot) {
+// KIND8: the lane is one quadrant (role 0..3 = TL, TR, BL, BR) of an 8x8 Hadamard block; all four lanes of the quad
+// return the block's distortion.  out[point]: distortion of the 9 refinement points in HM's point order.
+template <int STAGE, int HAD, int BPS, int KIND8>
+__device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3 * BPS], const float (&orgM)[16], int cqx, int cqy, int role, int bd,
+                                             const uint32_t* tab_h, const float* tab_v, uint32_t (&out)[9]) {
   constexpr int step = STAGE == 0 ? 2 : 1, PW = 3 * BPS;
   // point index of (dx, dy) in s_acMvRefineH / s_acMvRefineQ order (reference TEncSearch.cpp:51-75)
   constexpr int idxH[3][3] = {{5, 1, 6}, {3, 0, 4}, {7, 2, 8}}, idxQ[3][3] = {{3, 1, 4}, {5, 0, 6}, {7, 2, 8}};   // [dy+1][dx+1]
@@ -712,6 +713,10 @@ __device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3 * BPS], c
         float sad = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) sad += __builtin_fabsf(d[i]);
+        if (KIND8) {   // the quad's four 4x4 SADs belong to the same slots: hand out their sum
+          sad += me_dpp_f(sad, 1);
+          sad += me_dpp_f(sad, 0);
+        }
         contrib = (uint32_t)sad;
       } else {
         float m[16];
@@ -727,7 +732,7 @@ __device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3 * BPS], c
           z[k] = a + b; z[4 + k] = a - b; z[8 + k] = f + e; z[12 + k] = f - e;
         }
         float sum = 0.f;
-        if (kind8) {   // wave-uniform: combine the quad's four 4x4 transforms into the 8x8 transform (xCalcHADs8x8)
+        if (KIND8) {   // combine the quad's four 4x4 transforms into the 8x8 transform (xCalcHADs8x8)
           // two butterflies across the quad, each one v_fmac_f32 with a DPP source: z += t * z[neighbour], t = +-1 by
           // role.  Odd roles hold the negated difference, which the absolute sum does not see.  One asm block keeps
           // 16 instructions between a register's write and its DPP read (the hazard the assembler does not pad for).
@@ -754,27 +759,104 @@ __device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3 * BPS], c
           contrib = ((uint32_t)sum + 1) >> 1;
         }
       }
-      const int point = STAGE == 0 ? idxH[dyi][dxi] : idxQ[dyi][dxi];
-      if (!(HAD && kind8) || role == 0) atomicAdd(&acc_slot[point], contrib);
+      out[STAGE == 0 ? idxH[dyi][dxi] : idxQ[dyi][dxi]] = contrib;
     }
+  }
+}
+
+// Work sharing.  A kind-8 slot (width and height multiples of 8) is a set of 8x8 Hadamard blocks, any other slot a set
+// of 4x4 blocks; each of the 64 8x8 positions of the CTU is covered by kFracCover8 = 18 kind-8 slots (7 partition modes
+// at 64 and 32, three at 16, one at 8) and each of the 256 4x4 positions by kFracCover4 = 6 others (the 4 AMP shapes at
+// 16, 8x4, 4x8).  Slots that cover a position with the same integer MV (and, in the quarter-pel stage, the same half-pel
+// winner) get the same nine distortions from it, so each stage first lists the DISTINCT (position, MV) pairs, evaluates
+// those -- one lane per 4x4 block, a quad of lanes per 8x8 block -- and adds the result to every slot that shares it.
+// `cover`: uint16 [64][18] then [256][6] slot ids, ascending (built by the host from the slot table).
+constexpr int kFracCover8 = 18, kFracCover4 = 6, kFracPairs8 = 64 * kFracCover8, kFracPairs4 = 256 * kFracCover4;
+
+template <int STAGE, int HAD, int BPS, int KIND8>
+__device__ __forceinline__ void me_frac_item(const uint32_t* win, const uint32_t* curl, const uint32_t* st, const uint16_t* __restrict__ cover,
+                                             int pair, int role, int bd, const uint32_t* tab_h, const float* tab_v, uint32_t* acc) {
+  constexpr int PDW = frac_pdw(BPS), PW = 3 * BPS, NCOV = KIND8 ? kFracCover8 : kFracCover4;
+  constexpr uint32_t keymask = STAGE ? 0xfffffu : 0xffffu;
+  const int q = KIND8 ? pair : pair - kFracPairs8;
+  const int pos = q / NCOV, j = q - pos * NCOV;
+  const uint16_t* cov = cover + (KIND8 ? 0 : kFracPairs8) + pos * NCOV;
+  const uint32_t sv = st[cov[j]];
+  const int bx = KIND8 ? 2 * (pos & 7) + (role & 1) : (pos & 15), by = KIND8 ? 2 * (pos >> 3) + (role >> 1) : (pos >> 4);
+  // patch (0,0) = block sample (-4,-4) = window row (by*4 + my - lt_y), sample (bx*4 + mx - lt_x) (halo offsets cancel)
+  const int prow = by * 4 + (int)((sv >> 8) & 0xff), pcol = (bx * 4 + (int)(sv & 0xff)) * BPS;   // pcol in bytes
+  const uint32_t* rowp = win + prow * PDW + (pcol >> 2);
+  const uint32_t o = (uint32_t)pcol & 3u;
+  uint32_t P[12][PW];
+#pragma unroll
+  for (int r = 0; r < 12; ++r) {
+    uint32_t w[PW + 1];
+#pragma unroll
+    for (int k = 0; k <= PW; ++k) w[k] = rowp[r * PDW + k];
+#pragma unroll
+    for (int k = 0; k < PW; ++k) P[r][k] = __builtin_amdgcn_alignbyte(w[k + 1], w[k], o);
+  }
+  float orgM[16];   // current samples + kRoundMagic (exact: integers below 2^24)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if constexpr (BPS == 1) {
+      const uint32_t w = curl[(by * 4 + r) * 16 + bx];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) orgM[4 * r + c] = (float)((w >> (8 * c)) & 0xff) + kRoundMagic;
+    } else {
+      const uint2 w = *(const uint2*)&curl[(by * 4 + r) * 32 + bx * 2];
+      orgM[4 * r] = (float)(w.x & 0xffff) + kRoundMagic; orgM[4 * r + 1] = (float)(w.x >> 16) + kRoundMagic;
+      orgM[4 * r + 2] = (float)(w.y & 0xffff) + kRoundMagic; orgM[4 * r + 3] = (float)(w.y >> 16) + kRoundMagic;
+    }
+  }
+  uint32_t dist[9];
+  const int cqx = STAGE ? 2 * ((int)((sv >> 16) & 3) - 1) : 0, cqy = STAGE ? 2 * ((int)((sv >> 18) & 3) - 1) : 0;
+  me_frac_eval<STAGE, HAD, BPS, KIND8>(P, orgM, cqx, cqy, role, bd, tab_h, tab_v, dist);
+  // every slot of this position with the same key takes the distortions; the quad's lanes split the slot list
+  for (int j2 = j + (KIND8 ? role : 0); j2 < NCOV; j2 += KIND8 ? 4 : 1) {
+    const int s2 = cov[j2];
+    if (j2 == j || ((st[s2] ^ sv) & keymask) == 0) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) atomicAdd(&acc[s2 * 9 + i], dist[i]);
+    }
+  }
+}
+
+// distinct (position, key) pairs of one stage -> work lists.  Thread t < 64 owns 8x8 position t, the next 256 own the 4x4
+// positions; the first slot (lowest index in the cover list) with a given key is the one evaluated.
+template <int NCOV>
+__device__ __forceinline__ void me_frac_dedupe(const uint32_t* st, const uint16_t* __restrict__ cov, uint32_t keymask, int pair0,
+                                               uint32_t* counter, uint16_t* list) {
+  uint32_t key[NCOV];
+#pragma unroll
+  for (int j = 0; j < NCOV; ++j) key[j] = st[cov[j]] & keymask;
+#pragma unroll
+  for (int j = 0; j < NCOV; ++j) {
+    bool first = true;
+#pragma unroll
+    for (int k = 0; k < j; ++k) first = first && key[k] != key[j];
+    if (first) list[atomicAdd(counter, 1u)] = (uint16_t)(pair0 + j);
   }
 }
 
 template <int HAD, int BPS>
 __global__ void __launch_bounds__(frac_threads(BPS), BPS == 1 ? 2 : 1)
 me_frac_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet refs, int ref_pitch,
-               const MeJob* __restrict__ jobs, const uint32_t* __restrict__ items, const int16_t* __restrict__ int_mv,
+               const MeJob* __restrict__ jobs, const uint16_t* __restrict__ cover, const int16_t* __restrict__ int_mv,
                uint32_t lambda_q16, int bit_depth, int16_t* __restrict__ out_qmv, uint32_t* __restrict__ out_cost) {
-  constexpr int PDW = frac_pdw(BPS), PW = 3 * BPS, NT = frac_threads(BPS);
+  constexpr int PDW = frac_pdw(BPS), NT = frac_threads(BPS);
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t* acc = smem;                 // [593][9] distortion sums of the current stage
-  int* half = (int*)(smem + 5344);      // [593] half-pel winner, packed (hx & 0xffff) | (hy << 16)
-  uint32_t* tab_h = smem + 5344 + 600;  // [7][kFracTabH] packed horizontal taps of q = -3..3
+  uint32_t* st = smem + 5344;           // [593] slot state: (mx - lt_x) | (my - lt_y) << 8 | (half_x + 1) << 16 | (half_y + 1) << 18
+  uint32_t* tab_h = st + 600;           // [7][kFracTabH] packed horizontal taps of q = -3..3
   float* tab_v = (float*)(tab_h + 7 * kFracTabH);   // [7][kFracTabV] vertical taps
-  uint32_t* curl = smem + 5344 + 600 + 160;   // 64 x 64 current block
+  uint32_t* counter = tab_h + 152;      // [2] lengths of the two work lists
+  uint16_t* list8 = (uint16_t*)(tab_h + 160);                  // distinct (8x8 position, key) pairs
+  uint16_t* list4 = (uint16_t*)(tab_h + 160 + kFracPairs8 / 2);   // distinct (4x4 position, key) pairs
+  uint32_t* curl = tab_h + 160 + (kFracPairs8 + kFracPairs4) / 2;   // 64 x 64 current block
   uint32_t* win = curl + 1024 * BPS;    // reference window with a 4-sample halo, pitch PDW dwords (8-bit samples XOR 0x80)
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x;
   MeJob job = jobs[blockIdx.x];
   const uint8_t* __restrict__ ref_base = refs.base[job.ctu_x & 63];
   job.ctu_x &= ~63;
@@ -783,11 +865,17 @@ me_frac_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet
   const int16_t* mvs = int_mv + (long)blockIdx.x * kParts * 2;
 
   for (int i = tid; i < kFracAcc; i += NT) acc[i] = 0;
+  // integer MVs outside the CTU's window (not produced by the search) are clamped to it: the patch stays inside the LDS window
+  for (int s = tid; s < kParts; s += NT) {
+    const int mx = min(max((int)mvs[2 * s], job.lt_x), job.rb_x), my = min(max((int)mvs[2 * s + 1], job.lt_y), job.rb_y);
+    st[s] = (uint32_t)(mx - job.lt_x) | (uint32_t)(my - job.lt_y) << 8 | 1u << 16 | 1u << 18;
+  }
   if (tid < 7 * kFracTabH) tab_h[tid] = (tid & 7) < 3 * BPS ? me_htap_dw<BPS>((tid >> 3) - 3, 0, tid & 7) : 0u;
   if (tid >= 64 && tid < 64 + 7 * kFracTabV) {
     const int i = tid - 64, row = i / kFracTabV, j = i - row * kFracTabV;
     tab_v[i] = j < 9 ? (float)me_tap9(row - 3, j) * (BPS == 1 ? 1.f / 4096.f : __int_as_float((127 - (20 - bd)) << 23)) : 0.f;
   }
+  if (tid < 2) counter[tid] = 0;
   for (int i = tid; i < 256 * BPS; i += NT) {
     const int r = i / (4 * BPS), q = i - r * (4 * BPS);
     *(uint4*)&curl[r * 16 * BPS + 4 * q] = *(const uint4*)(cur_base + (long)(job.ctu_y + r) * cur_pitch + job.ctu_x * BPS + 16 * q);
@@ -808,51 +896,28 @@ me_frac_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet
 
 #pragma unroll 1
   for (int stage = 0; stage < 2; ++stage) {
+    const uint32_t keymask = stage ? 0xfffffu : 0xffffu;
+    for (int t = tid; t < 64 + 256; t += NT) {
+      if (t < 64) me_frac_dedupe<kFracCover8>(st, cover + t * kFracCover8, keymask, t * kFracCover8, &counter[0], list8);
+      else me_frac_dedupe<kFracCover4>(st, cover + kFracPairs8 + (t - 64) * kFracCover4, keymask, kFracPairs8 + (t - 64) * kFracCover4, &counter[1], list4);
+    }
+    __syncthreads();
+    const int n8 = 4 * (int)counter[0], n4 = (int)counter[1];
 #pragma unroll 1
-    for (int base = 0; base < kFracItems; base += NT) {
-      const uint32_t it = items[base + tid];
-      const int slot = it & 1023, bx = (it >> 10) & 15, by = (it >> 14) & 15;
-      const bool kind8 = (it >> 18) & 1;
-      // integer MVs outside the CTU's window (not produced by the search) are clamped to it: the patch stays inside the LDS window
-      const int mx = min(max((int)mvs[2 * slot], job.lt_x), job.rb_x), my = min(max((int)mvs[2 * slot + 1], job.lt_y), job.rb_y);
-      // patch (0,0) = block sample (-4,-4) = window row (by*4 + my - lt_y), sample (bx*4 + mx - lt_x) (halo offsets cancel)
-      const int prow = by * 4 + (my - job.lt_y), pcol = (bx * 4 + (mx - job.lt_x)) * BPS;   // pcol in bytes
-      const uint32_t* rowp = win + prow * PDW + (pcol >> 2);
-      const uint32_t o = (uint32_t)pcol & 3u;
-      uint32_t P[12][PW];
-#pragma unroll
-      for (int r = 0; r < 12; ++r) {
-        uint32_t q[PW + 1];
-#pragma unroll
-        for (int k = 0; k <= PW; ++k) q[k] = rowp[r * PDW + k];
-#pragma unroll
-        for (int k = 0; k < PW; ++k) P[r][k] = __builtin_amdgcn_alignbyte(q[k + 1], q[k], o);
-      }
-      float orgM[16];   // current samples + kRoundMagic (exact: integers below 2^24)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if constexpr (BPS == 1) {
-          const uint32_t w = curl[(by * 4 + r) * 16 + bx];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) orgM[4 * r + c] = (float)((w >> (8 * c)) & 0xff) + kRoundMagic;
-        } else {
-          const uint2 w = *(const uint2*)&curl[(by * 4 + r) * 32 + bx * 2];
-          orgM[4 * r] = (float)(w.x & 0xffff) + kRoundMagic; orgM[4 * r + 1] = (float)(w.x >> 16) + kRoundMagic;
-          orgM[4 * r + 2] = (float)(w.y & 0xffff) + kRoundMagic; orgM[4 * r + 3] = (float)(w.y >> 16) + kRoundMagic;
-        }
-      }
-      if (stage == 0) {
-        me_frac_eval<0, HAD, BPS>(P, orgM, 0, 0, kind8, lane & 3, bd, tab_h, tab_v, acc + slot * 9);
-      } else {
-        const int hv = half[slot];
-        me_frac_eval<1, HAD, BPS>(P, orgM, 2 * (int)(short)(hv & 0xffff), 2 * (hv >> 16), kind8, lane & 3, bd, tab_h, tab_v, acc + slot * 9);
-      }
+    for (int i = tid; i < n8; i += NT) {   // whole quads: n8 and NT are multiples of 4
+      if (stage == 0) me_frac_item<0, HAD, BPS, 1>(win, curl, st, cover, list8[i >> 2], tid & 3, bd, tab_h, tab_v, acc);
+      else me_frac_item<1, HAD, BPS, 1>(win, curl, st, cover, list8[i >> 2], tid & 3, bd, tab_h, tab_v, acc);
+    }
+#pragma unroll 1
+    for (int i = tid; i < n4; i += NT) {
+      if (stage == 0) me_frac_item<0, HAD, BPS, 0>(win, curl, st, cover, list4[i], 0, bd, tab_h, tab_v, acc);
+      else me_frac_item<1, HAD, BPS, 0>(win, curl, st, cover, list4[i], 0, bd, tab_h, tab_v, acc);
     }
     __syncthreads();
     for (int s = tid; s < kParts; s += NT) {
-      const int mx = min(max((int)mvs[2 * s], job.lt_x), job.rb_x), my = min(max((int)mvs[2 * s + 1], job.lt_y), job.rb_y);
-      const int hv = stage ? half[s] : 0;
-      const int hx = (int)(short)(hv & 0xffff), hy = hv >> 16;
+      const uint32_t sv = st[s];
+      const int mx = (int)(sv & 0xff) + job.lt_x, my = (int)((sv >> 8) & 0xff) + job.lt_y;
+      const int hx = stage ? (int)((sv >> 16) & 3) - 1 : 0, hy = stage ? (int)((sv >> 18) & 3) - 1 : 0;
       const int bxq = 4 * mx + 2 * hx, byq = 4 * my + 2 * hy;   // centre of this stage in quarter units
       constexpr int ph[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};
       constexpr int pq[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {1, 1}};
@@ -866,7 +931,7 @@ me_frac_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet
         if (d < best) { best = d; bi = i; }
       }
       if (stage == 0) {
-        half[s] = (ph[bi][0] & 0xffff) | (ph[bi][1] << 16);
+        st[s] = (sv & 0xffffu) | (uint32_t)(ph[bi][0] + 1) << 16 | (uint32_t)(ph[bi][1] + 1) << 18;
       } else {
         const long o = (long)blockIdx.x * kParts + s;
         out_qmv[2 * o] = (int16_t)(bxq + pq[bi][0]);
@@ -874,8 +939,9 @@ me_frac_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet
         out_cost[o] = best;
       }
     }
-    __syncthreads();
     if (stage == 0) {
+      if (tid < 2) counter[tid] = 0;
+      __syncthreads();   // every thread has read its acc entries
       for (int i = tid; i < kFracAcc; i += NT) acc[i] = 0;
       __syncthreads();
     }

@@ -449,13 +449,19 @@ def test_device_resident_producer_and_async_api(engine, oracle_lib):
 
 
 @pytest.mark.parametrize("use_had,sr,use_pred,bd", [(1, 16, True, 8), (0, 16, True, 8), (1, 64, False, 8), (1, 16, True, 10),
-                                                      (0, 64, False, 12), (1, 24, True, 9)])
+                                                      (0, 64, False, 12), (1, 24, True, 9), (1, 17, True, -8), (0, 33, False, -10)])
 def test_fractional_refinement_vs_oracle(engine, oracle_lib, use_had, sr, use_pred, bd):
     """the step after the path: xPatternSearchFracDIF for all 593 slots of every CTU (half + quarter-pel, HM's
     8-tap interpolation, Hadamard or SAD), fed with the engine's own integer MVs"""
     from hmme import synth
     w, h = 200, 136                                   # 4 x 3 CTUs, partial right column and bottom row
+    unrelated = bd < 0   # negative depth: current and reference are unrelated noise -> nearly every slot has its own MV (no work sharing)
+    bd = abs(bd)
     cur, ref, _ = synth.make_pair(w, h, seed=31 + sr, bit_depth=bd, max_mv=min(sr, 9), region=64, noise_sigma=2.5)
+    if unrelated:
+        rng0 = np.random.default_rng(77 + sr)
+        cur = np.ascontiguousarray(np.pad(rng0.integers(0, 1 << bd, size=(h, w)), synth.MARGIN, mode="edge").astype(cur.dtype))
+        ref = np.ascontiguousarray(np.pad(rng0.integers(0, 1 << bd, size=(h, w)), synth.MARGIN, mode="edge").astype(ref.dtype))
     m = synth.MARGIN
     n_ctu = 4 * 3
     pred = synth.random_predictors(n_ctu, seed=8, max_pel=6) if use_pred else None

@@ -9,6 +9,12 @@ w, h, sr = 3840, 2160, 64
 if len(sys.argv) > 1: w, h = (int(v) for v in sys.argv[1].split("x"))
 bd = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 cur, ref, _ = synth.make_pair(w, h, seed=1234, bit_depth=bd)
+content = sys.argv[3] if len(sys.argv) > 3 else "coherent"
+if content == "noise":   # unrelated pictures: nearly every slot has its own integer MV, nothing to share
+    import numpy as np
+    rng = np.random.default_rng(5)
+    cur = np.ascontiguousarray(np.pad(rng.integers(0, 1 << bd, size=(h, w)), synth.MARGIN, mode="edge").astype(cur.dtype))
+    ref = np.ascontiguousarray(np.pad(rng.integers(0, 1 << bd, size=(h, w)), synth.MARGIN, mode="edge").astype(ref.dtype))
 m = synth.MARGIN
 eng = api.Engine(0, 64); eng.set_lambda(57.9)
 pc, pr = eng.plane(w, h, bd), eng.plane(w, h, bd)
@@ -31,4 +37,4 @@ for had in (1, 0):
     e1.record(); torch.cuda.synchronize()
     out["hadamard" if had else "sad"] = round(e0.elapsed_time(e1) / 5, 3)
 frac = (d_q.to(torch.int32) - 4 * d_mv.to(torch.int32)).abs().amax().item()
-print(json.dumps({"size": f"{w}x{h}", "bit_depth": bd, "refine_ms": out, "slots_per_s_hadamard": round(n * 593 / (out["hadamard"] * 1e-3)), "max_frac_offset_qpel": frac}))
+print(json.dumps({"size": f"{w}x{h}", "bit_depth": bd, "content": content, "refine_ms": out, "slots_per_s_hadamard": round(n * 593 / (out["hadamard"] * 1e-3)), "max_frac_offset_qpel": frac}))
