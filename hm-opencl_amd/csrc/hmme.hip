@@ -23,7 +23,7 @@ constexpr int kMarginY = 80;   // TComPicYuv: maxCUHeight + 16 (reference TComPi
 constexpr int kWinPitch = 1024;  // per-CTU path: bytes per packed window row (>= 2 * (257 + 63) + 8)
 constexpr int kWinRows = 2 * 128 + 1 + 63;
 constexpr size_t kLdsBudget16 = 78 * 1024;   // per workgroup of the 16-bit path -> 2 workgroups per CU
-constexpr int kPdw16Small = 97, kPdw16Large = 161;   // 16-bit window pitch in dwords for SR <= 64 / SR <= 128 (odd: no LDS conflicts)
+constexpr int kPdw16Small = 98, kPdw16Large = 162;   // 16-bit window pitch in dwords for SR <= 64 / SR <= 128 (even: rows stay 8-byte aligned for ds_read_b64)
 std::string g_create_error;
 }  // namespace
 

@@ -403,34 +403,43 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const Re
   const int ny = jb.y1 - jb.y0;                                        // candidate rows of this strip
 
   for (int s = tid; s < kParts; s += kThreads) best64[s] = ~0ull;
-  if (tid == 0) *task_ctr = 0;
   for (int i = tid; i < 64 * 8; i += kThreads) {
     const int r = i >> 3, q = i & 7;
     curl[i] = *(const u32x4_t*)(cur_base + (long)(job.ctu_y + r) * cur_pitch + 2 * job.ctu_x + 16 * q);
   }
-  {
-    const uint8_t* src = ref_base + (long)(job.ctu_y + job.lt_y + jb.y0) * ref_pitch + 2 * (job.ctu_x + job.lt_x);
-    const uint32_t mis = (uint32_t)(uintptr_t)src & 3u;
-    const uint32_t* src_al = (const uint32_t*)(src - mis);
-    const int pitch_dw = ref_pitch >> 2;
-    const int n = (ny + 63) * PDW;
-    for (int i = tid; i < n; i += kThreads) {
-      const int r = i / PDW, k = i - r * PDW;
-      const uint32_t lo = src_al[(long)r * pitch_dw + k], hi = src_al[(long)r * pitch_dw + k + 1];
-      win[i] = __builtin_amdgcn_alignbyte(hi, lo, mis);
-    }
-  }
-  __syncthreads();
-
-  const int pairs = (wx + 1) >> 1;                                     // candidate pairs per window row
-  const int n_iters = (ny * pairs + 63) >> 6;
-  const int n_tasks = (n_iters + kIterPerTask16 - 1) / kIterPerTask16;
   // key = ((sum & mask) << lsh) + c  ==  (((sum << fen_shift) >> sh) << 10) + c
   const uint32_t mask_a = ~((1u << sh) - 1u), lsh_a = kIdxBits16 - sh;
   const uint32_t mask_e = FEN ? ~((1u << (sh > 0 ? sh - 1 : 0)) - 1u) : mask_a, lsh_e = FEN ? kIdxBits16 + 1 - sh : lsh_a;
   const bool rb1 = lane & 2, rb0 = lane & 1;
   const lds_vu32x4_t* curv4 = (const lds_vu32x4_t*)curl;
   constexpr int ME16_PDW = PDW;
+  static_assert(PDW % 2 == 0, "window rows must stay 8-byte aligned (ds_read_b64)");
+
+  // Two passes: the even window columns, then the odd ones, each over a window loaded with a shift of `par` samples.
+  // A lane owns the candidates (x, x + 2): both read dword-aligned u16 pairs, the second one dword further on, so no
+  // per-lane realignment (v_alignbit per dword and row) is left in the tree.
+#pragma unroll 1
+  for (int par = 0; par < 2; ++par) {
+    if (par) __syncthreads();                                          // every wave is done with the previous window
+    if (tid == 0) *task_ctr = 0;
+    {
+      const uint8_t* src = ref_base + (long)(job.ctu_y + job.lt_y + jb.y0) * ref_pitch + 2 * (job.ctu_x + job.lt_x + par);
+      const uint32_t mis = (uint32_t)(uintptr_t)src & 3u;
+      const uint32_t* src_al = (const uint32_t*)(src - mis);
+      const int pitch_dw = ref_pitch >> 2;
+      const int n = (ny + 63) * PDW;
+      for (int i = tid; i < n; i += kThreads) {
+        const int r = i / PDW, k = i - r * PDW;
+        const uint32_t lo = src_al[(long)r * pitch_dw + k], hi = src_al[(long)r * pitch_dw + k + 1];
+        win[i] = __builtin_amdgcn_alignbyte(hi, lo, mis);
+      }
+    }
+    __syncthreads();
+
+  const int n_par = (wx + 1 - par) >> 1;                               // candidates of this column parity per window row
+  const int pairs = (n_par + 1) >> 1;                                  // lanes per window row
+  const int n_iters = (ny * pairs + 63) >> 6;
+  const int n_tasks = (n_iters + kIterPerTask16 - 1) / kIterPerTask16;
 
   while (true) {
     int t = 0;
@@ -444,7 +453,7 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const Re
     for (int it = 0; it < n_it; ++it) {
       const int q = (it0 + it) * 64 + lane;
       const int row = q / pairs, pr = q - row * pairs;
-      const int cx = 2 * pr, cy = jb.y0 + row;
+      const int cx = par + 4 * pr, cy = jb.y0 + row;
       const bool vy = row < ny;
       const int mvy = job.lt_y + cy, mvx = job.lt_x + cx;
       const uint32_t by = me_component_bits((mvy << 2) - job.pred_y);
@@ -452,11 +461,11 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const Re
       uint32_t cc[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const uint32_t cost = (lambda_q16 * (me_component_bits(((mvx + j) << 2) - job.pred_x) + by)) >> 16;
-        cc[j] = (((vy && (cx + j) < wx) ? cost : kInvCost16) << kIdxBits16) | tag | (uint32_t)j;
+        const uint32_t cost = (lambda_q16 * (me_component_bits(((mvx + 2 * j) << 2) - job.pred_x) + by)) >> 16;
+        cc[j] = (((vy && (cx + 2 * j) < wx) ? cost : kInvCost16) << kIdxBits16) | tag | (uint32_t)j;
       }
       const uint32_t c0 = cc[0], c1 = cc[1];
-      const lds_vu32_t* lpv = (const lds_vu32_t*)(win + min(row, ny - 1) * PDW + pr);
+      const lds_vu64_t* lpq = (const lds_vu64_t*)(win + min(row, ny - 1) * PDW + 2 * pr);   // 8-byte aligned: PDW is even
       if constexpr (FEN) {
 #include "me_tree16_fen1.inc"
       } else {
@@ -471,7 +480,7 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const Re
       if (slot >= 0 && cost < kInvCost16) {                                                                          \
         const int kq = (it0 + (int)((key >> 8) & 1)) * 64 + (int)((key >> 2) & 63);                                \
         const int krow = kq / pairs;                                                                               \
-        const int bx = 2 * (kq - krow * pairs) + (int)(key & 3);                                                   \
+        const int bx = par + 4 * (kq - krow * pairs) + 2 * (int)(key & 3);                                         \
         atomicMin(&best64[slot], ((unsigned long long)cost << 32) | ((unsigned long long)(jb.y0 + krow) << 16) |   \
                                      (unsigned long long)bx);                                                      \
       }                                                                                                            \
@@ -480,6 +489,7 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const Re
     ME_FLUSH16(5, b5) ME_FLUSH16(6, b6) ME_FLUSH16(7, b7) ME_FLUSH16(8, b8) ME_FLUSH16(9, b9)
 #undef ME_FLUSH16
   }
+  }   // par
   __syncthreads();
   for (int s = tid; s < kParts; s += kThreads) atomicMin(&g_best[(long)jb.job * kParts + s], best64[s]);
 }

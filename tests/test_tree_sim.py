@@ -100,44 +100,48 @@ INV16, IDX16 = 4000000, G.IDX_BITS16
 
 
 def model_search16(tree, cur, ref, origin, lt, rb, pred, lq, bit_depth, iters_per_task=2):
-    """python model of me_search16_kernel (16-bit samples, 2 candidates per lane, linear lane packing)"""
+    """python model of me_search16_kernel (16-bit samples; two passes, even and odd window columns, the LDS window
+    loaded with a shift of `par` samples; a lane owns candidates (x, x+2); linear lane packing)"""
     sh = bit_depth - 8
     wx, wy = rb[0] - lt[0] + 1, rb[1] - lt[1] + 1
     ox, oy = origin[0] + lt[0], origin[1] + lt[1]
-    pitch = 2 * ((wx + 63 + 2 + 1) // 2) + 2
-    win = np.zeros((wy + 63, pitch), np.uint16)
-    w = ref[oy:oy + wy + 63, ox:ox + min(pitch, ref.shape[1] - ox)]
-    win[:w.shape[0], :w.shape[1]] = w
+    pitch = 2 * ((wx + 63 + 2 + 1) // 2) + 4
     slot_of = tree.slot_of_lane()
     best64 = np.full(593, (1 << 64) - 1, dtype=np.uint64)
     lanes = np.arange(64)
-    P = (wx + 1) // 2
-    iters = (wy * P + 63) // 64
-    for it0 in range(0, iters, iters_per_task):
-        best = np.full((G.N_GROUPS, 64), 0xFFFFFFFF, np.uint32)
-        for it in range(min(iters_per_task, iters - it0)):
-            q = (it0 + it) * 64 + lanes
-            cy, cx = q // P, 2 * (q % P)
-            c = np.zeros((2, 64), np.uint32)
-            for l in range(64):
-                by = cbits(((lt[1] + int(cy[l])) << 2) - pred[1])
-                for j in range(2):
-                    cost = ((lq * (cbits(((lt[0] + int(cx[l]) + j) << 2) - pred[0]) + by)) & 0xFFFFFFFF) >> 16
-                    valid = cy[l] < wy and cx[l] + j < wx
-                    c[j, l] = ((cost if valid else INV16) << IDX16) | (it << 8) | (l << 2) | j
-            lane_off = np.minimum(cy, wy - 1) * pitch + cx
-            G.simulate16(tree, win, cur, lane_off, c, best, sh)
-        for g in range(G.N_GROUPS):
-            for l in range(64):
-                s, key = slot_of[g, l], int(best[g, l])
-                cost = key >> IDX16
-                if s < 0 or cost >= INV16:
-                    continue
-                kit, kl, kj = (key >> 8) & 1, (key >> 2) & 63, key & 3
-                q = (it0 + kit) * 64 + kl
-                v = np.uint64((cost << 32) | ((q // P) << 16) | (2 * (q % P) + kj))
-                if v < best64[s]:
-                    best64[s] = v
+    for par in range(2):
+        win = np.zeros((wy + 63, pitch), np.uint16)
+        w = ref[oy:oy + wy + 63, ox + par:ox + par + min(pitch, ref.shape[1] - ox - par)]
+        win[:w.shape[0], :w.shape[1]] = w
+        n_par = (wx + 1 - par) // 2            # candidates of this column parity per window row
+        P = (n_par + 1) // 2
+        iters = (wy * P + 63) // 64
+        for it0 in range(0, iters, iters_per_task):
+            best = np.full((G.N_GROUPS, 64), 0xFFFFFFFF, np.uint32)
+            for it in range(min(iters_per_task, iters - it0)):
+                q = (it0 + it) * 64 + lanes
+                cy, cx = q // P, par + 4 * (q % P)
+                c = np.zeros((2, 64), np.uint32)
+                for l in range(64):
+                    by = cbits(((lt[1] + int(cy[l])) << 2) - pred[1])
+                    for j in range(2):
+                        x = int(cx[l]) + 2 * j
+                        cost = ((lq * (cbits(((lt[0] + x) << 2) - pred[0]) + by)) & 0xFFFFFFFF) >> 16
+                        valid = cy[l] < wy and x < wx
+                        c[j, l] = ((cost if valid else INV16) << IDX16) | (it << 8) | (l << 2) | j
+                lane_off = np.minimum(cy, wy - 1) * pitch + (cx - par)
+                G.simulate16(tree, win, cur, lane_off, c, best, sh)
+            for g in range(G.N_GROUPS):
+                for l in range(64):
+                    s, key = slot_of[g, l], int(best[g, l])
+                    cost = key >> IDX16
+                    if s < 0 or cost >= INV16:
+                        continue
+                    kit, kl, kj = (key >> 8) & 1, (key >> 2) & 63, key & 3
+                    q = (it0 + kit) * 64 + kl
+                    v = np.uint64((cost << 32) | ((q // P) << 16) | (par + 4 * (q % P) + 2 * kj))
+                    if v < best64[s]:
+                        best64[s] = v
     out = np.zeros((593, 3), np.int64)
     for s in range(593):
         v = int(best64[s])

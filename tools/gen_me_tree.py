@@ -68,7 +68,7 @@ def slot_2Nx2N(s, cx, cy):
     return BASE_2Nx2N[s] + cy * n + cx
 
 
-LOAD_OPS = ("LDS", "CURLD", "BASE", "LDS16", "CURLD16")
+LOAD_OPS = ("LDS", "CURLD", "BASE", "LDS16", "LDS16P", "CURLD16")
 
 
 class Tree:
@@ -336,12 +336,14 @@ class Tree:
 class Tree16(Tree):
     """Reduction tree of the 16-bit sample path (10-bit video; later bi-pred int16 origins).
 
-    A lane owns TWO horizontally adjacent candidates (x even, x+1) and every value is a pair of exact
+    A lane owns TWO candidates of the same column parity (x, x+2) -- the kernel runs the even and the odd columns
+    as two passes over an LDS window loaded with a one-sample shift, so both candidates read dword-aligned
+    samples and nothing is realigned per lane -- and every value is a pair of exact
     32-bit sums: HM applies `>> (bitDepth-8)` to the whole-PU sum *after* the FEN `<< 1`
     (TComRdCost.cpp:520-521), which is a floor and therefore not linear -- no key linearity, no u16
     packing; each slot's key is formed from its own exact sum:
         key_j = ((S_j & MASK_f) << LSH_f) + C_j      (v_and_b32 + v_lshl_add_u32)
-    Leaves are v_sad_u16 (2 samples per op); the odd candidate's dwords come from v_alignbit_b32."""
+    Leaves are v_sad_u16 (2 samples per op)."""
 
     def block16(self, cx8, cy8):
         """-> [(E, A)] for the 4 blocks TL, TR, BL, BR of the CU; E/A are 2-candidate sum pairs"""
@@ -350,17 +352,14 @@ class Tree16(Tree):
         for r in range(8):
             row = cy8 * 8 + r
             d = []
-            for i in range(5):
-                v = self.new("d")
-                self.ops.append(("LDS16", v, row, 4 * cx8 + i))
-                d.append(v)
+            for i in range(0, 6, 2):   # three aligned 64-bit reads (ds_read_b64): dwords 0..5, the last one unused
+                v0, v1 = self.new("d"), self.new("d")
+                self.ops.append(("LDS16P", v0, v1, row, 4 * cx8 + i))
+                d += [v0, v1]
+            d = d[:5]
             w = self.new("w")
             self.ops.append(("CURLD16", w, row, cx8))
-            o = []
-            for i in range(4):
-                v = self.new("o")
-                self.ops.append(("ALIGN16", v, d[i + 1], d[i]))
-                o.append(v)
+            o = d[1:]   # second candidate = two samples to the right: the same row one dword on, no realignment
             rows[r] = (d, o, w)
         for by in range(2):
             for bl in range(2):
@@ -433,9 +432,9 @@ HEADER = """// GENERATED by tools/gen_me_tree.py -- do not edit.  One lane-itera
 
 
 HEADER16 = """// GENERATED by tools/gen_me_tree.py -- do not edit.  One lane-iteration of the 16-bit-sample
-// reduction tree (fen=%d): two candidates (x even, x+1) per lane, exact 32-bit sums, v_sad_u16 leaves.
-// Expects in scope: lpv (per-lane volatile LDS dword pointer at the even candidate, window row 0),
-// ME16_PDW (window pitch in dwords), curv4 (volatile LDS copy of the 64x64 current block, u32x4[64][8]),
+// reduction tree (fen=%d): two candidates (x, x+2) per lane, exact 32-bit sums, v_sad_u16 leaves.
+// Expects in scope: lpq (per-lane volatile LDS pointer to 64-bit words at the first candidate, window row 0),
+// ME16_PDW (window pitch in dwords, even), curv4 (volatile LDS copy of the 64x64 current block, u32x4[64][8]),
 // c0, c1, mask_a/lsh_a/mask_e/lsh_e, b0..b9, rb1, rb0 and the me_merge* helpers.
 """
 
@@ -482,6 +481,9 @@ def emit_cpp(tree, path, header=None):
             o.append(f"b{op[1]} = min(b{op[1]}, {op[2]});")
         elif t == "LDS16":
             o.append(f"const uint32_t {op[1]} = lpv[{op[2]} * ME16_PDW + {op[3]}];")
+        elif t == "LDS16P":   # ME16_PDW and the dword index are even: an 8-byte-aligned ds_read_b64, conflict-free at a lane stride of 2 dwords
+            o.append(f"const uint64_t {op[1]}_q = lpq[({op[3]} * ME16_PDW + {op[4]}) >> 1]; "
+                     f"const uint32_t {op[1]} = (uint32_t){op[1]}_q, {op[2]} = (uint32_t)({op[1]}_q >> 32);")
         elif t == "CURLD16":
             o.append(f"const u32x4_t {op[1]} = curv4[{op[2] * 8 + op[3]}];")
         elif t == "ALIGN16":
@@ -559,9 +561,13 @@ def simulate16(tree, window, cur, lane_off, c, best, sh):
     MAXK = np.full(64, 0xFFFFFFFF, np.uint32)
     for op in tree.ops:
         t = op[0]
-        if t == "LDS16":       # dword k of row = samples 2k, 2k+1 (relative to the lane's even candidate)
+        if t == "LDS16":       # dword k of row = samples 2k, 2k+1 (relative to the lane's first candidate)
             idx = lane_off + op[2] * pitch + 2 * op[3]
             val[op[1]] = np.stack([flat[idx], flat[idx + 1]], axis=1)
+        elif t == "LDS16P":
+            for v, k in ((op[1], op[4]), (op[2], op[4] + 1)):
+                idx = lane_off + op[3] * pitch + 2 * k
+                val[v] = np.stack([flat[idx], flat[idx + 1]], axis=1)
         elif t == "CURLD16":
             val[op[1]] = cur[op[2], op[3] * 8:op[3] * 8 + 8].astype(np.int64).reshape(4, 2)
         elif t == "ALIGN16":   # (hi, lo) >> 16 : samples (lo.hi, hi.lo)
