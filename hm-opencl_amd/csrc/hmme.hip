@@ -57,7 +57,6 @@ struct hmme_ctx {
   int* d_flag = nullptr;
   bool lds_optin[4] = {false, false, false, false};
   uint16_t* d_frac_cover = nullptr;   // fractional refinement: slots covering each 8x8 / 4x4 position, same for every CTU
-  bool frac_optin[2][2] = {{false, false}, {false, false}};
   int16_t* d_imv = nullptr;           // host-facing refine call: integer MVs / quarter-pel MVs / costs on the device
   int16_t* d_qmv = nullptr;
   uint32_t* d_fcost = nullptr;
@@ -725,8 +724,6 @@ int hmme_refine_frame_multi_device(hmme_ctx* ctx, const hmme_plane* cur, const h
     if (refs[r]->pitch != refs[0]->pitch) return fail(ctx, HMME_ERR_ARG, "reference planes differ in pitch");
     set.base[r] = refs[r]->origin();
   }
-  if (fp->search_range > 64)
-    return fail(ctx, HMME_ERR_UNSUPPORTED, "fractional refinement: search range <= 64 only in this build (window must fit the LDS)");
   if (!d_int_mv || !d_out_qmv || !d_out_cost) return fail(ctx, HMME_ERR_ARG, "null buffer");
   if (count == 0) return HMME_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -744,15 +741,9 @@ int hmme_refine_frame_multi_device(hmme_ctx* ctx, const hmme_plane* cur, const h
   const int had = use_hadamard ? 1 : 0, wide = cur->bps == 2 ? 1 : 0;
   using frac_fn = void (*)(const uint8_t*, int, const RefSet, int, const MeJob*, const uint16_t*, const int16_t*, uint32_t, int, int16_t*,
                            uint32_t*);
-  static const frac_fn fns[2][2] = {{hmme::me_frac_kernel<0, 1>, hmme::me_frac_kernel<1, 1>},
-                                    {hmme::me_frac_kernel<0, 2>, hmme::me_frac_kernel<1, 2>}};
-  const frac_fn fn = fns[wide][had];
-  if (!ctx->frac_optin[wide][had]) {
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    ctx->frac_optin[wide][had] = true;
-  }
-  hipLaunchKernelGGL(fn, dim3(jobs), dim3(hmme::frac_threads(wide ? 2 : 1)), hmme::frac_lds_bytes(wide ? 2 : 1), s, cur->origin(), cur->pitch, set,
-                     refs[0]->pitch, (const MeJob*)ctx->d_jobs, ctx->d_frac_cover, (const int16_t*)d_int_mv, ctx->lambda_q16,
+  static const frac_fn fns[2][2] = {{hmme::me_frac_kernel<0, 1>, hmme::me_frac_kernel<1, 1>}, {hmme::me_frac_kernel<0, 2>, hmme::me_frac_kernel<1, 2>}};
+  hipLaunchKernelGGL(fns[wide][had], dim3(jobs), dim3(hmme::frac_threads(wide ? 2 : 1)), hmme::frac_lds_bytes(wide ? 2 : 1), s, cur->origin(),
+                     cur->pitch, set, refs[0]->pitch, (const MeJob*)ctx->d_jobs, ctx->d_frac_cover, (const int16_t*)d_int_mv, ctx->lambda_q16,
                      fp->bit_depth, (int16_t*)d_out_qmv, (uint32_t*)d_out_cost);
   HIP_TRY(ctx, hipGetLastError());
   return HMME_OK;

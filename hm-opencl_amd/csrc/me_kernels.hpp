@@ -576,13 +576,10 @@ __global__ void me_prep_jobs_split_kernel(MeJob16* jobs, int* first_strip_of_job
 // quad_perm DPP butterflies, so slots whose size is a multiple of 8 (8x8 Hadamard blocks) and the others (4x4
 // blocks) run the same code.  Per-slot distortions accumulate in LDS (ds_add_u32); 593 threads then add the MV cost
 // and pick the winner in HM's point order (strict '<', tables TEncSearch.cpp:51-75).
-constexpr int kFracRowsMax = 200;          // window + 4-sample halo: 129 + 63 + 8 = 200 rows of 200 samples
 constexpr int kFracAcc = 593 * 9;
-// BPS = bytes per sample of the planes (1: 8-bit video, 2: 9..12 bit).  Window pitch in dwords (odd), LDS bytes.
-constexpr int frac_pdw(int bps) { return bps == 1 ? 51 : 101; }
-// u16 planes: the window leaves room for one workgroup per CU, so that one has 8 waves (2 per SIMD) instead of 4
-constexpr int frac_threads(int bps) { return bps == 1 ? 256 : 512; }
-constexpr size_t frac_lds_bytes(int bps) { return (size_t)(5344 + 600 + 160 + (64 * 18 + 256 * 6) / 2 + 1024 * bps + kFracRowsMax * frac_pdw(bps)) * 4; }
+// BPS = bytes per sample of the planes (1: 8-bit video, 2: 9..12 bit)
+constexpr int frac_threads(int bps) { return 256; }
+constexpr size_t frac_lds_bytes(int bps) { return (size_t)(5344 + 600 + 160 + (64 * 18 + 256 * 6) / 2 + 1024 * bps) * 4; }
 
 __device__ __forceinline__ uint32_t me_mv_cost_q(uint32_t lambda_q16, int vx_q, int vy_q, int pred_x, int pred_y) {
   return (lambda_q16 * (me_component_bits(vx_q - pred_x) + me_component_bits(vy_q - pred_y))) >> 16;
@@ -782,29 +779,39 @@ __device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3 * BPS], c
 // those -- one lane per 4x4 block, a quad of lanes per 8x8 block -- and adds the result to every slot that shares it.
 // `cover`: uint16 [64][18] then [256][6] slot ids, ascending (built by the host from the slot table).
 constexpr int kFracCover8 = 18, kFracCover4 = 6, kFracPairs8 = 64 * kFracCover8, kFracPairs4 = 256 * kFracCover4;
+// slot state word: (mx - lt_x) | (my - lt_y) << 9 | (half_x + 1) << 18 | (half_y + 1) << 20; the sharing key of a stage
+constexpr uint32_t kFracKey0 = 0x3ffffu, kFracKey1 = 0x3fffffu;
 
+// `src`: window sample (-4,-4) of this CTU in the reference plane, `gpitch` bytes per row.  The 12x12 patch comes straight
+// from global memory: the windows of neighbouring CTUs overlap and stay in L2, and an LDS copy of the window (tried first)
+// was no faster while it capped the search range at 64 and the occupancy at one 16-bit workgroup per CU.
 template <int STAGE, int HAD, int BPS, int KIND8>
-__device__ __forceinline__ void me_frac_item(const uint32_t* win, const uint32_t* curl, const uint32_t* st, const uint16_t* __restrict__ cover,
-                                             int pair, int role, int bd, const uint32_t* tab_h, const float* tab_v, uint32_t* acc) {
-  constexpr int PDW = frac_pdw(BPS), PW = 3 * BPS, NCOV = KIND8 ? kFracCover8 : kFracCover4;
-  constexpr uint32_t keymask = STAGE ? 0xfffffu : 0xffffu;
+__device__ __forceinline__ void me_frac_item(const uint8_t* __restrict__ src, int gpitch, const uint32_t* curl, const uint32_t* st,
+                                             const uint16_t* __restrict__ cover, int pair, int role, int bd, const uint32_t* tab_h,
+                                             const float* tab_v, uint32_t* acc) {
+  constexpr int PW = 3 * BPS, NCOV = KIND8 ? kFracCover8 : kFracCover4;
+  constexpr uint32_t keymask = STAGE ? kFracKey1 : kFracKey0;
   const int q = KIND8 ? pair : pair - kFracPairs8;
   const int pos = q / NCOV, j = q - pos * NCOV;
   const uint16_t* cov = cover + (KIND8 ? 0 : kFracPairs8) + pos * NCOV;
   const uint32_t sv = st[cov[j]];
   const int bx = KIND8 ? 2 * (pos & 7) + (role & 1) : (pos & 15), by = KIND8 ? 2 * (pos >> 3) + (role >> 1) : (pos >> 4);
   // patch (0,0) = block sample (-4,-4) = window row (by*4 + my - lt_y), sample (bx*4 + mx - lt_x) (halo offsets cancel)
-  const int prow = by * 4 + (int)((sv >> 8) & 0xff), pcol = (bx * 4 + (int)(sv & 0xff)) * BPS;   // pcol in bytes
-  const uint32_t* rowp = win + prow * PDW + (pcol >> 2);
-  const uint32_t o = (uint32_t)pcol & 3u;
+  const int prow = by * 4 + (int)((sv >> 9) & 0x1ff), pcol = (bx * 4 + (int)(sv & 0x1ff)) * BPS;   // pcol in bytes
   uint32_t P[12][PW];
+  {
+    const uint8_t* a = src + (long)prow * gpitch + pcol;
+    const uint32_t o = (uint32_t)(uintptr_t)a & 3u;
+    const uint32_t* __restrict__ rowp = (const uint32_t*)(a - o);
+    const int gp = gpitch >> 2;
 #pragma unroll
-  for (int r = 0; r < 12; ++r) {
-    uint32_t w[PW + 1];
+    for (int r = 0; r < 12; ++r) {
+      uint32_t w[PW + 1];
 #pragma unroll
-    for (int k = 0; k <= PW; ++k) w[k] = rowp[r * PDW + k];
+      for (int k = 0; k <= PW; ++k) w[k] = rowp[r * gp + k];
 #pragma unroll
-    for (int k = 0; k < PW; ++k) P[r][k] = __builtin_amdgcn_alignbyte(w[k + 1], w[k], o);
+      for (int k = 0; k < PW; ++k) P[r][k] = __builtin_amdgcn_alignbyte(w[k + 1], w[k], o) ^ (BPS == 1 ? 0x80808080u : 0u);
+    }
   }
   float orgM[16];   // current samples + kRoundMagic (exact: integers below 2^24)
 #pragma unroll
@@ -820,7 +827,7 @@ __device__ __forceinline__ void me_frac_item(const uint32_t* win, const uint32_t
     }
   }
   uint32_t dist[9];
-  const int cqx = STAGE ? 2 * ((int)((sv >> 16) & 3) - 1) : 0, cqy = STAGE ? 2 * ((int)((sv >> 18) & 3) - 1) : 0;
+  const int cqx = STAGE ? 2 * ((int)((sv >> 18) & 3) - 1) : 0, cqy = STAGE ? 2 * ((int)((sv >> 20) & 3) - 1) : 0;
   me_frac_eval<STAGE, HAD, BPS, KIND8>(P, orgM, cqx, cqy, role, bd, tab_h, tab_v, dist);
   // every slot of this position with the same key takes the distortions; the quad's lanes split the slot list
   for (int j2 = j + (KIND8 ? role : 0); j2 < NCOV; j2 += KIND8 ? 4 : 1) {
@@ -850,21 +857,20 @@ __device__ __forceinline__ void me_frac_dedupe(const uint32_t* st, const uint16_
 }
 
 template <int HAD, int BPS>
-__global__ void __launch_bounds__(frac_threads(BPS), BPS == 1 ? 2 : 1)
+__global__ void __launch_bounds__(frac_threads(BPS), 2)
 me_frac_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet refs, int ref_pitch,
                const MeJob* __restrict__ jobs, const uint16_t* __restrict__ cover, const int16_t* __restrict__ int_mv,
                uint32_t lambda_q16, int bit_depth, int16_t* __restrict__ out_qmv, uint32_t* __restrict__ out_cost) {
-  constexpr int PDW = frac_pdw(BPS), NT = frac_threads(BPS);
+  constexpr int NT = frac_threads(BPS);
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t* acc = smem;                 // [593][9] distortion sums of the current stage
-  uint32_t* st = smem + 5344;           // [593] slot state: (mx - lt_x) | (my - lt_y) << 8 | (half_x + 1) << 16 | (half_y + 1) << 18
+  uint32_t* st = smem + 5344;           // [593] slot state: (mx - lt_x) | (my - lt_y) << 9 | (half_x + 1) << 18 | (half_y + 1) << 20
   uint32_t* tab_h = st + 600;           // [7][kFracTabH] packed horizontal taps of q = -3..3
   float* tab_v = (float*)(tab_h + 7 * kFracTabH);   // [7][kFracTabV] vertical taps
   uint32_t* counter = tab_h + 152;      // [2] lengths of the two work lists
   uint16_t* list8 = (uint16_t*)(tab_h + 160);                  // distinct (8x8 position, key) pairs
   uint16_t* list4 = (uint16_t*)(tab_h + 160 + kFracPairs8 / 2);   // distinct (4x4 position, key) pairs
   uint32_t* curl = tab_h + 160 + (kFracPairs8 + kFracPairs4) / 2;   // 64 x 64 current block
-  uint32_t* win = curl + 1024 * BPS;    // reference window with a 4-sample halo, pitch PDW dwords (8-bit samples XOR 0x80)
 
   const int tid = threadIdx.x;
   MeJob job = jobs[blockIdx.x];
@@ -878,7 +884,7 @@ me_frac_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet
   // integer MVs outside the CTU's window (not produced by the search) are clamped to it: the patch stays inside the LDS window
   for (int s = tid; s < kParts; s += NT) {
     const int mx = min(max((int)mvs[2 * s], job.lt_x), job.rb_x), my = min(max((int)mvs[2 * s + 1], job.lt_y), job.rb_y);
-    st[s] = (uint32_t)(mx - job.lt_x) | (uint32_t)(my - job.lt_y) << 8 | 1u << 16 | 1u << 18;
+    st[s] = (uint32_t)(mx - job.lt_x) | (uint32_t)(my - job.lt_y) << 9 | 1u << 18 | 1u << 20;
   }
   if (tid < 7 * kFracTabH) tab_h[tid] = (tid & 7) < 3 * BPS ? me_htap_dw<BPS>((tid >> 3) - 3, 0, tid & 7) : 0u;
   if (tid >= 64 && tid < 64 + 7 * kFracTabV) {
@@ -890,23 +896,12 @@ me_frac_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet
     const int r = i / (4 * BPS), q = i - r * (4 * BPS);
     *(uint4*)&curl[r * 16 * BPS + 4 * q] = *(const uint4*)(cur_base + (long)(job.ctu_y + r) * cur_pitch + job.ctu_x * BPS + 16 * q);
   }
-  {
-    const uint8_t* src = ref_base + (long)(job.ctu_y + job.lt_y - 4) * ref_pitch + (job.ctu_x + job.lt_x - 4) * BPS;
-    const uint32_t mis = (uint32_t)(uintptr_t)src & 3u;
-    const uint32_t* src_al = (const uint32_t*)(src - mis);
-    const int pitch_dw = ref_pitch >> 2;
-    const int n = (wy + 63 + 8) * PDW;
-    for (int i = tid; i < n; i += NT) {
-      const int r = i / PDW, k = i - r * PDW;
-      const uint32_t lo = src_al[(long)r * pitch_dw + k], hi = src_al[(long)r * pitch_dw + k + 1];
-      win[i] = __builtin_amdgcn_alignbyte(hi, lo, mis) ^ (BPS == 1 ? 0x80808080u : 0u);
-    }
-  }
+  const uint8_t* src = ref_base + (long)(job.ctu_y + job.lt_y - 4) * ref_pitch + (job.ctu_x + job.lt_x - 4) * BPS;   // window sample (-4,-4)
   __syncthreads();
 
 #pragma unroll 1
   for (int stage = 0; stage < 2; ++stage) {
-    const uint32_t keymask = stage ? 0xfffffu : 0xffffu;
+    const uint32_t keymask = stage ? kFracKey1 : kFracKey0;
     for (int t = tid; t < 64 + 256; t += NT) {
       if (t < 64) me_frac_dedupe<kFracCover8>(st, cover + t * kFracCover8, keymask, t * kFracCover8, &counter[0], list8);
       else me_frac_dedupe<kFracCover4>(st, cover + kFracPairs8 + (t - 64) * kFracCover4, keymask, kFracPairs8 + (t - 64) * kFracCover4, &counter[1], list4);
@@ -915,19 +910,19 @@ me_frac_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet
     const int n8 = 4 * (int)counter[0], n4 = (int)counter[1];
 #pragma unroll 1
     for (int i = tid; i < n8; i += NT) {   // whole quads: n8 and NT are multiples of 4
-      if (stage == 0) me_frac_item<0, HAD, BPS, 1>(win, curl, st, cover, list8[i >> 2], tid & 3, bd, tab_h, tab_v, acc);
-      else me_frac_item<1, HAD, BPS, 1>(win, curl, st, cover, list8[i >> 2], tid & 3, bd, tab_h, tab_v, acc);
+      if (stage == 0) me_frac_item<0, HAD, BPS, 1>(src, ref_pitch, curl, st, cover, list8[i >> 2], tid & 3, bd, tab_h, tab_v, acc);
+      else me_frac_item<1, HAD, BPS, 1>(src, ref_pitch, curl, st, cover, list8[i >> 2], tid & 3, bd, tab_h, tab_v, acc);
     }
 #pragma unroll 1
     for (int i = tid; i < n4; i += NT) {
-      if (stage == 0) me_frac_item<0, HAD, BPS, 0>(win, curl, st, cover, list4[i], 0, bd, tab_h, tab_v, acc);
-      else me_frac_item<1, HAD, BPS, 0>(win, curl, st, cover, list4[i], 0, bd, tab_h, tab_v, acc);
+      if (stage == 0) me_frac_item<0, HAD, BPS, 0>(src, ref_pitch, curl, st, cover, list4[i], 0, bd, tab_h, tab_v, acc);
+      else me_frac_item<1, HAD, BPS, 0>(src, ref_pitch, curl, st, cover, list4[i], 0, bd, tab_h, tab_v, acc);
     }
     __syncthreads();
     for (int s = tid; s < kParts; s += NT) {
       const uint32_t sv = st[s];
-      const int mx = (int)(sv & 0xff) + job.lt_x, my = (int)((sv >> 8) & 0xff) + job.lt_y;
-      const int hx = stage ? (int)((sv >> 16) & 3) - 1 : 0, hy = stage ? (int)((sv >> 18) & 3) - 1 : 0;
+      const int mx = (int)(sv & 0x1ff) + job.lt_x, my = (int)((sv >> 9) & 0x1ff) + job.lt_y;
+      const int hx = stage ? (int)((sv >> 18) & 3) - 1 : 0, hy = stage ? (int)((sv >> 20) & 3) - 1 : 0;
       const int bxq = 4 * mx + 2 * hx, byq = 4 * my + 2 * hy;   // centre of this stage in quarter units
       constexpr int ph[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};
       constexpr int pq[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {1, 1}};
@@ -941,7 +936,7 @@ me_frac_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet
         if (d < best) { best = d; bi = i; }
       }
       if (stage == 0) {
-        st[s] = (sv & 0xffffu) | (uint32_t)(ph[bi][0] + 1) << 16 | (uint32_t)(ph[bi][1] + 1) << 18;
+        st[s] = (sv & kFracKey0) | (uint32_t)(ph[bi][0] + 1) << 18 | (uint32_t)(ph[bi][1] + 1) << 20;
       } else {
         const long o = (long)blockIdx.x * kParts + s;
         out_qmv[2 * o] = (int16_t)(bxq + pq[bi][0]);

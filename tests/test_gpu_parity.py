@@ -449,7 +449,8 @@ def test_device_resident_producer_and_async_api(engine, oracle_lib):
 
 
 @pytest.mark.parametrize("use_had,sr,use_pred,bd", [(1, 16, True, 8), (0, 16, True, 8), (1, 64, False, 8), (1, 16, True, 10),
-                                                      (0, 64, False, 12), (1, 24, True, 9), (1, 17, True, -8), (0, 33, False, -10)])
+                                                      (0, 64, False, 12), (1, 24, True, 9), (1, 17, True, -8), (0, 33, False, -10),
+                                                      (1, 128, False, 10), (0, 96, True, 12), (1, 70, True, -10)])
 def test_fractional_refinement_vs_oracle(engine, oracle_lib, use_had, sr, use_pred, bd):
     """the step after the path: xPatternSearchFracDIF for all 593 slots of every CTU (half + quarter-pel, HM's
     8-tap interpolation, Hadamard or SAD), fed with the engine's own integer MVs"""
@@ -537,8 +538,7 @@ def test_tiny_and_sliver_pictures(engine, oracle_lib, w, h, sr, bd):
     with engine.plane(w, h, bd) as pc, engine.plane(w, h, bd) as pr:
         pc.upload_pel(cur, (m, m)); pr.upload_pel(ref, (m, m))
         mv, sad = engine.search_frame(pc, pr, sr, pred)
-        if sr <= 64:
-            qmv, _ = engine.refine_frame(pc, pr, sr, mv, pred)
-            assert np.abs(qmv.astype(np.int32) - 4 * mv.astype(np.int32)).max() <= 3
+        qmv, _ = engine.refine_frame(pc, pr, sr, mv, pred)
+        assert np.abs(qmv.astype(np.int32) - 4 * mv.astype(np.int32)).max() <= 3
     ox, oy, osad = oracle_lib.search_frame(cur, ref, (m, m), w, h, sr, pred, engine.lambda_q16, 1, bd, n_threads=4)
     assert np.array_equal(mv[:, :, 0], ox) and np.array_equal(mv[:, :, 1], oy) and np.array_equal(sad, osad)

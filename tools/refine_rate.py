@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "hm-opencl_amd"))
 import torch
 from hmme import api, synth
-w, h, sr = 3840, 2160, 64
+w, h, sr = 3840, 2160, int(os.environ.get("SR", "64"))
 if len(sys.argv) > 1: w, h = (int(v) for v in sys.argv[1].split("x"))
 bd = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 cur, ref, _ = synth.make_pair(w, h, seed=1234, bit_depth=bd)
@@ -16,7 +16,7 @@ if content == "noise":   # unrelated pictures: nearly every slot has its own int
     cur = np.ascontiguousarray(np.pad(rng.integers(0, 1 << bd, size=(h, w)), synth.MARGIN, mode="edge").astype(cur.dtype))
     ref = np.ascontiguousarray(np.pad(rng.integers(0, 1 << bd, size=(h, w)), synth.MARGIN, mode="edge").astype(ref.dtype))
 m = synth.MARGIN
-eng = api.Engine(0, 64); eng.set_lambda(57.9)
+eng = api.Engine(0, 128); eng.set_lambda(57.9)
 pc, pr = eng.plane(w, h, bd), eng.plane(w, h, bd)
 pc.upload_pel(cur, (m, m)); pr.upload_pel(ref, (m, m))
 n = api.load().hmme_num_ctus(w, h)
