@@ -151,7 +151,7 @@ int hmme_search_frame_multi_device(hmme_ctx* ctx, const hmme_plane* cur, const h
  * refinement around the slot's integer MV with HM's 8-tap interpolation, Hadamard (HadamardME = 1, xGetHADs) or SAD
  * distortion plus the MV cost.  int_mv: int16[n_refs][count][593][2] as produced by hmme_search_frame*.
  * out_qmv: quarter-pel MV (int << 2) + (half << 1) + quarter; out_cost: distortion + MV cost of the winner (the
- * ruiCost xPatternSearchFracDIF returns).  8..12-bit planes; search range <= 64 in this build.  Integer MVs outside
+ * ruiCost xPatternSearchFracDIF returns).  8..12-bit planes, any search range the search accepts.  Integer MVs outside
  * the CTU's search window (never produced by hmme_search_frame*) are clamped to it first. */
 int hmme_refine_frame(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp,
                       const int16_t* pred_q, const int16_t* int_mv, int use_hadamard, int16_t* out_qmv, uint32_t* out_cost);
