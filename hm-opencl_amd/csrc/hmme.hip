@@ -212,9 +212,8 @@ int check_frame_args(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref
   if (fp->bit_depth < 8 || fp->bit_depth > 12) return fail(ctx, HMME_ERR_UNSUPPORTED, "bit depth %d outside 8..12", fp->bit_depth);
   if (cur->bit_depth != fp->bit_depth || ref->bit_depth != fp->bit_depth)
     return fail(ctx, HMME_ERR_ARG, "planes hold %d/%d-bit samples, search asks for %d", cur->bit_depth, ref->bit_depth, fp->bit_depth);
-  const int sr_cap = fp->bit_depth == 8 ? (ctx->sr_max < 64 ? ctx->sr_max : 64) : ctx->sr_max;
-  if (fp->search_range < 1 || fp->search_range > sr_cap)
-    return fail(ctx, HMME_ERR_ARG, "search range %d outside [1, %d] (8-bit path: 64, 16-bit path: 128)", fp->search_range, sr_cap);
+  if (fp->search_range < 1 || fp->search_range > ctx->sr_max)
+    return fail(ctx, HMME_ERR_ARG, "search range %d outside [1, %d]", fp->search_range, ctx->sr_max);
   const int n = hmme_num_ctus(cur->width, cur->height);
   *first = fp->ctu_first;
   *count = fp->ctu_count < 0 ? n - fp->ctu_first : fp->ctu_count;
@@ -578,6 +577,8 @@ static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_para
     if (f > (nt + 3) / 4) f = (nt + 3) / 4;
     *n_strips = f < 1 ? 1 : f;
   }
+  const bool tile8 = !wide && fp->search_range > 64;   // window beyond 129 x 129: four tile searches per CTU, merged like split tasks
+  if (tile8) *n_strips = 4;
   const bool split8 = !wide && *n_strips > 1;
   size_t cap = ctx->jobs_bytes;
   int rc = ensure(ctx, (uint8_t**)&ctx->d_jobs, &cap, (wide || split8) ? sizeof(MeJob16) * (size_t)jobs * *n_strips : sizeof(MeJob) * (size_t)jobs);
@@ -590,7 +591,10 @@ static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_para
     if (rc) return rc;
   }
   const dim3 grid((jobs + 255) / 256), block(256);
-  if (split8)
+  if (tile8)
+    hipLaunchKernelGGL(hmme::me_prep_jobs_tile_kernel, grid, block, 0, s, (MeJob16*)ctx->d_jobs, ctx->d_first_strip,
+                       (const int16_t*)d_pred_q, first, count, n_refs, cur->width, cur->height, fp->search_range);
+  else if (split8)
     hipLaunchKernelGGL(hmme::me_prep_jobs_split_kernel, grid, block, 0, s, (MeJob16*)ctx->d_jobs, ctx->d_first_strip,
                        (const int16_t*)d_pred_q, first, count, n_refs, cur->width, cur->height, fp->search_range, *n_strips);
   else if (!wide)

@@ -157,6 +157,9 @@ static_assert(sizeof(MeJob16) == 24, "MeJob16 layout");
 
 
 // ---- the search kernel --------------------------------------------------------------------------
+// windows wider or taller than 129 candidates (8-bit planes, search range 65..128) are cut into up to 2 x 2 tiles of at most
+// 129 x 129: MeJob16::job carries the tile's (x, y) index in bits 30 and 29 above the output job index
+constexpr int kTileStep = 129, kTileJobMask = 0x1fffffff;
 // SPLIT = 0: one workgroup searches the whole window of jobs[blockIdx.x] (MeJob) and writes its 593 results.
 // SPLIT = 1: jobs are MeJob16; the workgroup runs tasks [y0, y1) only and merges into g_best with 64-bit atomicMin
 //            (decoded afterwards by me_finalize16_kernel) -- used where one CTU must fill many CUs.
@@ -174,9 +177,11 @@ me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefS
   const int lane = tid & 63;
   MeJob job;
   int t_first = 0, t_end = 0x7fffffff, out_job = blockIdx.x;
+  unsigned long long tile_off = 0;   // SPLIT, tiled windows: (y, x) of this tile's first candidate in the CTU's whole window
   if constexpr (SPLIT) {
     const MeJob16 jb = ((const MeJob16*)jobs_v)[blockIdx.x];
-    job = jb.j; t_first = jb.y0; t_end = jb.y1; out_job = jb.job;
+    job = jb.j; t_first = jb.y0; t_end = jb.y1; out_job = jb.job & kTileJobMask;
+    tile_off = (unsigned long long)(((jb.job >> 29) & 1) * kTileStep) << 16 | (unsigned long long)(((jb.job >> 30) & 1) * kTileStep);
   } else {
     job = ((const MeJob*)jobs_v)[blockIdx.x];
   }
@@ -291,7 +296,10 @@ me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefS
   // -- 4. results: integer MV (TComMv layout) and the pure SAD at the arg-min (ruiSAD, reference
   //       TEncSearch.cpp:3895: best - getCost(best))
   if constexpr (SPLIT) {
-    for (int s = tid; s < kParts; s += kThreads) atomicMin(&g_best[(long)out_job * kParts + s], best64[s]);
+    for (int s = tid; s < kParts; s += kThreads) {
+      const unsigned long long v = best64[s];
+      if (v != ~0ull) atomicMin(&g_best[(long)out_job * kParts + s], v + tile_off);
+    }
     return;
   }
   for (int s = tid; s < kParts; s += kThreads) {
@@ -563,6 +571,36 @@ __global__ void me_prep_jobs_split_kernel(MeJob16* jobs, int* first_strip_of_job
     js.y1 = (int16_t)((long)nt * (s + 1) / n_split);
     js.job = i;
     jobs[i * n_split + s] = js;
+  }
+}
+
+// 8-bit planes, search range 65..128: four tile jobs per (CTU, reference), each a complete search of its sub-window through the
+// SPLIT kernel; tile (0,0) comes first and keeps the window's own top-left, which me_finalize16_kernel decodes against
+__global__ void me_prep_jobs_tile_kernel(MeJob16* jobs, int* first_strip_of_job, const int16_t* __restrict__ pred_q,
+                                         int ctu_first, int ctu_count, int n_refs, int pic_w, int pic_h, int sr) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ctu_count * n_refs) return;
+  const int r = i / ctu_count;
+  const int ctus_x = (pic_w + 63) >> 6, n_ctu = ctus_x * ((pic_h + 63) >> 6);
+  const int ctu = ctu_first + (i - r * ctu_count);
+  const int cu_x = (ctu % ctus_x) * 64, cu_y = (ctu / ctus_x) * 64;
+  const long pq = 2 * ((long)r * n_ctu + ctu);
+  const int px = pred_q ? pred_q[pq] : 0, py = pred_q ? pred_q[pq + 1] : 0;
+  int ltx, lty, rbx, rby;
+  set_search_range(px, py, sr, cu_x, cu_y, pic_w, pic_h, ltx, lty, rbx, rby);
+  first_strip_of_job[i] = i * 4;
+  for (int t = 0; t < 4; ++t) {
+    const int tx = t & 1, ty = t >> 1;
+    const int x0 = ltx + tx * kTileStep, y0 = lty + ty * kTileStep;
+    const bool empty = x0 > rbx || y0 > rby;
+    MeJob16 js;
+    js.j.ctu_x = (int16_t)(cu_x | r); js.j.ctu_y = (int16_t)cu_y;
+    js.j.lt_x = (int16_t)(empty ? ltx : x0); js.j.lt_y = (int16_t)(empty ? lty : y0);
+    js.j.rb_x = (int16_t)min(rbx, js.j.lt_x + kTileStep - 1); js.j.rb_y = (int16_t)min(rby, js.j.lt_y + kTileStep - 1);
+    js.j.pred_x = (int16_t)px; js.j.pred_y = (int16_t)py;
+    js.y0 = 0; js.y1 = empty ? 0 : 0x7fff;   // task range: everything, or nothing for a tile the clipped window does not reach
+    js.job = i | tx << 30 | ty << 29;
+    jobs[i * 4 + t] = js;
   }
 }
 

@@ -45,7 +45,8 @@ extern "C" {
 
 #define HMME_NUM_CTU_PARTS 593 /* TLibCommon/TypeDef.h:263 */
 #define HMME_CTU_SIZE 64
-#define HMME_MAX_SEARCH_RANGE 128 /* 8-bit path: SR <= 64 (window 129^2); 16-bit path (bit depth 9..12): SR <= 128 */
+#define HMME_MAX_SEARCH_RANGE 128 /* frame calls: any bit depth (8-bit windows beyond 129^2 run as 2x2 tiles); hmme_search_ctu: 8-bit
+                                      windows up to 129^2, 16-bit ones up to 257^2 */
 
 enum {
   HMME_OK = 0,

@@ -281,7 +281,7 @@ def test_plane_bit_depth_mismatch_is_an_error(engine):
     with pytest.raises(api.HmmeError, match="bit"):
         engine.search_frame(p8, p10, 8)
     with pytest.raises(api.HmmeError, match="search range"):
-        engine.search_frame(p8, p8, 100)          # SR > 64 needs the 16-bit path
+        engine.search_frame(p8, p8, 129)          # beyond HMME_MAX_SEARCH_RANGE
     p8.close(); p10.close()
 
 
@@ -520,7 +520,7 @@ def test_refinement_multi_reference_and_errors(engine):
         assert np.array_equal(d_q[r].cpu().numpy(), q1) and np.array_equal(d_c[r].cpu().numpy().astype(np.uint32), c1)
         assert np.abs(q1.astype(np.int32) - 4 * mv[r].astype(np.int32)).max() <= 3
     with pytest.raises(api.HmmeError, match="search range"):
-        engine.refine_frame(pc, refs[0], 65, np.zeros((n, 593, 2), np.int16))
+        engine.refine_frame(pc, refs[0], 129, np.zeros((n, 593, 2), np.int16))
     for pl in planes:
         pl.close()
 
@@ -542,3 +542,31 @@ def test_tiny_and_sliver_pictures(engine, oracle_lib, w, h, sr, bd):
         assert np.abs(qmv.astype(np.int32) - 4 * mv.astype(np.int32)).max() <= 3
     ox, oy, osad = oracle_lib.search_frame(cur, ref, (m, m), w, h, sr, pred, engine.lambda_q16, 1, bd, n_threads=4)
     assert np.array_equal(mv[:, :, 0], ox) and np.array_equal(mv[:, :, 1], oy) and np.array_equal(sad, osad)
+
+
+@pytest.mark.parametrize("sr,fen,use_pred", [(65, 1, True), (100, 1, False), (128, 0, True)])
+def test_8bit_search_range_beyond_64_tiles(engine, oracle_lib, sr, fen, use_pred):
+    """8-bit planes with a window beyond 129 x 129 candidates: four tile searches per CTU merged in raster order"""
+    from hmme import api, synth
+    w, h = 328, 200                                   # 6 x 4 CTUs, partial right column and bottom row; windows clipped at every border
+    cur, ref, _ = synth.make_pair(w, h, seed=900 + sr, max_mv=40, region=64, noise_sigma=3.0)
+    m = synth.MARGIN
+    n = api.load().hmme_num_ctus(w, h)
+    pred = synth.random_predictors(n, seed=sr, max_pel=30) if use_pred else None
+    engine.set_lambda(57.9)
+    with engine.plane(w, h) as pc, engine.plane(w, h) as pr:
+        pc.upload_pel(cur, (m, m)); pr.upload_pel(ref, (m, m))
+        mv, sad = engine.search_frame(pc, pr, sr, pred, fen=fen)
+        qmv, cost = engine.refine_frame(pc, pr, sr, mv, pred)
+    ox, oy, osad = oracle_lib.search_frame(cur, ref, (m, m), w, h, sr, pred, engine.lambda_q16, fen, 8, n_threads=8)
+    assert np.array_equal(mv[:, :, 0], ox) and np.array_equal(mv[:, :, 1], oy) and np.array_equal(sad, osad)
+    assert np.abs(qmv.astype(np.int32) - 4 * mv.astype(np.int32)).max() <= 3
+    table = oracle_lib.slot_table()
+    for ctu, s in [(0, 592), (7, 300), (n - 1, 0), (9, 566)]:
+        cx, cy = (ctu % 6) * 64, (ctu // 6) * 64
+        x, y, bw, bh = (int(v) for v in table[s])
+        imv = (int(mv[ctu, s, 0]), int(mv[ctu, s, 1]))
+        p = (int(pred[ctu, 0]), int(pred[ctu, 1])) if use_pred else (0, 0)
+        hx, hy, qx, qy, c = oracle_lib.frac_refine(cur, (m + cx + x, m + cy + y), ref, (m + cx + x, m + cy + y), bw, bh, imv, p,
+                                                    engine.lambda_q16, 1, 8)
+        assert (int(qmv[ctu, s, 0]), int(qmv[ctu, s, 1]), int(cost[ctu, s])) == (4 * imv[0] + 2 * hx + qx, 4 * imv[1] + 2 * hy + qy, c)
