@@ -429,7 +429,7 @@ int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
     return fail(ctx, HMME_ERR_RANGE, "hmme_search_ctu: current-block sample outside [%d, %d] (bit depth %d)", -maxv, 2 * maxv, p->bit_depth);
   const bool wide = p->bit_depth > 8 || bipred_origin;
   const int bias = bipred_origin ? (1 << p->bit_depth) : 0;
-  const int sr_cap = wide ? ctx->sr_max : (ctx->sr_max < 64 ? ctx->sr_max : 64);
+  const int sr_cap = ctx->sr_max;
   if (wx < 1 || wy < 1 || wx > 2 * sr_cap + 1 || wy > 2 * sr_cap + 1)
     return fail(ctx, HMME_ERR_ARG, "window %dx%d outside 1..%d", wx, wy, 2 * sr_cap + 1);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -469,14 +469,24 @@ int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
   if (!wide) {
     // one CTU alone would keep 1 of 256 CUs busy for ~17 lane-iterations per wave: deal its tasks to many workgroups
     // (4 tasks each = one per wave) and merge through the 64-bit atomicMin table
-    const int nt = hmme::me_num_tasks(wx, wy);
-    int n_split = (nt + 3) / 4;
-    if (n_split > 64) n_split = 64;
+    // windows beyond 129 x 129 candidates: up to 2 x 2 tiles (tile (0,0) first: finalize decodes against its top-left)
+    const int tiles_x = (wx + hmme::kTileStep - 1) / hmme::kTileStep, tiles_y = (wy + hmme::kTileStep - 1) / hmme::kTileStep;
+    const int per_tile = 64 / (tiles_x * tiles_y);
     MeJob16 js[64];
-    for (int i = 0; i < n_split; ++i) {
-      js[i].j = job; js[i].job = 0;
-      js[i].y0 = (int16_t)((long)nt * i / n_split); js[i].y1 = (int16_t)((long)nt * (i + 1) / n_split);
-    }
+    int n_split = 0;
+    for (int ty = 0; ty < tiles_y; ++ty)
+      for (int tx = 0; tx < tiles_x; ++tx) {
+        MeJob sub = job;
+        sub.lt_x = (int16_t)(job.lt_x + tx * hmme::kTileStep); sub.lt_y = (int16_t)(job.lt_y + ty * hmme::kTileStep);
+        sub.rb_x = (int16_t)std::min<int>(job.rb_x, sub.lt_x + hmme::kTileStep - 1);
+        sub.rb_y = (int16_t)std::min<int>(job.rb_y, sub.lt_y + hmme::kTileStep - 1);
+        const int nt = hmme::me_num_tasks(sub.rb_x - sub.lt_x + 1, sub.rb_y - sub.lt_y + 1);
+        const int parts = std::max(1, std::min(per_tile, (nt + 3) / 4));
+        for (int i = 0; i < parts; ++i, ++n_split) {
+          js[n_split].j = sub; js[n_split].job = 0 | tx << 30 | ty << 29;
+          js[n_split].y0 = (int16_t)((long)nt * i / parts); js[n_split].y1 = (int16_t)((long)nt * (i + 1) / parts);
+        }
+      }
     const int zero = 0;
     size_t cap = (size_t)ctx->first_strip_cap * sizeof(int);
     rc = ensure(ctx, &ctx->d_first_strip, &cap, sizeof(int) * 16);

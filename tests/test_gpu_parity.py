@@ -142,15 +142,18 @@ def test_error_behaviour(engine):
     cur = np.zeros((64, 64), np.int16)
     ref = np.zeros((100, 100), np.int16)
     engine.set_lambda(1.0)
-    bad = api.SearchParams(-70, -8, 70, 8, 0, 0, 1, 8)           # window wider than sr_max
+    bad = api.SearchParams(-129, -8, 129, 8, 0, 0, 1, 8)         # window wider than 2 * sr_max + 1
     with pytest.raises(api.HmmeError, match="window"):
-        engine.search_ctu(cur, (0, 0), ref, (18, 18), bad)
+        engine.search_ctu(cur, (0, 0), np.zeros((100, 400), np.int16), (140, 18), bad)
+    with api.Engine(0, 32) as small:                             # an engine created for a smaller range enforces it
+        with pytest.raises(api.HmmeError, match="window"):
+            small.search_ctu(cur, (0, 0), np.zeros((100, 200), np.int16), (50, 18), api.SearchParams(-40, -8, 40, 8, 0, 0, 1, 8))
     p14 = api.SearchParams(-8, -8, 8, 8, 0, 0, 1, 14)
     with pytest.raises(api.HmmeError, match="bit depth"):
         engine.search_ctu(cur, (0, 0), ref, (18, 18), p14)
-    wide8 = api.SearchParams(-100, -8, 100, 8, 0, 0, 1, 8)          # SR > 64 exists on the 16-bit path only
+    wide8 = api.SearchParams(-130, -8, 130, 8, 0, 0, 1, 8)          # beyond HMME_MAX_SEARCH_RANGE
     with pytest.raises(api.HmmeError, match="window"):
-        engine.search_ctu(cur, (0, 0), np.zeros((100, 300), np.int16), (118, 18), wide8)
+        engine.search_ctu(cur, (0, 0), np.zeros((100, 400), np.int16), (148, 18), wide8)
     cur2 = cur.copy(); cur2[5, 5] = 999                             # beyond even a bi-pred origin (2*255)
     p = api.SearchParams(-8, -8, 8, 8, 0, 0, 1, 8)
     with pytest.raises(api.HmmeError, match="outside"):
@@ -570,3 +573,25 @@ def test_8bit_search_range_beyond_64_tiles(engine, oracle_lib, sr, fen, use_pred
         hx, hy, qx, qy, c = oracle_lib.frac_refine(cur, (m + cx + x, m + cy + y), ref, (m + cx + x, m + cy + y), bw, bh, imv, p,
                                                     engine.lambda_q16, 1, 8)
         assert (int(qmv[ctu, s, 0]), int(qmv[ctu, s, 1]), int(cost[ctu, s])) == (4 * imv[0] + 2 * hx + qx, 4 * imv[1] + 2 * hy + qy, c)
+
+
+def test_search_ctu_8bit_windows_beyond_129(engine, oracle_lib):
+    """per-CTU call with an 8-bit window wider / taller than 129 candidates (2 x 1, 1 x 2 and 2 x 2 tiles)"""
+    from hmme import api
+    rng = np.random.default_rng(11)
+    for (lt, rb) in [((-100, -20), (90, 30)), ((-10, -128), (12, 128)), ((-128, -128), (128, 128)), ((-64, -64), (65, 64))]:
+        wx, wy = rb[0] - lt[0] + 1, rb[1] - lt[1] + 1
+        ref = rng.integers(0, 256, size=(wy + 63 + 8, wx + 63 + 8)).astype(np.int16)
+        o = (4 - lt[0], 4 - lt[1])
+        dx, dy = int(rng.integers(lt[0], rb[0] + 1)), int(rng.integers(lt[1], rb[1] + 1))
+        cur = ref[o[1] + dy:o[1] + dy + 64, o[0] + dx:o[0] + dx + 64].copy()
+        cur[::7, ::5] ^= 3
+        pred = (int(rng.integers(-200, 201)), int(rng.integers(-200, 201)))
+        fen = int(rng.integers(0, 2))
+        engine.set_lambda(57.9)
+        p = api.SearchParams(lt[0], lt[1], rb[0], rb[1], pred[0], pred[1], fen, 8)
+        mv, sad = engine.search_ctu(cur, (0, 0), ref, o, p)
+        op = oracle_lib.make_params(lt, rb, pred, engine.lambda_q16, fen, 8)
+        ox, oy, osad = oracle_lib.search_ctu(cur, (0, 0), ref, o, op)
+        assert np.array_equal(mv[:, 0], ox) and np.array_equal(mv[:, 1], oy) and np.array_equal(sad, osad), (lt, rb)
+        assert tuple(mv[592]) == (dx, dy)
