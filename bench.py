@@ -111,8 +111,20 @@ def cpu_baseline(cur, ref, w, h, sr, lq, bd=8, budget_s=14.0):
         probes += p_; s4 += s_; passes += 1
     dt_tz = time.time() - t0
     n_tz *= passes
+    # the same exhaustive search on one core (SURVEY 8d asks for both figures)
+    n_one = max(4, min(64, int(n_full / max(dt_full, 1e-3) / cores * 1.5)))
+    t0 = time.time(); O.search_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, bd, first, n_one, 1); dt_one = time.time() - t0
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
     return {
         "value": round(sads_full / dt_full / 1e9, 4), "unit": "GSAD/s", "cores": cores, "kind": "port",
+        "host": {"cpu": model, "logical_cpus": os.cpu_count(), "usable_by_this_process": usable_cores()},
+        "one_core": {"value": round(n_one * 256 * (2 * sr + 1) ** 2 / dt_one / 1e9, 4), "unit": "GSAD/s", "ctus_per_s": round(n_one / dt_one, 2),
+                     "sample": f"{n_one} CTUs, 1 thread, {dt_one:.2f} s"},
         "sample": f"oracle exhaustive search (xPatternSearch restatement, all 593 PUs) of {n_full} interior CTUs of the "
                   f"same frame pair, {cores} threads, {dt_full:.2f} s",
         "ctus_per_s": round(n_full / dt_full, 2),
@@ -262,6 +274,13 @@ def main():
             out["valu_roofline"] = {"bound": "valu-issue", "valu_busy_frac": round(prof["valu_busy_frac"], 4),
                                     "valu_wave_instructions_per_launch": int(prof["valu_wave_instructions_per_launch"]),
                                     "effective_clock_ghz": round(prof.get("effective_clock_ghz", 0.0), 3),
+                                    # every candidate touches each of the CTU's 4096 samples once (FEN halves nothing in the kernel:
+                                    # the even-row sums are the first half of the full sums)
+                                    "abs_diff_per_s": round(sads * 16 / (kernel_ms * 1e-3), 0),
+                                    "frac_of_nominal_sad_u8_peak": round(sads * 16 / (kernel_ms * 1e-3) / 314.6e12, 4),
+                                    "nominal_peak_note": "314.6e12 abs-diff/s = SURVEY 8d's paper figure (v_sad_u8 at 2 cycles per wave-instruction); "
+                                                         "measured issue rates are 4.3 cycles (v_sad_u8) / 16 cycles per 16 abs-diffs (v_qsad_pk_u16_u8), "
+                                                         "i.e. a SAD-only ceiling of 0.25 of that figure (DESIGN.md 5)",
                                     "source": "profiles/latest_pmc_%s_sr%d.json (rocprofv3 --pmc passes of this command)" % (args.size, sr)}
         if sr <= 64:   # the step after the path, reported beside the headline, never part of `value`
             d_q = torch.zeros((n_refs, n_ctu, api.NUM_PARTS, 2), dtype=torch.int16, device=dev)
@@ -278,7 +297,7 @@ def main():
             out["refine"] = {"what": "xPatternSearchFracDIF (half + quarter-pel, Hadamard) for all 593 slots of every CTU, on the integer winners",
                              "kernel": "me_frac_kernel<1, %d>" % (1 if bd == 8 else 2), "ms_per_step": round(r_ms, 4),
                              "slots_per_s": round(n_ctu * n_refs * api.NUM_PARTS / (r_ms * 1e-3))}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only: the other ranks would wait on it
             out["cpu_baseline"] = cpu_baseline(cur, ref, w, h, sr, lq, bd)
         print(json.dumps(out), flush=True)
     pc.close()
