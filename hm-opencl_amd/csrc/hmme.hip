@@ -42,7 +42,7 @@ struct hmme_ctx {
   uint32_t* h_sad = nullptr;
   int16_t* d_mv1 = nullptr;
   uint32_t* d_sad1 = nullptr;
-  MeJob* d_job1 = nullptr;
+  MeJob16* d_job1 = nullptr;         // up to 64 task-range / strip / tile jobs of one CTU
   // frame path scratch (grown on demand)
   void* d_jobs = nullptr;         // MeJob[] or MeJob16[]
   size_t jobs_bytes = 0;
@@ -495,7 +495,7 @@ int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_first_strip, &zero, sizeof zero, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_job1, js, sizeof(MeJob16) * n_split, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));   // js / zero live on this stack frame
-    rc = launch_search8_split(ctx, ctx->d_ctu, 64, one_ref(ref_base), kWinPitch, (const MeJob16*)ctx->d_job1, ctx->d_first_strip, 1, n_split,
+    rc = launch_search8_split(ctx, ctx->d_ctu, 64, one_ref(ref_base), kWinPitch, ctx->d_job1, ctx->d_first_strip, 1, n_split,
                               p->fen, ctx->d_mv1, ctx->d_sad1, s);
   } else {
     const int pdw = (wx <= 129 && wy <= 129) ? kPdw16Small : kPdw16Large;
@@ -516,7 +516,7 @@ int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_first_strip, &zero, sizeof zero, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_job1, js, sizeof(MeJob16) * n_strips, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));   // js / zero live on this stack frame
-    rc = launch_search16(ctx, ctx->d_ctu, 128, one_ref(ref_base), kWinPitch, (const MeJob16*)ctx->d_job1, ctx->d_first_strip, 1, n_strips, pdw,
+    rc = launch_search16(ctx, ctx->d_ctu, 128, one_ref(ref_base), kWinPitch, ctx->d_job1, ctx->d_first_strip, 1, n_strips, pdw,
                          smax, p->fen, p->bit_depth, ctx->d_mv1, ctx->d_sad1, s);
   }
   if (rc) return rc;
