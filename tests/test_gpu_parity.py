@@ -595,3 +595,50 @@ def test_search_ctu_8bit_windows_beyond_129(engine, oracle_lib):
         ox, oy, osad = oracle_lib.search_ctu(cur, (0, 0), ref, o, op)
         assert np.array_equal(mv[:, 0], ox) and np.array_equal(mv[:, 1], oy) and np.array_equal(sad, osad), (lt, rb)
         assert tuple(mv[592]) == (dx, dy)
+
+
+def _fuzz_case(engine, oracle_lib, seed):
+    from hmme import api, synth
+    rng = np.random.default_rng(seed)
+    w, h = 8 * int(rng.integers(1, 26)), 8 * int(rng.integers(1, 18))
+    bd = int(rng.choice([8, 8, 10, 12, 9]))
+    sr = int(rng.choice([1, 2, 3, 7, 16, 31, 64, 65, 90, 128]))
+    fen = int(rng.integers(0, 2))
+    n = api.load().hmme_num_ctus(w, h)
+    if n * (2 * sr + 1) ** 2 > 6 * 129 * 129:     # keep the oracle's share of the run in seconds
+        sr = 16
+    max_pel = int(rng.choice([0, 4, 40, 300]))    # far predictors: windows clipped to slivers at the picture border
+    pred = synth.random_predictors(n, seed=seed, max_pel=max_pel) if max_pel else None
+    cur, ref, _ = synth.make_pair(w, h, seed=seed, bit_depth=bd, max_mv=min(sr, 10), region=32, noise_sigma=float(rng.choice([0.0, 2.0])))
+    lam = float(rng.choice([0.0, 3.3, 57.9, 4000.0]))
+    engine.set_lambda(lam)
+    m = synth.MARGIN
+    with engine.plane(w, h, bd) as pc, engine.plane(w, h, bd) as pr:
+        pc.upload_pel(cur, (m, m)); pr.upload_pel(ref, (m, m))
+        mv, sad = engine.search_frame(pc, pr, sr, pred, fen=fen)
+        use_had = int(rng.integers(0, 2))
+        qmv, cost = engine.refine_frame(pc, pr, sr, mv, pred, use_hadamard=bool(use_had))
+    ox, oy, osad = oracle_lib.search_frame(cur, ref, (m, m), w, h, sr, pred, engine.lambda_q16, fen, bd, n_threads=8)
+    tag = dict(seed=seed, w=w, h=h, bd=bd, sr=sr, fen=fen, max_pel=max_pel, lam=lam)
+    assert np.array_equal(mv[:, :, 0], ox) and np.array_equal(mv[:, :, 1], oy) and np.array_equal(sad, osad), tag
+    table = oracle_lib.slot_table()
+    ctus_x = (w + 63) // 64
+    for k in range(12):
+        ctu, s = int(rng.integers(0, n)), int(rng.integers(0, 593))
+        cx, cy = (ctu % ctus_x) * 64, (ctu // ctus_x) * 64
+        x, y, bw, bh = (int(v) for v in table[s])
+        imv = (int(mv[ctu, s, 0]), int(mv[ctu, s, 1]))
+        p = (int(pred[ctu, 0]), int(pred[ctu, 1])) if pred is not None else (0, 0)
+        hx, hy, qx, qy, c = oracle_lib.frac_refine(cur, (m + cx + x, m + cy + y), ref, (m + cx + x, m + cy + y), bw, bh, imv, p,
+                                                    engine.lambda_q16, use_had, bd)
+        got = (int(qmv[ctu, s, 0]), int(qmv[ctu, s, 1]), int(cost[ctu, s]))
+        assert got == (4 * imv[0] + 2 * hx + qx, 4 * imv[1] + 2 * hy + qy, c), (tag, ctu, s, use_had)
+
+
+def test_fuzz_frames_vs_oracle(engine, oracle_lib):
+    """random picture sizes (multiples of the 8-sample minimum CU), bit depths, search ranges 1..128, FEN, lambdas and
+    predictors up to 300 pel away: integer search of every CTU and spot-checked refinement against the oracle"""
+    n = int(os.environ.get("HMME_FUZZ_CASES", "14"))
+    base = int(os.environ.get("HMME_FUZZ_SEED", "1000"))
+    for i in range(n):
+        _fuzz_case(engine, oracle_lib, base + i)
