@@ -642,3 +642,41 @@ def test_fuzz_frames_vs_oracle(engine, oracle_lib):
     base = int(os.environ.get("HMME_FUZZ_SEED", "1000"))
     for i in range(n):
         _fuzz_case(engine, oracle_lib, base + i)
+
+
+def test_fuzz_search_ctu_vs_oracle(engine, oracle_lib):
+    """per-CTU call: random windows up to 257 x 257 (ragged, clipped, one candidate wide), every bit depth, FEN, lambdas,
+    predictors, plain and bi-prediction origins (2*org - pred, outside the sample range)"""
+    from hmme import api
+    n = int(os.environ.get("HMME_FUZZ_CTU", "30"))
+    rng = np.random.default_rng(int(os.environ.get("HMME_FUZZ_SEED", "1000")))
+    for it in range(n):
+        bd = int(rng.choice([8, 8, 9, 10, 12]))
+        maxv = (1 << bd) - 1
+        sr = int(rng.choice([1, 4, 4, 9, 33, 64, 100, 128]))
+        lt = (-int(rng.integers(0, sr + 1)), -int(rng.integers(0, sr + 1)))
+        rb = (int(rng.integers(0, sr + 1)), int(rng.integers(0, sr + 1)))
+        if it % 7 == 0:
+            lt, rb = (-sr, -sr), (sr, sr)
+        wx, wy = rb[0] - lt[0] + 1, rb[1] - lt[1] + 1
+        ref = rng.integers(0, maxv + 1, size=(wy + 63 + 6, wx + 63 + 6)).astype(np.int16)
+        o = (3 - lt[0], 3 - lt[1])
+        dx, dy = int(rng.integers(lt[0], rb[0] + 1)), int(rng.integers(lt[1], rb[1] + 1))
+        cur = ref[o[1] + dy:o[1] + dy + 64, o[0] + dx:o[0] + dx + 64].astype(np.int32)
+        cur = cur + rng.integers(-3, 4, size=cur.shape)
+        if it % 3 == 0:   # bi-prediction origin: 2 * org - other prediction, unclipped
+            other = rng.integers(0, maxv + 1, size=cur.shape)
+            cur = np.clip(2 * np.clip(cur, 0, maxv) - other, -maxv, 2 * maxv)
+        else:
+            cur = np.clip(cur, 0, maxv)
+        cur = cur.astype(np.int16)
+        pred = (int(rng.integers(-500, 501)), int(rng.integers(-500, 501)))
+        fen = int(rng.integers(0, 2))
+        lam = float(rng.choice([0.0, 4.7, 57.9, 2000.0]))
+        engine.set_lambda(lam)
+        p = api.SearchParams(lt[0], lt[1], rb[0], rb[1], pred[0], pred[1], fen, bd)
+        mv, sad = engine.search_ctu(cur, (0, 0), ref, o, p)
+        op = oracle_lib.make_params(lt, rb, pred, engine.lambda_q16, fen, bd)
+        ox, oy, osad = oracle_lib.search_ctu(cur, (0, 0), ref, o, op)
+        tag = dict(it=it, bd=bd, lt=lt, rb=rb, pred=pred, fen=fen, lam=lam)
+        assert np.array_equal(mv[:, 0], ox) and np.array_equal(mv[:, 1], oy) and np.array_equal(sad, osad), tag
