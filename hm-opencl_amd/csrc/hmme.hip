@@ -22,6 +22,12 @@ constexpr int kMarginX = 128;  // samples; >= 72 needed by clipMv's bounds (+3 f
 constexpr int kMarginY = 80;   // TComPicYuv: maxCUHeight + 16 (reference TComPicYuv.cpp:91-92)
 constexpr int kWinPitch = 1024;  // per-CTU path: bytes per packed window row (>= 2 * (257 + 63) + 8)
 constexpr int kWinRows = 2 * 128 + 1 + 63;
+// per-CTU call block: up to 64 MeJob16, the job's first strip (always 0), the 593-entry 64-bit merge table (all ones),
+// the 64 x 64 current block (1 or 2 bytes per sample), the packed window
+constexpr size_t kCallJobs = 0, kCallFirst = 1536, kCallBest = 2048, kCallCtu = 7168, kCallWin = 15360;
+constexpr int kCallMaxJobs = 64;
+static_assert(sizeof(MeJob16) * kCallMaxJobs <= kCallFirst && kCallBest + 8 * HMME_NUM_CTU_PARTS <= kCallCtu && kCallCtu + 64 * 64 * 2 <= kCallWin,
+              "per-CTU call block layout");
 constexpr size_t kLdsBudget16 = 78 * 1024;   // per workgroup of the 16-bit path -> 2 workgroups per CU
 constexpr int kPdw16Small = 98, kPdw16Large = 162;   // 16-bit window pitch in dwords for SR <= 64 / SR <= 128 (even: rows stay 8-byte aligned for ds_read_b64)
 std::string g_create_error;
@@ -34,15 +40,14 @@ struct hmme_ctx {
   std::string err;
   std::string info;
   hipStream_t stream = nullptr;   // private stream of the synchronous entry points
-  // per-CTU path scratch
-  uint8_t* d_ctu = nullptr;       // 64 x 64 samples (1 or 2 bytes each)
-  uint8_t* d_win = nullptr;       // window copy, pitch kWinPitch
-  uint8_t* h_stage = nullptr;     // pinned: ctu + window
-  int16_t* h_mv = nullptr;        // pinned results
-  uint32_t* h_sad = nullptr;
-  int16_t* d_mv1 = nullptr;
-  uint32_t* d_sad1 = nullptr;
-  MeJob16* d_job1 = nullptr;         // up to 64 task-range / strip / tile jobs of one CTU
+  // per-CTU path: one device block and its pinned host mirror -- jobs, first-strip index, merge table preset, current
+  // block, window -- so that a call is one upload, the kernels, one download (layout: kCall* offsets below)
+  uint8_t* d_call = nullptr;
+  uint8_t* h_call = nullptr;
+  uint8_t* h_call_dev = nullptr;  // device-side address of h_call (mapped pinned memory)
+  uint8_t* h_res = nullptr;       // 593 MVs (int16 x, y), 593 SADs, then the completion word: pinned host memory the finalize kernel writes
+  uint8_t* d_res = nullptr;       // ... and its device-side address
+  uint32_t call_seq = 0;
   // frame path scratch (grown on demand)
   void* d_jobs = nullptr;         // MeJob[] or MeJob16[]
   size_t jobs_bytes = 0;
@@ -125,27 +130,37 @@ int launch_search8(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const RefSe
   return HMME_OK;
 }
 
-int finalize_best(hmme_ctx* ctx, const MeJob16* d_jobs, const int* d_first_strip, int n_jobs, int16_t* d_mv, uint32_t* d_sad,
-                  hipStream_t stream);
+int finalize_best(hmme_ctx* ctx, const unsigned long long* d_best, const MeJob16* d_jobs, const int* d_first_strip, int n_jobs, int16_t* d_mv,
+                  uint32_t* d_sad, hipStream_t stream);
 
 // 8-bit split mode: n_jobs * n_split workgroups, each runs a slice of its CTU's tasks and merges through ctx->d_best
-int launch_search8_split(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const RefSet& ref, int ref_pitch, const MeJob16* d_jobs,
-                         const int* d_first_strip, int n_jobs, int n_split, int fen, int16_t* d_mv, uint32_t* d_sad,
-                         hipStream_t stream) {
-  if (n_jobs <= 0) return HMME_OK;
+// the 64-bit merge table of a split / strip / tile launch: the caller's (already all ones), or ctx->d_best grown and preset here
+int merge_table(hmme_ctx* ctx, int n_jobs, unsigned long long* preset, hipStream_t stream, unsigned long long** table) {
+  if (preset) { *table = preset; return HMME_OK; }
   size_t cap = ctx->best_cap;
   int rc = ensure(ctx, &ctx->d_best, &cap, sizeof(unsigned long long) * HMME_NUM_CTU_PARTS * (size_t)n_jobs);
   ctx->best_cap = cap;
   if (rc) return rc;
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_best, 0xFF, sizeof(unsigned long long) * HMME_NUM_CTU_PARTS * (size_t)n_jobs, stream));
+  *table = ctx->d_best;
+  return HMME_OK;
+}
+
+int launch_search8_split(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const RefSet& ref, int ref_pitch, const MeJob16* d_jobs,
+                         const int* d_first_strip, int n_jobs, int n_split, int fen, int16_t* d_mv, uint32_t* d_sad,
+                         hipStream_t stream, unsigned long long* preset_best = nullptr, bool finalize = true) {
+  if (n_jobs <= 0) return HMME_OK;
+  unsigned long long* best = nullptr;
+  int rc = merge_table(ctx, n_jobs, preset_best, stream, &best);
+  if (rc) return rc;
   if (fen)
     hipLaunchKernelGGL((hmme::me_search_kernel<1, 1>), dim3(n_jobs * n_split), dim3(hmme::kThreads), 0, stream, cur, cur_pitch,
-                       ref, ref_pitch, (const void*)d_jobs, ctx->lambda_q16, (int16_t*)nullptr, (uint32_t*)nullptr, ctx->d_best);
+                       ref, ref_pitch, (const void*)d_jobs, ctx->lambda_q16, (int16_t*)nullptr, (uint32_t*)nullptr, best);
   else
     hipLaunchKernelGGL((hmme::me_search_kernel<0, 1>), dim3(n_jobs * n_split), dim3(hmme::kThreads), 0, stream, cur, cur_pitch,
-                       ref, ref_pitch, (const void*)d_jobs, ctx->lambda_q16, (int16_t*)nullptr, (uint32_t*)nullptr, ctx->d_best);
+                       ref, ref_pitch, (const void*)d_jobs, ctx->lambda_q16, (int16_t*)nullptr, (uint32_t*)nullptr, best);
   HIP_TRY(ctx, hipGetLastError());
-  return finalize_best(ctx, d_jobs, d_first_strip, n_jobs, d_mv, d_sad, stream);
+  return finalize ? finalize_best(ctx, best, d_jobs, d_first_strip, n_jobs, d_mv, d_sad, stream) : HMME_OK;
 }
 
 // ---- 16-bit path -------------------------------------------------------------------------------------
@@ -176,29 +191,27 @@ int launch16_t(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const RefSet& r
 // d_jobs: n_jobs * n_strips MeJob16; results merged in ctx->d_best then decoded into d_mv / d_sad
 int launch_search16(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const RefSet& ref, int ref_pitch, const MeJob16* d_jobs,
                     const int* d_first_strip, int n_jobs, int n_strips, int pdw, int strip_rows_max, int fen, int bit_depth,
-                    int16_t* d_mv, uint32_t* d_sad, hipStream_t stream) {
+                    int16_t* d_mv, uint32_t* d_sad, hipStream_t stream, unsigned long long* preset_best = nullptr, bool finalize = true) {
   if (n_jobs <= 0) return HMME_OK;
-  size_t cap = ctx->best_cap;
-  int rc = ensure(ctx, &ctx->d_best, &cap, sizeof(unsigned long long) * HMME_NUM_CTU_PARTS * (size_t)n_jobs);
-  ctx->best_cap = cap;
+  unsigned long long* best = nullptr;
+  int rc = merge_table(ctx, n_jobs, preset_best, stream, &best);
   if (rc) return rc;
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_best, 0xFF, sizeof(unsigned long long) * HMME_NUM_CTU_PARTS * (size_t)n_jobs, stream));
   const size_t lds = lds_bytes16(pdw, strip_rows_max);
   const int sh = bit_depth - 8, n_wg = n_jobs * n_strips;
   if (pdw == kPdw16Small)
-    rc = fen ? launch16_t<1, kPdw16Small>(ctx, cur, cur_pitch, ref, ref_pitch, d_jobs, n_wg, lds, sh, ctx->d_best, stream)
-             : launch16_t<0, kPdw16Small>(ctx, cur, cur_pitch, ref, ref_pitch, d_jobs, n_wg, lds, sh, ctx->d_best, stream);
+    rc = fen ? launch16_t<1, kPdw16Small>(ctx, cur, cur_pitch, ref, ref_pitch, d_jobs, n_wg, lds, sh, best, stream)
+             : launch16_t<0, kPdw16Small>(ctx, cur, cur_pitch, ref, ref_pitch, d_jobs, n_wg, lds, sh, best, stream);
   else
-    rc = fen ? launch16_t<1, kPdw16Large>(ctx, cur, cur_pitch, ref, ref_pitch, d_jobs, n_wg, lds, sh, ctx->d_best, stream)
-             : launch16_t<0, kPdw16Large>(ctx, cur, cur_pitch, ref, ref_pitch, d_jobs, n_wg, lds, sh, ctx->d_best, stream);
+    rc = fen ? launch16_t<1, kPdw16Large>(ctx, cur, cur_pitch, ref, ref_pitch, d_jobs, n_wg, lds, sh, best, stream)
+             : launch16_t<0, kPdw16Large>(ctx, cur, cur_pitch, ref, ref_pitch, d_jobs, n_wg, lds, sh, best, stream);
   if (rc) return rc;
-  return finalize_best(ctx, d_jobs, d_first_strip, n_jobs, d_mv, d_sad, stream);
+  return finalize ? finalize_best(ctx, best, d_jobs, d_first_strip, n_jobs, d_mv, d_sad, stream) : HMME_OK;
 }
 
-int finalize_best(hmme_ctx* ctx, const MeJob16* d_jobs, const int* d_first_strip, int n_jobs, int16_t* d_mv, uint32_t* d_sad,
-                  hipStream_t stream) {
+int finalize_best(hmme_ctx* ctx, const unsigned long long* d_best, const MeJob16* d_jobs, const int* d_first_strip, int n_jobs, int16_t* d_mv,
+                  uint32_t* d_sad, hipStream_t stream) {
   const long total = (long)n_jobs * HMME_NUM_CTU_PARTS;
-  hipLaunchKernelGGL(hmme::me_finalize16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, ctx->d_best, d_jobs,
+  hipLaunchKernelGGL(hmme::me_finalize16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d_best, d_jobs,
                      d_first_strip, n_jobs, ctx->lambda_q16, d_mv, d_sad);
   HIP_TRY(ctx, hipGetLastError());
   return HMME_OK;
@@ -293,14 +306,14 @@ int hmme_create(int device, int sr_max, unsigned flags, hmme_ctx** out) {
     if (e_ != hipSuccess) { int rc = fail(nullptr, HMME_ERR_NOMEM, "hmme_create: %s -> %s", #call, hipGetErrorString(e_)); hmme_destroy(ctx); return rc; } \
   } while (0)
   CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-  CREATE_TRY(hipMalloc(&ctx->d_ctu, 64 * 64 * 2));
-  CREATE_TRY(hipMalloc(&ctx->d_win, win_bytes));
-  CREATE_TRY(hipHostMalloc(&ctx->h_stage, 64 * 64 * 2 + win_bytes));
-  CREATE_TRY(hipHostMalloc(&ctx->h_mv, sizeof(int16_t) * 2 * HMME_NUM_CTU_PARTS));
-  CREATE_TRY(hipHostMalloc(&ctx->h_sad, sizeof(uint32_t) * HMME_NUM_CTU_PARTS));
-  CREATE_TRY(hipMalloc(&ctx->d_mv1, sizeof(int16_t) * 2 * HMME_NUM_CTU_PARTS));
-  CREATE_TRY(hipMalloc(&ctx->d_sad1, sizeof(uint32_t) * HMME_NUM_CTU_PARTS));
-  CREATE_TRY(hipMalloc(&ctx->d_job1, sizeof(MeJob16) * 64));
+  CREATE_TRY(hipMalloc(&ctx->d_call, kCallWin + win_bytes));
+  CREATE_TRY(hipHostMalloc(&ctx->h_call, kCallWin + win_bytes, hipHostMallocMapped));
+  CREATE_TRY(hipHostGetDevicePointer((void**)&ctx->h_call_dev, ctx->h_call, 0));
+  std::memset(ctx->h_call, 0, kCallWin);
+  std::memset(ctx->h_call + kCallBest, 0xFF, 8 * HMME_NUM_CTU_PARTS);
+  CREATE_TRY(hipHostMalloc(&ctx->h_res, 8 * HMME_NUM_CTU_PARTS + 64, hipHostMallocMapped));
+  std::memset(ctx->h_res, 0, 8 * HMME_NUM_CTU_PARTS + 64);
+  CREATE_TRY(hipHostGetDevicePointer((void**)&ctx->d_res, ctx->h_res, 0));
   CREATE_TRY(hipMalloc(&ctx->d_flag, sizeof(int)));
   CREATE_TRY(hipMemset(ctx->d_flag, 0, sizeof(int)));
 #undef CREATE_TRY
@@ -312,13 +325,12 @@ void hmme_destroy(hmme_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   if (ctx->stream) { hipStreamSynchronize(ctx->stream); hipStreamDestroy(ctx->stream); }
-  hipFree(ctx->d_ctu); hipFree(ctx->d_win); hipFree(ctx->d_mv1); hipFree(ctx->d_sad1); hipFree(ctx->d_job1);
+  hipFree(ctx->d_call);
   hipFree(ctx->d_jobs); hipFree(ctx->d_first_strip); hipFree(ctx->d_best);
   hipFree(ctx->d_pred); hipFree(ctx->d_mv); hipFree(ctx->d_sad); hipFree(ctx->d_flag);
   hipFree(ctx->d_frac_cover); hipFree(ctx->d_imv); hipFree(ctx->d_qmv); hipFree(ctx->d_fcost);
-  if (ctx->h_stage) hipHostFree(ctx->h_stage);
-  if (ctx->h_mv) hipHostFree(ctx->h_mv);
-  if (ctx->h_sad) hipHostFree(ctx->h_sad);
+  if (ctx->h_call) hipHostFree(ctx->h_call);
+  if (ctx->h_res) hipHostFree(ctx->h_res);
   delete ctx;
 }
 
@@ -436,11 +448,11 @@ int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
   // pack CTU and window in pinned memory (the reference copies the same window with a scalar CPU loop,
   // TEncOpenCL.cpp:275-277); 1 byte per sample on the 8-bit path, 2 otherwise
   const int bps = wide ? 2 : 1;
-  uint8_t* h_ctu = ctx->h_stage;
-  uint8_t* h_win = ctx->h_stage + 64 * 64 * 2;
+  uint8_t* h_ctu = ctx->h_call + kCallCtu;
+  uint8_t* h_win = ctx->h_call + kCallWin;
   const int rows = wy + 63, cols = wx + 63;
   const int16_t* src = ref0 + (long)p->lt_y * ref_stride + p->lt_x;
-  bool bad = false;
+  int vlo = 0, vhi = 0;
   for (int y = 0; y < 64; ++y)
     for (int x = 0; x < 64; ++x) {
       const int v = ctu[y * ctu_stride + x] + bias;
@@ -448,32 +460,28 @@ int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
     }
   for (int y = 0; y < rows; ++y) {
     uint8_t* row = h_win + (size_t)y * kWinPitch;
-    for (int x = 0; x < cols; ++x) {
-      const int v = src[(long)y * ref_stride + x];
-      bad |= v < 0 || v > maxv;
-      if (wide) ((uint16_t*)row)[x] = (uint16_t)(v + bias); else row[x] = (uint8_t)v;
+    const int16_t* srow = src + (long)y * ref_stride;
+    if (wide) {
+      for (int x = 0; x < cols; ++x) { const int v = srow[x]; vlo = v < vlo ? v : vlo; vhi = v > vhi ? v : vhi; ((uint16_t*)row)[x] = (uint16_t)(v + bias); }
+    } else {
+      for (int x = 0; x < cols; ++x) { const int v = srow[x]; vlo = v < vlo ? v : vlo; vhi = v > vhi ? v : vhi; row[x] = (uint8_t)v; }
     }
-    std::memset(row + cols * bps, 0, kWinPitch - cols * bps);
+    std::memset(row + cols * bps, 0, 16);   // the kernels stage whole dwords past the last sample
   }
-  if (bad) return fail(ctx, HMME_ERR_RANGE, "hmme_search_ctu: reference sample outside [0,%d] for bit depth %d", maxv, p->bit_depth);
+  if (vlo < 0 || vhi > maxv) return fail(ctx, HMME_ERR_RANGE, "hmme_search_ctu: reference sample outside [0,%d] for bit depth %d", maxv, p->bit_depth);
   MeJob job;
   job.ctu_x = 0; job.ctu_y = 0;
   job.lt_x = (int16_t)p->lt_x; job.lt_y = (int16_t)p->lt_y; job.rb_x = (int16_t)p->rb_x; job.rb_y = (int16_t)p->rb_y;
   job.pred_x = (int16_t)p->pred_x; job.pred_y = (int16_t)p->pred_y;
   hipStream_t s = ctx->stream;
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ctu, h_ctu, 64 * 64 * bps, hipMemcpyHostToDevice, s));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_win, h_win, (size_t)rows * kWinPitch + 64, hipMemcpyHostToDevice, s));
-  // the kernel addresses ref(ctu + lt): bias the base so that (lt_x, lt_y) lands on the window copy's first sample
-  const uint8_t* ref_base = ctx->d_win - (long)p->lt_y * kWinPitch - (long)p->lt_x * bps;
-  int rc;
+  // one CTU alone would keep a few of the 256 CUs busy: its work is dealt to up to 64 workgroups (task ranges and window tiles on
+  // the 8-bit path, strips of candidate rows on the 16-bit path) that merge through the 64-bit atomicMin table
+  MeJob16* js = (MeJob16*)(ctx->h_call + kCallJobs);
+  int n_wg = 0, pdw = 0, smax = 0;
   if (!wide) {
-    // one CTU alone would keep 1 of 256 CUs busy for ~17 lane-iterations per wave: deal its tasks to many workgroups
-    // (4 tasks each = one per wave) and merge through the 64-bit atomicMin table
     // windows beyond 129 x 129 candidates: up to 2 x 2 tiles (tile (0,0) first: finalize decodes against its top-left)
     const int tiles_x = (wx + hmme::kTileStep - 1) / hmme::kTileStep, tiles_y = (wy + hmme::kTileStep - 1) / hmme::kTileStep;
-    const int per_tile = 64 / (tiles_x * tiles_y);
-    MeJob16 js[64];
-    int n_split = 0;
+    const int per_tile = kCallMaxJobs / (tiles_x * tiles_y);
     for (int ty = 0; ty < tiles_y; ++ty)
       for (int tx = 0; tx < tiles_x; ++tx) {
         MeJob sub = job;
@@ -481,50 +489,57 @@ int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
         sub.rb_x = (int16_t)std::min<int>(job.rb_x, sub.lt_x + hmme::kTileStep - 1);
         sub.rb_y = (int16_t)std::min<int>(job.rb_y, sub.lt_y + hmme::kTileStep - 1);
         const int nt = hmme::me_num_tasks(sub.rb_x - sub.lt_x + 1, sub.rb_y - sub.lt_y + 1);
-        const int parts = std::max(1, std::min(per_tile, (nt + 3) / 4));
-        for (int i = 0; i < parts; ++i, ++n_split) {
-          js[n_split].j = sub; js[n_split].job = 0 | tx << 30 | ty << 29;
-          js[n_split].y0 = (int16_t)((long)nt * i / parts); js[n_split].y1 = (int16_t)((long)nt * (i + 1) / parts);
+        const int parts = std::max(1, std::min(per_tile, (nt + 3) / 4));   // 4 tasks = one per wave
+        for (int i = 0; i < parts; ++i, ++n_wg) {
+          js[n_wg].j = sub; js[n_wg].job = 0 | tx << 30 | ty << 29;
+          js[n_wg].y0 = (int16_t)((long)nt * i / parts); js[n_wg].y1 = (int16_t)((long)nt * (i + 1) / parts);
         }
       }
-    const int zero = 0;
-    size_t cap = (size_t)ctx->first_strip_cap * sizeof(int);
-    rc = ensure(ctx, &ctx->d_first_strip, &cap, sizeof(int) * 16);
-    ctx->first_strip_cap = (int)(cap / sizeof(int));
-    if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_first_strip, &zero, sizeof zero, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_job1, js, sizeof(MeJob16) * n_split, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));   // js / zero live on this stack frame
-    rc = launch_search8_split(ctx, ctx->d_ctu, 64, one_ref(ref_base), kWinPitch, ctx->d_job1, ctx->d_first_strip, 1, n_split,
-                              p->fen, ctx->d_mv1, ctx->d_sad1, s);
   } else {
-    const int pdw = (wx <= 129 && wy <= 129) ? kPdw16Small : kPdw16Large;
-    const int n_strips = strips_for(pdw, wy);
-    if (n_strips > 16) return fail(ctx, HMME_ERR_UNSUPPORTED, "window needs %d strips", n_strips);
-    MeJob16 js[16];
-    int smax = 0;
-    for (int i = 0; i < n_strips; ++i) {
+    pdw = (wx <= 129 && wy <= 129) ? kPdw16Small : kPdw16Large;
+    // at least as many strips as the LDS needs, and enough of them to spread the CTU over the chip: a strip is
+    // >= 4 candidate rows (each also stages the 63 rows below it)
+    n_wg = std::max(strips_for(pdw, wy), std::min(kCallMaxJobs, (wy + 3) / 4));
+    if (n_wg > kCallMaxJobs) return fail(ctx, HMME_ERR_UNSUPPORTED, "window needs %d strips", n_wg);
+    for (int i = 0; i < n_wg; ++i) {
       js[i].j = job; js[i].job = 0;
-      js[i].y0 = (int16_t)((long)wy * i / n_strips); js[i].y1 = (int16_t)((long)wy * (i + 1) / n_strips);
+      js[i].y0 = (int16_t)((long)wy * i / n_wg); js[i].y1 = (int16_t)((long)wy * (i + 1) / n_wg);
       if (js[i].y1 - js[i].y0 > smax) smax = js[i].y1 - js[i].y0;
     }
-    const int zero = 0;
-    size_t cap = (size_t)ctx->first_strip_cap * sizeof(int);
-    rc = ensure(ctx, &ctx->d_first_strip, &cap, sizeof(int) * 16);
-    ctx->first_strip_cap = (int)(cap / sizeof(int));
-    if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_first_strip, &zero, sizeof zero, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_job1, js, sizeof(MeJob16) * n_strips, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));   // js / zero live on this stack frame
-    rc = launch_search16(ctx, ctx->d_ctu, 128, one_ref(ref_base), kWinPitch, ctx->d_job1, ctx->d_first_strip, 1, n_strips, pdw,
-                         smax, p->fen, p->bit_depth, ctx->d_mv1, ctx->d_sad1, s);
   }
+  {
+    const int n16 = (int)((kCallWin + (size_t)rows * kWinPitch + 64 + 15) / 16);
+    hipLaunchKernelGGL(hmme::me_stage_call_kernel, dim3((n16 + 255) / 256), dim3(256), 0, s, (const uint4*)ctx->h_call_dev, (uint4*)ctx->d_call, n16);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  // the kernel addresses ref(ctu + lt): bias the base so that (lt_x, lt_y) lands on the window copy's first sample
+  const uint8_t* ref_base = ctx->d_call + kCallWin - (long)p->lt_y * kWinPitch - (long)p->lt_x * bps;
+  const MeJob16* d_js = (const MeJob16*)(ctx->d_call + kCallJobs);
+  const int* d_first = (const int*)(ctx->d_call + kCallFirst);
+  unsigned long long* d_best1 = (unsigned long long*)(ctx->d_call + kCallBest);
+  // the 4.7 KB of results go straight into pinned host memory (mapped into the device's address space): no download step
+  int16_t* d_mv1 = (int16_t*)ctx->d_res;
+  uint32_t* d_sad1 = (uint32_t*)(ctx->d_res + 4 * HMME_NUM_CTU_PARTS);
+  int rc;
+  if (!wide)
+    rc = launch_search8_split(ctx, ctx->d_call + kCallCtu, 64, one_ref(ref_base), kWinPitch, d_js, d_first, 1, n_wg, p->fen, d_mv1, d_sad1, s, d_best1, false);
+  else
+    rc = launch_search16(ctx, ctx->d_call + kCallCtu, 128, one_ref(ref_base), kWinPitch, d_js, d_first, 1, n_wg, pdw, smax, p->fen, p->bit_depth,
+                         d_mv1, d_sad1, s, d_best1, false);
   if (rc) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mv, ctx->d_mv1, sizeof(int16_t) * 2 * HMME_NUM_CTU_PARTS, hipMemcpyDeviceToHost, s));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_sad, ctx->d_sad1, sizeof(uint32_t) * HMME_NUM_CTU_PARTS, hipMemcpyDeviceToHost, s));
-  HIP_TRY(ctx, hipStreamSynchronize(s));
-  std::memcpy(out_mv, ctx->h_mv, sizeof(int16_t) * 2 * HMME_NUM_CTU_PARTS);
-  std::memcpy(out_sad, ctx->h_sad, sizeof(uint32_t) * HMME_NUM_CTU_PARTS);
+  volatile uint32_t* done = (volatile uint32_t*)(ctx->h_res + 8 * HMME_NUM_CTU_PARTS);
+  const uint32_t seq = ++ctx->call_seq ? ctx->call_seq : ++ctx->call_seq;   // never 0, the word's initial value
+  hipLaunchKernelGGL(hmme::me_finalize1_kernel, dim3(1), dim3(640), 0, s, d_best1, d_js, ctx->lambda_q16, d_mv1, d_sad1,
+                     (volatile uint32_t*)(ctx->d_res + 8 * HMME_NUM_CTU_PARTS), seq);
+  HIP_TRY(ctx, hipGetLastError());
+  // the caller blocks on this call anyway (TEncSearch.cpp:3749-3758): poll the completion word for a while instead of paying the
+  // interrupt wake-up of hipStreamSynchronize, then fall back to it (a faulted kernel never publishes)
+  for (int spin = 0; *done != seq && spin < 200000; ++spin) __builtin_ia32_pause();
+  if (*done != seq) HIP_TRY(ctx, hipStreamSynchronize(s));
+  if (*done != seq) return fail(ctx, HMME_ERR_DEVICE, "hmme_search_ctu: the device did not publish results");
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  std::memcpy(out_mv, ctx->h_res, sizeof(int16_t) * 2 * HMME_NUM_CTU_PARTS);
+  std::memcpy(out_sad, ctx->h_res + 4 * HMME_NUM_CTU_PARTS, sizeof(uint32_t) * HMME_NUM_CTU_PARTS);
   return HMME_OK;
 }
 

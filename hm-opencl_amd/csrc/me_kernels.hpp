@@ -517,6 +517,32 @@ __global__ void me_finalize16_kernel(const unsigned long long* __restrict__ g_be
 }
 
 // one MeJob16 per (CTU, strip) from the per-CTU predictors
+// ---- per-CTU call: everything stays on the compute queue ------------------------------------------------------------
+// the call block (jobs, merge-table preset, current block, window) is pulled from mapped pinned host memory by the GPU itself
+// -- no copy-engine hop and no cross-queue dependency in front of the search kernel
+__global__ void me_stage_call_kernel(const uint4* __restrict__ host_block, uint4* __restrict__ dev_block, int n16) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n16) dev_block[i] = host_block[i];
+}
+// single-job finalize (one workgroup) that writes the results straight into mapped pinned host memory and then publishes a
+// sequence number there: the host polls that word instead of sleeping in hipStreamSynchronize
+__global__ void __launch_bounds__(640)
+me_finalize1_kernel(const unsigned long long* __restrict__ g_best, const MeJob16* __restrict__ jobs, uint32_t lambda_q16,
+                    int16_t* __restrict__ out_mv, uint32_t* __restrict__ out_sad, volatile uint32_t* done_flag, uint32_t seq) {
+  const int o = threadIdx.x;
+  if (o < kParts) {
+    const MeJob job = jobs[0].j;
+    const unsigned long long v = g_best[o];
+    const int mvx = job.lt_x + (int)(v & 0xffff), mvy = job.lt_y + (int)((v >> 16) & 0xffff);
+    out_mv[2 * o] = (int16_t)mvx;
+    out_mv[2 * o + 1] = (int16_t)mvy;
+    out_sad[o] = (uint32_t)(v >> 32) - me_mv_cost(lambda_q16, mvx, mvy, job.pred_x, job.pred_y);
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (o == 0) { *done_flag = seq; __threadfence_system(); }
+}
+
 __global__ void me_prep_jobs16_kernel(MeJob16* jobs, int* first_strip_of_job, const int16_t* __restrict__ pred_q,
                                       int ctu_first, int ctu_count, int n_refs, int pic_w, int pic_h, int sr, int n_strips) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

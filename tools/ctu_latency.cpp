@@ -1,0 +1,36 @@
+// Latency of hmme_search_ctu from C++ (what TEncOpenCL::calcMotionVectors pays per call), without Python in the loop.
+// Build: g++ -O2 -o ctu_latency_cpp tools/ctu_latency.cpp -Iinclude -Lhm-opencl_amd/csrc -lhmme -Wl,-rpath,$PWD/hm-opencl_amd/csrc
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "hmme.h"
+
+int main() {
+  hmme_ctx* ctx = nullptr;
+  if (hmme_create(0, 128, 0, &ctx) != HMME_OK) { fprintf(stderr, "create: %s\n", hmme_last_error(nullptr)); return 1; }
+  hmme_set_lambda(ctx, 57.9);
+  struct Case { const char* name; int sr, bd; } cases[] = {{"8bit_sr64", 64, 8}, {"8bit_sr8", 8, 8}, {"8bit_sr128", 128, 8}, {"10bit_sr64", 64, 10}, {"10bit_sr128", 128, 10}};
+  printf("{");
+  for (const Case& c : cases) {
+    const int side = 64 + 2 * c.sr + 8, maxv = (1 << c.bd) - 1;
+    std::vector<int16_t> cur(64 * 64), ref((size_t)side * side);
+    srand(1);
+    for (auto& v : cur) v = (int16_t)(rand() % (maxv + 1));
+    for (auto& v : ref) v = (int16_t)(rand() % (maxv + 1));
+    hmme_search_params p = {-c.sr, -c.sr, c.sr, c.sr, 5, -3, 1, c.bd};
+    std::vector<int16_t> mv(2 * HMME_NUM_CTU_PARTS);
+    std::vector<uint32_t> sad(HMME_NUM_CTU_PARTS);
+    const int16_t* r0 = ref.data() + (size_t)(c.sr + 4) * side + (c.sr + 4);
+    for (int i = 0; i < 5; ++i)
+      if (hmme_search_ctu(ctx, cur.data(), 64, r0, side, &p, mv.data(), sad.data()) != HMME_OK) { fprintf(stderr, "%s\n", hmme_last_error(ctx)); return 1; }
+    const int n = 200;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < n; ++i) hmme_search_ctu(ctx, cur.data(), 64, r0, side, &p, mv.data(), sad.data());
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / n;
+    printf("%s\"%s_ms_per_call\": %.4f", &c == cases ? "" : ", ", c.name, ms);
+  }
+  printf("}\n");
+  hmme_destroy(ctx);
+  return 0;
+}
