@@ -282,21 +282,21 @@ def main():
                                                          "measured issue rates are 4.3 cycles (v_sad_u8) / 16 cycles per 16 abs-diffs (v_qsad_pk_u16_u8), "
                                                          "i.e. a SAD-only ceiling of 0.25 of that figure (DESIGN.md 5)",
                                     "source": "profiles/latest_pmc_%s_sr%d.json (rocprofv3 --pmc passes of this command)" % (args.size, sr)}
-        if sr <= 64:   # the step after the path, reported beside the headline, never part of `value`
-            d_q = torch.zeros((n_refs, n_ctu, api.NUM_PARTS, 2), dtype=torch.int16, device=dev)
-            d_c = torch.zeros((n_refs, n_ctu, api.NUM_PARTS), dtype=torch.int32, device=dev)
-            d_mv16 = bufs[(state["k"] - 1) & 1][0].view(torch.int16).contiguous()   # TComMv words -> int16 (x, y) pairs
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            for i in range(4):
-                if i == 1:
-                    ev[0].record()
-                eng.refine_frame_multi_device(pc, ref_planes, fp, None, d_mv16.data_ptr(), 1, d_q.data_ptr(), d_c.data_ptr(), stream)
-            ev[1].record()
-            torch.cuda.synchronize()
-            r_ms = ev[0].elapsed_time(ev[1]) / 3
-            out["refine"] = {"what": "xPatternSearchFracDIF (half + quarter-pel, Hadamard) for all 593 slots of every CTU, on the integer winners",
-                             "kernel": "me_frac_kernel<1, %d>" % (1 if bd == 8 else 2), "ms_per_step": round(r_ms, 4),
-                             "slots_per_s": round(n_ctu * n_refs * api.NUM_PARTS / (r_ms * 1e-3))}
+        # the step after the path, reported beside the headline, never part of `value`
+        d_q = torch.zeros((n_refs, n_ctu, api.NUM_PARTS, 2), dtype=torch.int16, device=dev)
+        d_c = torch.zeros((n_refs, n_ctu, api.NUM_PARTS), dtype=torch.int32, device=dev)
+        d_mv16 = bufs[(state["k"] - 1) & 1][0].view(torch.int16).contiguous()   # TComMv words -> int16 (x, y) pairs
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        for i in range(4):
+            if i == 1:
+                ev[0].record()
+            eng.refine_frame_multi_device(pc, ref_planes, fp, None, d_mv16.data_ptr(), 1, d_q.data_ptr(), d_c.data_ptr(), stream)
+        ev[1].record()
+        torch.cuda.synchronize()
+        r_ms = ev[0].elapsed_time(ev[1]) / 3
+        out["refine"] = {"what": "xPatternSearchFracDIF (half + quarter-pel, Hadamard) for all 593 slots of every CTU, on the integer winners",
+                         "kernel": "me_frac_kernel<1, %d>" % (1 if bd == 8 else 2), "ms_per_step": round(r_ms, 4),
+                         "slots_per_s": round(n_ctu * n_refs * api.NUM_PARTS / (r_ms * 1e-3))}
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only: the other ranks would wait on it
             out["cpu_baseline"] = cpu_baseline(cur, ref, w, h, sr, lq, bd)
         print(json.dumps(out), flush=True)
