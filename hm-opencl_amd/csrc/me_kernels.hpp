@@ -146,11 +146,16 @@ struct MeJob16 {
 };
 
 // number of tasks me_search_kernel makes out of a wx x wy window (same arithmetic on host and device)
+// "fold": with 33 quads per row (the 129-wide window) and an odd number of rows, the 32-quad part's last iteration has an
+// idle second row of lanes; its first lanes take the leftover quads of the LAST window row, so the narrow parts stop one
+// row earlier (129 rows: 2 iterations of 64 rows instead of 3)
+__host__ __device__ inline bool me_fold(int quads, int wy) { return (quads & 32) && (quads & 31) && (wy & 1); }
 __host__ __device__ inline int me_num_tasks(int wx, int wy) {
   const int quads = (wx + 3) >> 2;
+  const int wy_low = me_fold(quads, wy) ? wy - 1 : wy;
   int n = 0;
   for (int k = 5; k >= 0; --k)
-    if (quads & (1 << k)) n += ((wy + (64 >> k) - 1) / (64 >> k) + kIterPerTask - 1) / kIterPerTask;
+    if (quads & (1 << k)) n += (((k == 5 ? wy : wy_low) + (64 >> k) - 1) / (64 >> k) + kIterPerTask - 1) / kIterPerTask;
   return n;
 }
 static_assert(sizeof(MeJob16) == 24, "MeJob16 layout");
@@ -217,6 +222,8 @@ me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefS
   //       (129 -> 32 + 1); part k lays a wave out as 2^k quads x (64 >> k) rows per iteration.
   const int quads = (wx + 3) >> 2;
   const int n_tasks = min(me_num_tasks(wx, wy), t_end);
+  const bool fold = me_fold(quads, wy);
+  const int wy_low = fold ? wy - 1 : wy;
 
   const uint32_t mult_a = 1u << kIdxBits;
   const uint32_t mult_e = FEN ? (2u << kIdxBits) : (1u << kIdxBits);
@@ -233,7 +240,7 @@ me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefS
       int xq = 0, rem = t;
       for (int kk = 5; kk >= 0; --kk) {
         if (!(quads & (1 << kk))) continue;
-        const int iters = (wy + (64 >> kk) - 1) / (64 >> kk);
+        const int iters = ((kk == 5 ? wy : wy_low) + (64 >> kk) - 1) / (64 >> kk);
         const int nt = (iters + kIterPerTask - 1) / kIterPerTask;
         if (rem < nt) { x0 = xq * 4; k = kk; it0 = rem * kIterPerTask; n_it = min(kIterPerTask, iters - it0); break; }
         rem -= nt;
@@ -242,14 +249,15 @@ me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefS
     }
     const int ty = 64 >> k;
     const int lx = lane & ((1 << k) - 1), ly = lane >> k;
-    const int cx = x0 + 4 * lx;
+    const bool fold_part = fold && k == 5;
 
     // running minima of the task: register g, lane l <-> slot ME_SLOT_OF[g][l]
     uint32_t b0 = ME_MAXKEY, b1 = ME_MAXKEY, b2 = ME_MAXKEY, b3 = ME_MAXKEY, b4 = ME_MAXKEY, b5 = ME_MAXKEY,
              b6 = ME_MAXKEY, b7 = ME_MAXKEY, b8 = ME_MAXKEY, b9 = ME_MAXKEY;
 
     for (int it = 0; it < n_it; ++it) {
-      const int cy = (it0 + it) * ty + ly;
+      int cx = x0 + 4 * lx, cy = (it0 + it) * ty + ly;
+      if (fold_part && cy == wy) { cx += 128; cy = wy - 1; }   // idle second row of the last iteration: leftover quads of the last row
       const bool vy = cy < wy;
       // per-candidate constants: (mv cost | invalid marker) << 10 | iteration | lane | j
       const int mvy = job.lt_y + cy, mvx = job.lt_x + cx;
@@ -281,8 +289,9 @@ me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefS
       const uint32_t cost = key >> kIdxBits;                                                                       \
       if (slot >= 0 && cost < kInvCost) {                                                                          \
         const int kit = (key >> 8) & 3, kl = (key >> 2) & 63, kj = key & 3;                                        \
-        const int bx = x0 + 4 * (kl & ((1 << k) - 1)) + kj;                                                        \
-        const int byy = (it0 + kit) * ty + (kl >> k);                                                              \
+        int bx = x0 + 4 * (kl & ((1 << k) - 1)) + kj;                                                              \
+        int byy = (it0 + kit) * ty + (kl >> k);                                                                    \
+        if (fold_part && byy == wy) { bx += 128; byy = wy - 1; }                                                   \
         atomicMin(&best64[slot],                                                                                   \
                   ((unsigned long long)cost << 32) | ((unsigned long long)byy << 16) | (unsigned long long)bx);    \
       }                                                                                                            \

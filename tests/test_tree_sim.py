@@ -32,19 +32,24 @@ def model_search(tree, cur, ref, origin, lt, rb, pred, lq, iters_per_task=2):
     best64 = np.full(593, (1 << 64) - 1, dtype=np.uint64)
     lanes = np.arange(64)
     quads = (wx + 3) >> 2
+    fold = bool(quads & 32) and bool(quads & 31) and bool(wy & 1)   # me_fold(): idle lanes of the 32-quad part's last iteration
     x0 = 0
     for k in range(5, -1, -1):
         if not quads & (1 << k):
             continue
         ty = 64 >> k
-        iters = (wy + ty - 1) // ty
+        iters = ((wy if k == 5 or not fold else wy - 1) + ty - 1) // ty
         for it0 in range(0, iters, iters_per_task):
             best = np.full((G.N_GROUPS, 64), 0xFFFFFFFF, np.uint32)
             n_it = min(iters_per_task, iters - it0)
             lx, ly = lanes & ((1 << k) - 1), lanes >> k
-            cx = x0 + 4 * lx
             for it in range(n_it):
+                cx = x0 + 4 * lx
                 cy = (it0 + it) * ty + ly
+                if fold and k == 5:
+                    m_ = cy == wy
+                    cx = np.where(m_, cx + 128, cx)
+                    cy = np.where(m_, wy - 1, cy)
                 c = np.zeros((4, 64), np.uint32)
                 for l in range(64):
                     by = cbits(((lt[1] + int(cy[l])) << 2) - pred[1])
@@ -63,6 +68,8 @@ def model_search(tree, cur, ref, origin, lt, rb, pred, lq, iters_per_task=2):
                     kit, kl, kj = (key >> 8) & 3, (key >> 2) & 63, key & 3
                     bx = x0 + 4 * (kl & ((1 << k) - 1)) + kj
                     byy = (it0 + kit) * ty + (kl >> k)
+                    if fold and k == 5 and byy == wy:
+                        bx, byy = bx + 128, wy - 1
                     v = np.uint64((cost << 32) | (byy << 16) | bx)
                     if v < best64[s]:
                         best64[s] = v
@@ -94,6 +101,18 @@ def test_generated_tree_reproduces_reference_goldens(case):
     got = model_search(tree, cur, ref, (m["origin_x"], m["origin_y"]), (m["lt_x"], m["lt_y"]), (m["rb_x"], m["rb_y"]),
                        (m["pred_x"], m["pred_y"]), m["lambda_q16"])
     assert np.array_equal(got, d["out"][case])
+
+
+def test_generated_tree_full_window_with_folded_last_row():
+    """the 129 x 129 window of SearchRange 64 (33 quads per row, odd row count): the leftover quad of the last row rides in
+    the idle lanes of the 32-quad part's last iteration (me_fold)"""
+    d = np.load(os.path.join(GOLDEN, "search_sr64.npz"))
+    m = dict(zip(d["meta_columns"].tolist(), (int(v) for v in d["meta"][0])))
+    assert (m["rb_x"] - m["lt_x"] + 1, m["rb_y"] - m["lt_y"] + 1) == (129, 129) and m["bit_depth"] == 8
+    tree = G.Tree(m["fen"]).build()
+    got = model_search(tree, d["cur"][0].astype(np.uint8), d["ref"][0].astype(np.uint8), (m["origin_x"], m["origin_y"]),
+                       (m["lt_x"], m["lt_y"]), (m["rb_x"], m["rb_y"]), (m["pred_x"], m["pred_y"]), m["lambda_q16"])
+    assert np.array_equal(got, d["out"][0])
 
 
 INV16, IDX16 = 4000000, G.IDX_BITS16
