@@ -576,6 +576,22 @@ int hmme_plane_bit_depth(const hmme_plane* pl) { return pl ? pl->bit_depth : 0; 
 int hmme_plane_upload_pel(hmme_plane* pl, const int16_t* origin, int stride) { return plane_upload<int16_t>(pl, origin, stride); }
 int hmme_plane_upload_u8(hmme_plane* pl, const uint8_t* origin, int stride) { return plane_upload<uint8_t>(pl, origin, stride); }
 
+int hmme_host_register(hmme_ctx* ctx, void* buffer, size_t bytes) {
+  if (!ctx) return HMME_ERR_ARG;
+  if (!buffer || !bytes) return fail(ctx, HMME_ERR_ARG, "hmme_host_register: null buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipHostRegister(buffer, bytes, hipHostRegisterDefault));
+  return HMME_OK;
+}
+
+int hmme_host_unregister(hmme_ctx* ctx, void* buffer) {
+  if (!ctx) return HMME_ERR_ARG;
+  if (!buffer) return fail(ctx, HMME_ERR_ARG, "hmme_host_unregister: null buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipHostUnregister(buffer));
+  return HMME_OK;
+}
+
 int hmme_plane_set_device_u8(hmme_plane* pl, const void* d_src, int src_pitch, void* stream) {
   if (!pl) return HMME_ERR_ARG;
   if (!d_src || src_pitch < pl->width) return fail(pl->ctx, HMME_ERR_ARG, "hmme_plane_set_device_u8: bad source");

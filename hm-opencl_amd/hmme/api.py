@@ -18,7 +18,7 @@ NUM_PARTS = 593
 SYMBOLS = ["hmme_create", "hmme_destroy", "hmme_last_error", "hmme_device_info", "hmme_set_lambda",
            "hmme_set_lambda_q16", "hmme_get_lambda_q16", "hmme_params_ocl_compat", "hmme_set_search_range",
            "hmme_slot_index", "hmme_slot_rect", "hmme_search_ctu", "hmme_plane_create", "hmme_plane_create_ex", "hmme_plane_bit_depth", "hmme_plane_destroy", "hmme_plane_upload_pel",
-           "hmme_plane_upload_u8", "hmme_plane_set_device_u8", "hmme_plane_width", "hmme_plane_height",
+           "hmme_plane_upload_u8", "hmme_host_register", "hmme_host_unregister", "hmme_plane_set_device_u8", "hmme_plane_width", "hmme_plane_height",
            "hmme_num_ctus", "hmme_search_frame", "hmme_search_frame_device", "hmme_search_frame_multi",
            "hmme_search_frame_multi_device", "hmme_refine_frame", "hmme_refine_frame_multi_device",
            "hmme_time_search_kernel"]
@@ -80,6 +80,8 @@ def load():
     L.hmme_plane_destroy.restype = None
     L.hmme_plane_upload_pel.argtypes = [vp, vp, i]
     L.hmme_plane_upload_u8.argtypes = [vp, vp, i]
+    L.hmme_host_register.argtypes = [vp, vp, C.c_size_t]
+    L.hmme_host_unregister.argtypes = [vp, vp]
     L.hmme_plane_set_device_u8.argtypes = [vp, vp, i, vp]
     L.hmme_plane_width.argtypes = [vp]
     L.hmme_plane_height.argtypes = [vp]
@@ -171,6 +173,13 @@ class Engine:
 
     def plane(self, width, height, bit_depth=8):
         return Plane(self, width, height, bit_depth)
+
+    def host_register(self, array):
+        """page-lock a long-lived numpy buffer: uploads from it then run at PCIe rate (hmme_host_register)"""
+        self._check(self.L.hmme_host_register(self.h, array.ctypes.data, array.nbytes))
+
+    def host_unregister(self, array):
+        self._check(self.L.hmme_host_unregister(self.h, array.ctypes.data))
 
     def search_ctu(self, cur_plane, cur_xy, ref_plane, ref_xy, params):
         """per-CTU drop-in (calcMotionVectors).  planes: 2-D int16; *_xy = CTU origin inside them.

@@ -37,6 +37,7 @@
 #ifndef HMME_H
 #define HMME_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -119,6 +120,11 @@ void hmme_plane_destroy(hmme_plane* plane);
  * rejected with HMME_ERR_RANGE */
 int hmme_plane_upload_pel(hmme_plane* plane, const int16_t* origin, int stride);
 int hmme_plane_upload_u8(hmme_plane* plane, const uint8_t* origin, int stride);
+/* Optional: page-lock a long-lived host buffer (e.g. the TComPicYuv planes of the decoded picture buffer,
+ * TComPicYuv.cpp:80-133) so that uploads from it run at PCIe rate instead of through the runtime's pageable staging.
+ * The buffer must stay allocated until hmme_host_unregister; uploads work with or without registration. */
+int hmme_host_register(hmme_ctx* ctx, void* buffer, size_t bytes);
+int hmme_host_unregister(hmme_ctx* ctx, void* buffer);
 /* device-side producers (e.g. a torch tensor): copy a width x height u8 image that already
  * lives in device memory, then extend borders; asynchronous on `stream` (hipStream_t) */
 int hmme_plane_set_device_u8(hmme_plane* plane, const void* d_src, int src_pitch, void* stream);

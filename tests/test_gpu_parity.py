@@ -680,3 +680,22 @@ def test_fuzz_search_ctu_vs_oracle(engine, oracle_lib):
         ox, oy, osad = oracle_lib.search_ctu(cur, (0, 0), ref, o, op)
         tag = dict(it=it, bd=bd, lt=lt, rb=rb, pred=pred, fen=fen, lam=lam)
         assert np.array_equal(mv[:, 0], ox) and np.array_equal(mv[:, 1], oy) and np.array_equal(sad, osad), tag
+
+
+def test_upload_from_registered_host_memory(engine):
+    """hmme_host_register page-locks the caller's picture buffer; uploads from it give the same plane"""
+    from hmme import synth
+    w, h, sr = 192, 128, 8
+    cur, ref, _ = synth.make_pair(w, h, seed=5, max_mv=4)
+    m = synth.MARGIN
+    engine.set_lambda(57.9)
+    with engine.plane(w, h) as pc, engine.plane(w, h) as pr:
+        pc.upload_pel(cur, (m, m)); pr.upload_pel(ref, (m, m))
+        want = engine.search_frame(pc, pr, sr)
+        engine.host_register(cur); engine.host_register(ref)
+        try:
+            pc.upload_pel(cur, (m, m)); pr.upload_pel(ref, (m, m))
+            got = engine.search_frame(pc, pr, sr)
+        finally:
+            engine.host_unregister(cur); engine.host_unregister(ref)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
