@@ -71,41 +71,53 @@ __device__ __forceinline__ uint64_t me_pksub(uint64_t a, uint64_t b) {
 // key_j = sad_j * mult + c_j : one v_mad_u32_u16 per candidate (op_sel picks the packed half)
 #define ME_KEYS(v, p, mult)                                                                                    \
   uint32_t v##_0, v##_1, v##_2, v##_3;                                                                         \
-  asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(v##_0) : "v"((uint32_t)(p)), "s"(mult), "v"(c0));                   \
-  asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(v##_1) : "v"((uint32_t)(p)), "s"(mult), "v"(c1));   \
-  asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(v##_2) : "v"((uint32_t)((p) >> 32)), "s"(mult), "v"(c2));           \
-  asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(v##_3) : "v"((uint32_t)((p) >> 32)), "s"(mult), "v"(c3))
+  asm volatile("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(v##_0) : "v"((uint32_t)(p)), "s"(mult), "v"(c0));                   \
+  asm volatile("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(v##_1) : "v"((uint32_t)(p)), "s"(mult), "v"(c1));   \
+  asm volatile("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(v##_2) : "v"((uint32_t)((p) >> 32)), "s"(mult), "v"(c2));           \
+  asm volatile("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(v##_3) : "v"((uint32_t)((p) >> 32)), "s"(mult), "v"(c3))
 // keys are linear in the SAD:  K(a U b) = K(a) + K(b) - c ;  K(a \ b) = K(a) - K(b) + c
 #define ME_LIN(v, a, b)                                                                                         \
   uint32_t v##_0, v##_1, v##_2, v##_3;                                                                          \
-  asm("v_add3_u32 %0, %1, %2, %3" : "=v"(v##_0) : "v"(a##_0), "v"(b##_0), "v"(nc0));                              \
-  asm("v_add3_u32 %0, %1, %2, %3" : "=v"(v##_1) : "v"(a##_1), "v"(b##_1), "v"(nc1));                              \
-  asm("v_add3_u32 %0, %1, %2, %3" : "=v"(v##_2) : "v"(a##_2), "v"(b##_2), "v"(nc2));                              \
-  asm("v_add3_u32 %0, %1, %2, %3" : "=v"(v##_3) : "v"(a##_3), "v"(b##_3), "v"(nc3))
+  asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(v##_0) : "v"(a##_0), "v"(b##_0), "v"(nc0));                              \
+  asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(v##_1) : "v"(a##_1), "v"(b##_1), "v"(nc1));                              \
+  asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(v##_2) : "v"(a##_2), "v"(b##_2), "v"(nc2));                              \
+  asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(v##_3) : "v"(a##_3), "v"(b##_3), "v"(nc3))
 // K(a) >= K(b) whenever b's rectangle is inside a's, so |K(a) - K(b)| + c is exact: one v_sad_u32
 #define ME_SUB(v, a, b)                                                                                         \
   uint32_t v##_0, v##_1, v##_2, v##_3;                                                                          \
-  asm("v_sad_u32 %0, %1, %2, %3" : "=v"(v##_0) : "v"(a##_0), "v"(b##_0), "v"(c0));                                \
-  asm("v_sad_u32 %0, %1, %2, %3" : "=v"(v##_1) : "v"(a##_1), "v"(b##_1), "v"(c1));                                \
-  asm("v_sad_u32 %0, %1, %2, %3" : "=v"(v##_2) : "v"(a##_2), "v"(b##_2), "v"(c2));                                \
-  asm("v_sad_u32 %0, %1, %2, %3" : "=v"(v##_3) : "v"(a##_3), "v"(b##_3), "v"(c3))
-#define ME_MIN4(k) min(min(k##_0, k##_1), min(k##_2, k##_3))
+  asm volatile("v_sad_u32 %0, %1, %2, %3" : "=v"(v##_0) : "v"(a##_0), "v"(b##_0), "v"(c0));                                \
+  asm volatile("v_sad_u32 %0, %1, %2, %3" : "=v"(v##_1) : "v"(a##_1), "v"(b##_1), "v"(c1));                                \
+  asm volatile("v_sad_u32 %0, %1, %2, %3" : "=v"(v##_2) : "v"(a##_2), "v"(b##_2), "v"(c2));                                \
+  asm volatile("v_sad_u32 %0, %1, %2, %3" : "=v"(v##_3) : "v"(a##_3), "v"(b##_3), "v"(c3))
+// the key arithmetic above, this minimum and the masked merges below are `asm volatile`: not for side effects but to keep
+// their mutual order in the ISA equal to the generator's order, which places every masked merge >= 2 of these instructions
+// after the ones that produce its inputs (tools/gen_me_tree.py space_merges)
+__device__ __forceinline__ uint32_t me_min4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  uint32_t r;
+  asm volatile("v_min3_u32 %0, %1, %2, %3\n\tv_min_u32 %0, %0, %4" : "=&v"(r) : "v"(a), "v"(b), "v"(c), "v"(d));
+  return r;
+}
+#define ME_MIN4(k) me_min4(k##_0, k##_1, k##_2, k##_3)
 
 // butterfly transpose-reduce: merge two slot registers into one; lanes whose role bit is 0 keep
 // slot a (min over the lane pair), lanes whose role bit is 1 keep slot b.
 // Levels 0/1 (447 of the 588 merges): two DPP mins, the second one bank-masked so that it only
 // overwrites the role-0 lanes.  s_nop 1 = the 2 wait states a DPP read needs after a VALU write of its
 // source (hipcc does not pad hazards inside an asm statement).
-#define ME_MERGE_DPP_MASKED(NAME, CTRL, MASK0)                                                               \
+// The _nn variants carry no padding: tools/gen_me_tree.py (space_merges) emits them only where >= 3 other ops separate the
+// merge from the ops that produce its inputs, and tools/check_dpp_hazard.py verifies the distance in the final ISA (make check-isa).
+#define ME_MERGE_DPP_MASKED(NAME, PAD, CTRL, MASK0)                                                          \
   __device__ __forceinline__ uint32_t NAME(uint32_t a, uint32_t b) {                                         \
     uint32_t r;                                                                                              \
-    asm("s_nop 1\n\tv_min_u32_dpp %0, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                       \
+    asm volatile(PAD "v_min_u32_dpp %0, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                     \
         "v_min_u32_dpp %0, %1, %1 " CTRL " row_mask:0xf bank_mask:" MASK0                                    \
         : "=&v"(r) : "v"(a), "v"(b));                                                                        \
     return r;                                                                                                \
   }
-ME_MERGE_DPP_MASKED(me_merge0, "row_ror:8", "0x3")          // role = lane bit 3: lanes 0-7 of a row = banks 0,1
-ME_MERGE_DPP_MASKED(me_merge1, "row_half_mirror", "0x5")    // role = lane bit 2: lanes 0-3, 8-11 = banks 0,2
+ME_MERGE_DPP_MASKED(me_merge0, "s_nop 1\n\t", "row_ror:8", "0x3")          // role = lane bit 3: lanes 0-7 of a row = banks 0,1
+ME_MERGE_DPP_MASKED(me_merge1, "s_nop 1\n\t", "row_half_mirror", "0x5")    // role = lane bit 2: lanes 0-3, 8-11 = banks 0,2
+ME_MERGE_DPP_MASKED(me_merge0_nn, "", "row_ror:8", "0x3")
+ME_MERGE_DPP_MASKED(me_merge1_nn, "", "row_half_mirror", "0x5")
 __device__ __forceinline__ uint32_t me_merge2(uint32_t a, uint32_t b) {   // role = lane bit 5
   u32x2_t r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
   return min(r.x, r.y);

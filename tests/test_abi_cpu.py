@@ -74,3 +74,17 @@ def test_slot_layout_matches_reference_getIndexBlock(slots):
         assert api.slot_index(ps, depth, pi, z) == slot
         assert api.slot_rect(slot) == (x, y, w, h)
     assert api.slot_index(3, 3, 0, 0) == -1 and api.slot_index(4, 3, 0, 0) == -1 and api.slot_index(0, 1, 0, 1) == -1
+
+
+def test_generated_isa_has_no_dpp_hazard():
+    """the unpadded DPP merges of me_search_kernel rely on instruction spacing the generator arranges; the final ISA
+    (hipcc cross-compiles gfx950 here) must not have a DPP read within 2 wait states of the write of its source"""
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    if not shutil.which("hipcc"):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "hm-opencl_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "check-isa"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 hazard(s)" in r.stdout

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""ISA check for the hand-written DPP instructions (inline asm is not padded by the compiler's hazard recognizer):
+a VALU write of a VGPR must be followed by 2 wait states before a DPP instruction reads that VGPR as its DPP source
+(gfx9 data hazard).  Every instruction the wave issues is one wait state, `s_nop N` is N + 1.
+usage: check_dpp_hazard.py <file.s> [kernel-name-substring ...]   -> exit 1 on a violation"""
+import re
+import sys
+
+
+def regs(tok):
+    """VGPR numbers named by an operand token: v12 -> {12}, v[10:13] -> {10..13}"""
+    m = re.fullmatch(r"v(\d+)", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def check(path, names):
+    bad = total = 0
+    kernel = None
+    hist = []   # (wait states this instruction provides, set of VGPRs it writes)
+    for ln in open(path):
+        ln = ln.split(";")[0].strip()
+        if not ln:
+            continue
+        if ln.endswith(":") and not ln.startswith("."):
+            kernel = ln[:-1]
+            hist = []
+            continue
+        if ln.startswith(".") or kernel is None or (names and not any(n in kernel for n in names)):
+            continue
+        parts = ln.replace(",", " ").split()
+        op, args = parts[0], parts[1:]
+        if op.endswith("_dpp"):
+            total += 1
+            src = regs(args[1]) if len(args) > 1 else set()
+            need, i = 2, len(hist) - 1
+            while need > 0 and i >= 0:
+                ws, written = hist[i]
+                if written & src:
+                    bad += 1
+                    print(f"{kernel}: '{ln}' reads {sorted(written & src)} {2 - need} wait state(s) after its write")
+                    break
+                need -= ws
+                i -= 1
+        if op == "s_nop":
+            hist.append((int(args[0], 0) + 1, set()))
+        elif op.startswith("v_") and not op.startswith("v_cmp"):
+            hist.append((1, regs(args[0]) if args else set()))
+        else:
+            hist.append((1, set()))   # loads write VGPRs too, but their data arrives behind s_waitcnt, not by this hazard
+        hist = hist[-4:]
+    print(f"{path}: {total} DPP instructions checked, {bad} hazard(s)")
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if check(sys.argv[1], sys.argv[2:]) else 0)

@@ -439,10 +439,70 @@ HEADER16 = """// GENERATED by tools/gen_me_tree.py -- do not edit.  One lane-ite
 """
 
 
+MASKED_MERGE_LEVELS = (0, 1)   # the two levels done with hand-written bank-masked DPP pairs (me_merge0 / me_merge1)
+# instructions of the ops that the 8-bit kernel emits as `asm volatile` (their mutual order in the ISA is the order here)
+ORDERED_INSTRS = {"KEYS": 4, "LIN": 4, "SUB": 4, "MIN4": 2}
+
+
+def space_merges(ops, enable):
+    """A DPP instruction must not read a VGPR within 2 wait states of the VALU write that produced it, and the compiler
+    does not pad inside inline asm.  The masked merges, the per-slot minima that feed them and the key arithmetic are
+    `asm volatile` in the 8-bit kernel, so their mutual order in the ISA is this list's order; a masked merge is held
+    back in a FIFO until >= 2 such instructions (one KEYS / LIN / SUB / MIN4 / other masked merge) separate it from the
+    ops that produce its inputs -- then it needs no s_nop (unpadded variant, checked by tools/check_dpp_hazard.py).
+    What is still waiting when nothing independent is left gets the padded variant.
+    -> [(op, padded)]; `padded` only matters for masked-level MERGE ops.  enable=False: original order, all padded."""
+    if not enable:
+        return [(op, True) for op in ops]
+    out, where = [], {}          # emitted (op, padded); value name -> ordered-instruction count right after its producer
+    pending = []
+    count = [0]
+
+    def inputs(op):
+        return [x for x in (op[3], op[4]) if x is not None] if op[0] == "MERGE" else [op[2]]
+
+    def masked(op):
+        return op[0] == "MERGE" and op[1] in MASKED_MERGE_LEVELS
+
+    def try_flush(force=False):
+        progress = True
+        while progress and pending:
+            progress = False
+            for op in list(pending):
+                ins = inputs(op)
+                if any(x not in where for x in ins):
+                    continue                                        # its producer is itself waiting
+                fresh = masked(op) and any(count[0] - where[x] < 2 for x in ins)
+                if fresh and not force:
+                    continue
+                pending.remove(op)
+                if masked(op):
+                    count[0] += 2
+                if op[0] == "MERGE":
+                    # results of the compiler-scheduled levels can land anywhere: treat them as fresh for good
+                    where[op[2]] = count[0] if masked(op) else float("inf")
+                out.append((op, fresh))
+                progress = True
+
+    for op in ops:
+        try_flush()
+        if op[0] in ("MERGE", "ACC"):
+            pending.append(op)
+            try_flush()
+        else:
+            count[0] += ORDERED_INSTRS.get(op[0], 0)
+            if op[0] == "MIN4":
+                where[op[1]] = count[0]
+            out.append((op, False))
+    try_flush(force=True)
+    assert not pending
+    return out
+
+
 def emit_cpp(tree, path, header=None):
     o = [(header or HEADER) % tree.fen]
     max_declared = False
-    for op in tree.ops:
+    for op, padded in space_merges(tree.ops, enable=not isinstance(tree, Tree16)):
         t = op[0]
         if t == "BASE":
             _, b, row, k = op
@@ -476,7 +536,8 @@ def emit_cpp(tree, path, header=None):
             _, level, m, a, b = op
             a = a if a is not None else "ME_MAXKEY"
             b = b if b is not None else "ME_MAXKEY"
-            o.append(f"const uint32_t {m} = me_merge{level}({a}, {b}{'' if level < 4 else f', rb{5 - level}'});")
+            nn = "_nn" if level in MASKED_MERGE_LEVELS and not padded else ""
+            o.append(f"const uint32_t {m} = me_merge{level}{nn}({a}, {b}{'' if level < 4 else f', rb{5 - level}'});")
         elif t == "ACC":
             o.append(f"b{op[1]} = min(b{op[1]}, {op[2]});")
         elif t == "LDS16":
