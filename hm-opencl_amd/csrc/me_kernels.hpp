@@ -408,6 +408,16 @@ __global__ void me_fill_plane_kernel(uint8_t* __restrict__ dst, int dst_pitch, i
 // horizontal strips of candidate rows so that one strip's reference rows fit LDS (SR 128: 320 x 322 samples);
 // strips of a CTU are separate workgroups that merge through 64-bit atomicMin on a global table.
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+// 16-bit kernel: key of each of the lane's two candidates from its exact sum, and their minimum; `asm volatile` for the same
+// reason as me_min4 (ordered against the masked merges)
+__device__ __forceinline__ uint32_t me_keymin2(uint32_t s0, uint32_t s1, uint32_t mask, uint32_t lsh, uint32_t c0, uint32_t c1) {
+  uint32_t r, t;
+  asm volatile("v_and_b32 %0, %4, %2\n\tv_and_b32 %1, %4, %3\n\t"
+               "v_lshl_add_u32 %0, %0, %5, %6\n\tv_lshl_add_u32 %1, %1, %5, %7\n\t"
+               "v_min_u32 %0, %0, %1"
+               : "=&v"(r), "=&v"(t) : "v"(s0), "v"(s1), "s"(mask), "s"(lsh), "v"(c0), "v"(c1));
+  return r;
+}
 typedef volatile __attribute__((address_space(3))) uint32_t lds_vu32_t;
 typedef volatile __attribute__((address_space(3))) u32x4_t lds_vu32x4_t;
 #define ME_SAD16(a, b, acc) __builtin_amdgcn_sad_u16((a), (b), (acc))

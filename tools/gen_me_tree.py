@@ -441,13 +441,13 @@ HEADER16 = """// GENERATED by tools/gen_me_tree.py -- do not edit.  One lane-ite
 
 MASKED_MERGE_LEVELS = (0, 1)   # the two levels done with hand-written bank-masked DPP pairs (me_merge0 / me_merge1)
 # instructions of the ops that the 8-bit kernel emits as `asm volatile` (their mutual order in the ISA is the order here)
-ORDERED_INSTRS = {"KEYS": 4, "LIN": 4, "SUB": 4, "MIN4": 2}
+ORDERED_INSTRS = {"KEYS": 4, "LIN": 4, "SUB": 4, "MIN4": 2, "KEYMIN2": 5}
 
 
 def space_merges(ops, enable):
     """A DPP instruction must not read a VGPR within 2 wait states of the VALU write that produced it, and the compiler
     does not pad inside inline asm.  The masked merges, the per-slot minima that feed them and the key arithmetic are
-    `asm volatile` in the 8-bit kernel, so their mutual order in the ISA is this list's order; a masked merge is held
+    `asm volatile` in both kernels, so their mutual order in the ISA is this list's order; a masked merge is held
     back in a FIFO until >= 2 such instructions (one KEYS / LIN / SUB / MIN4 / other masked merge) separate it from the
     ops that produce its inputs -- then it needs no s_nop (unpadded variant, checked by tools/check_dpp_hazard.py).
     What is still waiting when nothing independent is left gets the padded variant.
@@ -491,7 +491,7 @@ def space_merges(ops, enable):
             try_flush()
         else:
             count[0] += ORDERED_INSTRS.get(op[0], 0)
-            if op[0] == "MIN4":
+            if op[0] in ("MIN4", "KEYMIN2"):       # the ops whose result a level-0 merge reads
                 where[op[1]] = count[0]
             out.append((op, False))
     try_flush(force=True)
@@ -502,7 +502,7 @@ def space_merges(ops, enable):
 def emit_cpp(tree, path, header=None):
     o = [(header or HEADER) % tree.fen]
     max_declared = False
-    for op, padded in space_merges(tree.ops, enable=not isinstance(tree, Tree16)):
+    for op, padded in space_merges(tree.ops, enable=True):
         t = op[0]
         if t == "BASE":
             _, b, row, k = op
@@ -561,7 +561,7 @@ def emit_cpp(tree, path, header=None):
             o.append(f"const uint32_t {op[1]}_0 = {op[2]}_0 - {op[3]}_0, {op[1]}_1 = {op[2]}_1 - {op[3]}_1;")
         elif t == "KEYMIN2":
             f_ = "e" if op[3] == "E" else "a"
-            o.append(f"const uint32_t {op[1]} = min((({op[2]}_0 & mask_{f_}) << lsh_{f_}) + c0, (({op[2]}_1 & mask_{f_}) << lsh_{f_}) + c1);")
+            o.append(f"const uint32_t {op[1]} = me_keymin2({op[2]}_0, {op[2]}_1, mask_{f_}, lsh_{f_}, c0, c1);")
         else:
             raise ValueError(t)
     write_if_changed(path, "\n".join(o) + "\n")
