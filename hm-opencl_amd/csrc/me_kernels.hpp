@@ -274,7 +274,9 @@ me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefS
       // per-candidate constants: (mv cost | invalid marker) << 10 | iteration | lane | j
       const int mvy = job.lt_y + cy, mvx = job.lt_x + cx;
       const uint32_t by = me_component_bits((mvy << 2) - job.pred_y);
-      const uint32_t tag = ((uint32_t)it << 8) | ((uint32_t)lane << 2);
+      uint32_t lane_now = (uint32_t)lane;
+      asm("" : "+v"(lane_now));   // keep `lane << 2` out of the loop-invariant registers: at 255 VGPRs it was the one value spilled
+      const uint32_t tag = ((uint32_t)it << 8) | (lane_now << 2);
       uint32_t cc[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
