@@ -484,16 +484,35 @@ def space_merges(ops, enable):
                 out.append((op, fresh))
                 progress = True
 
+    key_at = {}                  # key name -> ordered-instruction count right after the KEYS / LIN / SUB that made it
+    held = []                    # MIN4 ops waiting for one other ordered op to separate them from the op that made their keys:
+                                 # hipcc pads an asm block that reads what the asm block right before it wrote (s_nop 0)
+
+    def emit_plain(op):
+        count[0] += ORDERED_INSTRS.get(op[0], 0)
+        if op[0] in ("KEYS", "LIN", "SUB"):
+            key_at[op[1]] = count[0]
+        if op[0] in ("MIN4", "KEYMIN2"):       # the ops whose result a level-0 merge reads
+            where[op[1]] = count[0]
+        out.append((op, False))
+
+    def release_held(force=False):
+        for op in list(held):
+            if force or count[0] > key_at.get(op[2], -1):
+                held.remove(op)
+                emit_plain(op)
+
     for op in ops:
         try_flush()
         if op[0] in ("MERGE", "ACC"):
             pending.append(op)
             try_flush()
+        elif op[0] == "MIN4" and key_at.get(op[2], -1) == count[0]:
+            held.append(op)
         else:
-            count[0] += ORDERED_INSTRS.get(op[0], 0)
-            if op[0] in ("MIN4", "KEYMIN2"):       # the ops whose result a level-0 merge reads
-                where[op[1]] = count[0]
-            out.append((op, False))
+            emit_plain(op)
+            release_held()
+    release_held(force=True)
     try_flush(force=True)
     assert not pending
     return out
