@@ -29,7 +29,10 @@ constexpr int kCallMaxJobs = 64;
 static_assert(sizeof(MeJob16) * kCallMaxJobs <= kCallFirst && kCallBest + 8 * HMME_NUM_CTU_PARTS <= kCallCtu && kCallCtu + 64 * 64 * 2 <= kCallWin,
               "per-CTU call block layout");
 constexpr size_t kLdsBudget16 = 78 * 1024;   // per workgroup of the 16-bit path -> 2 workgroups per CU
-constexpr int kPdw16Small = 98, kPdw16Large = 162;   // 16-bit window pitch in dwords for SR <= 64 / SR <= 128 (even: rows stay 8-byte aligned for ds_read_b64)
+// 16-bit window pitch in dwords for windows up to 129 / 257 candidates wide.  Even: rows stay 8-byte aligned for ds_read_b64.
+// 130 = 2 * 33 lanes-per-row + 64: with the kernel's linear lane packing every lane of a 129-wide even-column pass lands on
+// its own bank pair (measured +1.5 % over 98); the same trick for 257-wide windows (194) costs more strips than it saves
+constexpr int kPdw16Small = 130, kPdw16Large = 162;
 std::string g_create_error;
 }  // namespace
 
