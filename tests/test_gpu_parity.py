@@ -699,3 +699,47 @@ def test_upload_from_registered_host_memory(engine):
         finally:
             engine.host_unregister(cur); engine.host_unregister(ref)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+def test_contexts_are_independent_and_do_not_leak(oracle_lib):
+    """two contexts used alternately (one per host thread / per stream is the documented model) give the same tables as one,
+    and 25 create / use / destroy cycles leave the device memory where it was"""
+    import threading
+    import torch
+    from hmme import api, synth
+    w, h, sr = 256, 128, 16
+    cur, ref, _ = synth.make_pair(w, h, seed=3, max_mv=8, region=64)
+    m = synth.MARGIN
+
+    def run(eng, out, key):
+        eng.set_lambda(57.9)
+        with eng.plane(w, h) as pc, eng.plane(w, h) as pr:
+            pc.upload_pel(cur, (m, m)); pr.upload_pel(ref, (m, m))
+            for _ in range(4):
+                mv, sad = eng.search_frame(pc, pr, sr)
+                q, c = eng.refine_frame(pc, pr, sr, mv)
+                one = eng.search_ctu(cur, (m, m), ref, (m, m), api.SearchParams(-sr, -sr, sr, sr, 0, 0, 1, 8))
+            out[key] = (mv, sad, q, c, one)
+
+    with api.Engine(0, 64) as a, api.Engine(0, 64) as b:
+        res = {}
+        ts = [threading.Thread(target=run, args=(e, res, k)) for e, k in ((a, "a"), (b, "b"))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    assert set(res) == {"a", "b"}
+    for x, y in zip(res["a"][:4], res["b"][:4]):
+        assert np.array_equal(x, y)
+    assert np.array_equal(res["a"][4][0], res["b"][4][0]) and np.array_equal(res["a"][4][1], res["b"][4][1])
+    ox, oy, osad = oracle_lib.search_frame(cur, ref, (m, m), w, h, sr, None, oracle_lib.oracle().hmo_lambda_q16(57.9), 1, 8, n_threads=4)
+    assert np.array_equal(res["a"][0][:, :, 0], ox) and np.array_equal(res["a"][1], osad)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for _ in range(25):
+        with api.Engine(0, 128) as e:
+            tmp = {}
+            run(e, tmp, "x")
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info(0)[0]
+    assert free0 - free1 < 64 << 20, (free0, free1)
