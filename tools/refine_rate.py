@@ -10,6 +10,8 @@ if len(sys.argv) > 1: w, h = (int(v) for v in sys.argv[1].split("x"))
 bd = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 cur, ref, _ = synth.make_pair(w, h, seed=1234, bit_depth=bd)
 content = sys.argv[3] if len(sys.argv) > 3 else "coherent"
+if content == "mixed":   # small regions with their own motion and stronger noise: sharing inside a CTU is partial
+    cur, ref, _ = synth.make_pair(w, h, seed=1234, bit_depth=bd, max_mv=10, region=24, noise_sigma=6.0)
 if content == "noise":   # unrelated pictures: nearly every slot has its own integer MV, nothing to share
     import numpy as np
     rng = np.random.default_rng(5)
