@@ -46,14 +46,14 @@ extern "C" {
 
 #define HMME_NUM_CTU_PARTS 593 /* TLibCommon/TypeDef.h:263 */
 #define HMME_CTU_SIZE 64
-#define HMME_MAX_SEARCH_RANGE 128 /* frame calls: any bit depth (8-bit windows beyond 129^2 run as 2x2 tiles); hmme_search_ctu: 8-bit
-                                      windows up to 129^2, 16-bit ones up to 257^2 */
+#define HMME_MAX_SEARCH_RANGE 128 /* any bit depth, frame and per-CTU calls: windows up to 257 x 257 candidates (8-bit windows beyond
+                                      129 x 129 run as 2 x 2 tiles) */
 
 enum {
   HMME_OK = 0,
   HMME_ERR_ARG = -1,     /* invalid argument (null pointer, window larger than sr_max, ...) */
   HMME_ERR_DEVICE = -2,  /* no usable gfx950 device / HIP runtime error */
-  HMME_ERR_RANGE = -3,   /* sample outside [0,255] handed to the 8-bit path */
+  HMME_ERR_RANGE = -3,   /* sample outside the range of the bit depth (bi-prediction origins of hmme_search_ctu excepted) */
   HMME_ERR_NOMEM = -4,
   HMME_ERR_UNSUPPORTED = -5
 };
@@ -105,7 +105,8 @@ int hmme_slot_rect(int slot, int* x, int* y, int* w, int* h);
 
 /* ---- per-CTU drop-in (host buffers, HM `Pel` = int16) --------------------------------- */
 /* ctu: 64x64 current block (TEncSearch.cpp:3747); ref_at_ctu_origin: reference plane at the CTU
- * origin inside its padded buffer, as handed to calcMotionVectors.  Synchronous.
+ * origin inside its padded buffer, as handed to calcMotionVectors.  Synchronous.  Current-block samples may be the
+ * bi-prediction origin 2*org - pred (TEncSearch.cpp:3702-3712), i.e. lie in [-maxv, 2*maxv].
  * out_mv: int16[593][2] (hor, ver), out_sad: uint32[593] (pure SAD at the arg-min = ruiCost). */
 int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref_at_ctu_origin,
                     int ref_stride, const hmme_search_params* p, int16_t* out_mv, uint32_t* out_sad);
