@@ -49,20 +49,33 @@ def work_4x4_sads(api, w, h, sr):
     return total
 
 
-def pmc_profile(size, sr):
-    """derived figures of the last rocprofv3 --pmc passes of this same command (tools/profile_bench.sh),
-    committed under profiles/ -- counters cannot be read from inside the timed process."""
+def kernel_source_hash():
+    """sha256 over the sources libhmme.so is built from: ties a committed counter summary to the binary that was profiled"""
+    import hashlib
+    csrc = os.path.join(ROOT, "hm-opencl_amd", "csrc")
+    h = hashlib.sha256()
+    for name in ("hmme.hip", "me_kernels.hpp", "me_slotmap.inc", "me_tree_fen0.inc", "me_tree_fen1.inc", "me_tree16_fen0.inc",
+                 "me_tree16_fen1.inc"):
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def profile_label(size, sr, bd):
+    return f"{size}_sr{sr}" + ("" if bd == 8 else f"_{bd}bit")
+
+
+def pmc_profile(size, sr, bd):
+    """derived figures of the last rocprofv3 --pmc passes of this same command (tools/profile_bench.sh), committed under
+    profiles/ -- counters cannot be read from inside the timed process.  {} when there is no summary for this
+    configuration or when it was taken from other kernel sources than the ones this library was built from."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", f"latest_pmc_{size}_sr{sr}.json")))["derived"]
-    except (OSError, KeyError, ValueError):
+        d = json.load(open(os.path.join(ROOT, "profiles", f"latest_pmc_{profile_label(size, sr, bd)}.json")))
+    except (OSError, ValueError):
         return {}
-
-
-def pmc_traffic(size, sr):
-    """HBM bytes per launch of the search kernel: FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950
-    correction, + WRITE_SIZE.  None if no matching profile."""
-    v = pmc_profile(size, sr).get("hbm_traffic_bytes_per_launch")
-    return int(v) if v is not None else None
+    if d.get("kernel_source_hash") != kernel_source_hash():
+        return {"stale": True}
+    return d
 
 
 def usable_cores():
@@ -82,6 +95,25 @@ def usable_cores():
         except (OSError, ValueError, IndexError):
             pass
     return n
+
+
+def verify_against_oracle(res, cur, ref, w, h, sr, lq, bd):
+    """res: int32 [2, n_refs, n_ctu, 593] (TComMv words, SADs) of the last timed step; reference 0 is checked bit-exactly
+    against the oracle's exhaustive search on four CTUs.  Raises SystemExit on a mismatch."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    from hmme import synth
+    m = synth.MARGIN
+    ctus_x, ctus_y = (w + 63) // 64, (h + 63) // 64
+    sample = sorted({0, ctus_x * (ctus_y // 2) + ctus_x // 3, ctus_x * ctus_y - 1, ctus_x * (ctus_y - 1) + ctus_x // 2})
+    mv = np.ascontiguousarray(res[0, 0]).view(np.int16).reshape(res.shape[2], 593, 2)
+    sad = res[1, 0].view(np.uint32)
+    t0 = time.time()
+    for ctu in sample:
+        ox, oy, osad = O.search_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, bd, ctu, 1, 1)
+        if not (np.array_equal(mv[ctu, :, 0], ox[0]) and np.array_equal(mv[ctu, :, 1], oy[0]) and np.array_equal(sad[ctu], osad[0])):
+            raise SystemExit(f"bench.py: tables of the timed step differ from the CPU oracle at CTU {ctu}: nothing reported")
+    return {"ctus": sample, "slots": 593 * len(sample), "against": "oracle exhaustive search (bit-exact)", "seconds": round(time.time() - t0, 2)}
 
 
 def cpu_baseline(cur, ref, w, h, sr, lq, bd=8, budget_s=14.0):
@@ -193,44 +225,31 @@ def main():
         pl.upload_pel(r2, (synth.MARGIN, synth.MARGIN))
     n_ctu = api.load().hmme_num_ctus(w, h)
     fp = api.FrameParams(sr, 1, bd, 0, n_ctu)
-    # one picture pair per rank and step.  Results of step k land in buffer k % 2 ([2, 1, n_ctu, 593] int32: TComMv
+    # one picture pair per rank and step.  Results of step k land in buffer k % 2 ([2, n_refs, n_ctu, 593] int32: TComMv
     # words and SADs) and are all-gathered asynchronously on RCCL's stream while step k+1 searches into the other
-    # buffer: the 9.7 MB per rank per step never stalls the VALU-bound kernel.
-    bufs = [torch.zeros((2, n_refs, n_ctu, api.NUM_PARTS), dtype=torch.int32, device=dev) for _ in range(2)]
-    gathered = [torch.zeros((world, 2, n_refs, n_ctu, api.NUM_PARTS), dtype=torch.int32, device=dev) if use_dist else None
-                for _ in range(2)]
-    pending = [None, None]
+    # buffer (hmme/shard.py PipelinedGather; the same class runs under gloo in tests/test_shard_gloo.py)
     stream = torch.cuda.current_stream().cuda_stream
-    state = {"k": 0}
+    pipe = shard.PipelinedGather(lambda: torch.zeros((2, n_refs, n_ctu, api.NUM_PARTS), dtype=torch.int32, device=dev),
+                                 distributed=use_dist, async_op=(args.backend == "nccl"))
+    events = []
 
-    def step(ev=None):
-        b = state["k"] & 1
-        state["k"] += 1
-        if pending[b] is not None:      # the gather that last read this buffer must be done before we overwrite it
-            pending[b].wait()
-            pending[b] = None
+    def launch(buf, k):
+        ev = events[k - n_untimed] if k >= n_untimed else None
         if ev:
             ev[0].record()
-        eng.search_frame_multi_device(pc, ref_planes, fp, None, bufs[b][0].data_ptr(), bufs[b][1].data_ptr(), stream)
+        eng.search_frame_multi_device(pc, ref_planes, fp, None, buf[0].data_ptr(), buf[1].data_ptr(), stream)
         if ev:
             ev[1].record()
-        if use_dist:   # the one exchange step of the path: tables of all `world` pairs to every rank (RCCL/xGMI)
-            _, pending[b] = shard.gather_packed(bufs[b], gathered[b], async_op=(args.backend == "nccl"))
-
-    def drain():
-        for b in range(2):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
 
     # untimed set-up: the power management takes ~10 launches (tens of ms) to bring an idle GPU to its sustained clock; without
     # this the first timed steps of a short run (small K and W) are measured at a lower clock than the rest (5 steps: +6 %)
     for _ in range(24):
-        eng.search_frame_multi_device(pc, ref_planes, fp, None, bufs[0][0].data_ptr(), bufs[0][1].data_ptr(), stream)
+        eng.search_frame_multi_device(pc, ref_planes, fp, None, pipe.bufs[0][0].data_ptr(), pipe.bufs[0][1].data_ptr(), stream)
     torch.cuda.synchronize()
+    n_untimed = args.warmup
     for _ in range(args.warmup):
-        step()
-    drain()
+        pipe.step(launch)
+    pipe.drain()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -238,8 +257,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(events[k])
-    drain()
+        pipe.step(launch)
+    pipe.drain()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -255,7 +274,10 @@ def main():
         total_sads = sads * world * args.steps
         algo_bytes = algo_bytes_per_ctu(sr, bd) * n_ctu * n_refs
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        # sanity: results of the last step vs a freshly computed host call on a few CTUs
+        prof = pmc_profile(args.size, sr, bd) if n_refs == 1 else {}
+        search_kernel = "me_search_kernel" if bd == 8 else "me_search16_kernel"
+        kprof = prof.get("kernels", {}).get(search_kernel, {})
+        traffic = kprof.get("hbm_traffic_bytes_per_launch")
         out = {
             "metric": "GSAD/s", "value": round(total_sads / elapsed / 1e9, 2), "unit": "GSAD/s (4x4-block SAD evaluations)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -265,32 +287,43 @@ def main():
             "config": {"workload": f"{w}x{h} {bd}-bit luma, lowdelay_P_main{'' if bd == 8 else '10'} (FEN=1), SearchRange={sr}, CTU=64, exhaustive "
                                    f"integer search of all 593 PU shapes, {n_refs} reference picture{'s' if n_refs > 1 else ''} per launch, {n_ctu} CTUs per frame",
                        "frames_per_step": world, "parallelism": f"frame-shard x{world}", "lambda": LAMBDA,
+                       "collective": f"all_gather_into_tensor ({args.backend}), world {world}" if use_dist else "none (one rank)",
                        "sads_4x4_per_frame": sads},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args.size, sr) if bd == 8 else None,
-                         "kernel": "me_search_kernel<1, 0>" if bd == 8 else "me_search16_kernel<1,*> (+ finalize)",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": int(traffic) if traffic is not None else None,
+                         "kernel": "me_search_kernel<1, 0>" if bd == 8 else "me_search16_kernel<1,*> (+ merge-table preset and finalize)",
                          "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "kernel is VALU-bound (1664 abs-diff ops per unique input byte, SURVEY 8d); "
-                                 "see DESIGN.md for the VALU-issue roofline"},
+                         "note": "kernel is VALU-bound (1664 abs-diff ops per unique input byte at SR 64, SURVEY 8d); "
+                                 "see valu_roofline and DESIGN.md 5 for the instruction-issue roofline"},
         }
-        prof = pmc_profile(args.size, sr) if bd == 8 else {}
-        if prof.get("valu_busy_frac") is not None:   # what actually binds: integer VALU issue
-            out["valu_roofline"] = {"bound": "valu-issue", "valu_busy_frac": round(prof["valu_busy_frac"], 4),
-                                    "valu_wave_instructions_per_launch": int(prof["valu_wave_instructions_per_launch"]),
-                                    "effective_clock_ghz": round(prof.get("effective_clock_ghz", 0.0), 3),
-                                    # every candidate touches each of the CTU's 4096 samples once (FEN halves nothing in the kernel:
-                                    # the even-row sums are the first half of the full sums)
-                                    "abs_diff_per_s": round(sads * 16 / (kernel_ms * 1e-3), 0),
-                                    "frac_of_nominal_sad_u8_peak": round(sads * 16 / (kernel_ms * 1e-3) / 314.6e12, 4),
-                                    "nominal_peak_note": "314.6e12 abs-diff/s = SURVEY 8d's paper figure (v_sad_u8 at 2 cycles per wave-instruction); "
-                                                         "measured issue rates are 4.3 cycles (v_sad_u8) / 16 cycles per 16 abs-diffs (v_qsad_pk_u16_u8), "
-                                                         "i.e. a SAD-only ceiling of 0.25 of that figure (DESIGN.md 5)",
-                                    "source": "profiles/latest_pmc_%s_sr%d.json (rocprofv3 --pmc passes of this command)" % (args.size, sr)}
+        if prof.get("stale"):
+            out["roofline"]["traffic_note"] = "profiles/latest_pmc_* was taken from other kernel sources than this build: counters withheld"
+        if kprof.get("valu_busy_frac") is not None:   # what actually binds: integer VALU issue
+            # abs-diff operations the kernel performs: every candidate touches each of the CTU's 4096 samples once (FEN halves
+            # nothing in the kernel: the even-row sums are the first half of the full sums)
+            absdiff = sads * 16 / (kernel_ms * 1e-3)
+            # measured SAD-only ceiling (profiles/r01_valu_lds_rates_ubench.txt, 2 waves/SIMD): v_qsad_pk_u16_u8 issues 0.55
+            # wave-instructions per ns and CU, 1024 abs-diffs each -> 144e12 abs-diff/s on 256 CUs; v_sad_u16 0.93 per ns and CU
+            # (4.3 cycles), 128 abs-diffs each -> 30.5e12
+            ceiling = 144.2e12 if bd == 8 else 30.5e12
+            out["valu_roofline"] = {"bound": "valu-issue", "valu_busy_frac": round(kprof["valu_busy_frac"], 4),
+                                    "valu_wave_instructions_per_launch": int(kprof["valu_wave_instructions_per_launch"]),
+                                    "effective_clock_ghz": round(kprof.get("effective_clock_ghz", 0.0), 3),
+                                    "abs_diff_per_s": round(absdiff, 0),
+                                    "sad_only_ceiling_abs_diff_per_s": ceiling,
+                                    "frac_of_sad_only_ceiling": round(absdiff / ceiling, 4),
+                                    "frac_of_nominal_sad_u8_peak": round(absdiff / 314.6e12, 4),
+                                    "note": "sad_only_ceiling = the measured issue rate of the leaf instruction alone (v_qsad_pk_u16_u8 / v_sad_u16 "
+                                            "micro-benchmarks under profiles/), i.e. a kernel whose reduction tree and arg-min cost nothing; it is "
+                                            "0.46 (u8) of SURVEY 8d's paper figure 314.6e12 (v_sad_u8 at 2 cycles per wave-instruction)",
+                                    "source": "profiles/latest_pmc_%s.json (rocprofv3 --pmc passes of this command, same kernel sources: %s)"
+                                              % (profile_label(args.size, sr, bd), kernel_source_hash())}
         # the step after the path, reported beside the headline, never part of `value`
         d_q = torch.zeros((n_refs, n_ctu, api.NUM_PARTS, 2), dtype=torch.int16, device=dev)
         d_c = torch.zeros((n_refs, n_ctu, api.NUM_PARTS), dtype=torch.int32, device=dev)
-        d_mv16 = bufs[(state["k"] - 1) & 1][0].view(torch.int16).contiguous()   # TComMv words -> int16 (x, y) pairs
+        last = pipe.last_local
+        d_mv16 = last[0].view(torch.int16).contiguous()   # TComMv words -> int16 (x, y) pairs
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         for i in range(4):
             if i == 1:
@@ -302,7 +335,15 @@ def main():
         out["refine"] = {"what": "xPatternSearchFracDIF (half + quarter-pel, Hadamard) for all 593 slots of every CTU, on the integer winners",
                          "kernel": "me_frac_kernel<1, %d>" % (1 if bd == 8 else 2), "ms_per_step": round(r_ms, 4),
                          "slots_per_s": round(n_ctu * n_refs * api.NUM_PARTS / (r_ms * 1e-3))}
+        fprof = prof.get("kernels", {}).get("me_frac_kernel", {})
+        if fprof.get("hbm_traffic_bytes_per_launch") is not None:
+            out["refine"]["hbm_traffic_bytes_per_launch"] = int(fprof["hbm_traffic_bytes_per_launch"])
+            out["refine"]["valu_busy_frac"] = round(fprof.get("valu_busy_frac", 0.0), 4)
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only: the other ranks would wait on it
+            # what was timed is what is reported: tables of the LAST timed step against the CPU oracle on a CTU sample
+            # (corner, interior, partial bottom row); a mismatch fails the run
+            res = last.cpu().numpy()
+            out["verified"] = verify_against_oracle(res, cur, ref, w, h, sr, lq, bd)
             out["cpu_baseline"] = cpu_baseline(cur, ref, w, h, sr, lq, bd)
         print(json.dumps(out), flush=True)
     pc.close()

@@ -33,7 +33,7 @@ constexpr size_t kLdsBudget16 = 78 * 1024;   // per workgroup of the 16-bit path
 // 130 = 2 * 33 lanes-per-row + 64: with the kernel's linear lane packing every lane of a 129-wide even-column pass lands on
 // its own bank pair (measured +1.5 % over 98); the same trick for 257-wide windows (194) costs more strips than it saves
 constexpr int kPdw16Small = 130, kPdw16Large = 162;
-std::string g_create_error;
+thread_local std::string g_create_error;   // hmme_last_error(NULL): per host thread, like the contexts themselves
 }  // namespace
 
 struct hmme_ctx {
@@ -357,7 +357,7 @@ void hmme_params_ocl_compat(hmme_search_params* p, int lt_x, int lt_y, int sr) {
   // TEncOpenCL.cpp:312-313 scans [0, 2*SR] from LT and never reads RB; cl/sad.cl:374-398 prices the MV
   // against (0,0); no row sub-sampling, no bit-depth shift
   p->lt_x = lt_x; p->lt_y = lt_y; p->rb_x = lt_x + 2 * sr; p->rb_y = lt_y + 2 * sr;
-  p->pred_x = 0; p->pred_y = 0; p->fen = 0; p->bit_depth = 8;
+  p->pred_x = 0; p->pred_y = 0; p->fen = 0; p->bit_depth = 8; p->shift_free = 1;
 }
 
 void hmme_set_search_range(int pred_x_q, int pred_y_q, int sr, int cu_x, int cu_y, int pic_w, int pic_h, int* lt_x,
@@ -428,6 +428,13 @@ int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
   if (!ctx) return HMME_ERR_ARG;
   if (!ctu || !ref0 || !p || !out_mv || !out_sad) return fail(ctx, HMME_ERR_ARG, "hmme_search_ctu: null argument");
   if (p->bit_depth < 8 || p->bit_depth > 12) return fail(ctx, HMME_ERR_UNSUPPORTED, "bit depth %d outside 8..12", p->bit_depth);
+  // MeJob carries the window and the predictor as int16 (what TComMv holds, TComMv.h:51-55): anything wider would address
+  // the staged window at a truncated offset
+  {
+    const int v[6] = {p->lt_x, p->lt_y, p->rb_x, p->rb_y, p->pred_x, p->pred_y};
+    for (int i = 0; i < 6; ++i)
+      if (v[i] < -32768 || v[i] > 32767) return fail(ctx, HMME_ERR_ARG, "hmme_search_ctu: window / predictor component %d outside int16", v[i]);
+  }
   const int maxv = (1 << p->bit_depth) - 1;
   // samples outside [0, maxv] are the bi-prediction origin 2*org - pred_other (reference TEncSearch.cpp:3702-3712,
   // TComYuv::removeHighFreq TComYuv.cpp:409-440, unclipped).  They stay exact: the 16-bit kernel runs on samples
@@ -444,6 +451,10 @@ int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
     return fail(ctx, HMME_ERR_RANGE, "hmme_search_ctu: current-block sample outside [%d, %d] (bit depth %d)", -maxv, 2 * maxv, p->bit_depth);
   const bool wide = p->bit_depth > 8 || bipred_origin;
   const int bias = bipred_origin ? (1 << p->bit_depth) : 0;
+  // unshifted sums must fit the 24-bit cost field of the 16-bit kernel's keys (me_kernels.hpp kInvCost16)
+  if (p->shift_free && p->bit_depth > (bipred_origin ? 9 : 10))
+    return fail(ctx, HMME_ERR_UNSUPPORTED, "shift-free SADs at bit depth %d%s", p->bit_depth, bipred_origin ? " with a bi-prediction origin" : "");
+  const int shift_bd = p->shift_free ? 8 : p->bit_depth;   // the kernels shift by (this - 8)
   const int sr_cap = ctx->sr_max;
   if (wx < 1 || wy < 1 || wx > 2 * sr_cap + 1 || wy > 2 * sr_cap + 1)
     return fail(ctx, HMME_ERR_ARG, "window %dx%d outside 1..%d", wx, wy, 2 * sr_cap + 1);
@@ -527,7 +538,7 @@ int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
   if (!wide)
     rc = launch_search8_split(ctx, ctx->d_call + kCallCtu, 64, one_ref(ref_base), kWinPitch, d_js, d_first, 1, n_wg, p->fen, d_mv1, d_sad1, s, d_best1, false);
   else
-    rc = launch_search16(ctx, ctx->d_call + kCallCtu, 128, one_ref(ref_base), kWinPitch, d_js, d_first, 1, n_wg, pdw, smax, p->fen, p->bit_depth,
+    rc = launch_search16(ctx, ctx->d_call + kCallCtu, 128, one_ref(ref_base), kWinPitch, d_js, d_first, 1, n_wg, pdw, smax, p->fen, shift_bd,
                          d_mv1, d_sad1, s, d_best1, false);
   if (rc) return rc;
   volatile uint32_t* done = (volatile uint32_t*)(ctx->h_res + 8 * HMME_NUM_CTU_PARTS);

@@ -145,8 +145,11 @@ __device__ __forceinline__ uint32_t me_mv_cost(uint32_t lambda_q16, int x, int y
   return (lambda_q16 * (me_component_bits((x << 2) - pred_x) + me_component_bits((y << 2) - pred_y))) >> 16;
 }
 
-constexpr int kIdxBits16 = 9;              // key = cost << 9 | iter(1) | lane(6) | j(2): 23-bit cost field
-constexpr uint32_t kInvCost16 = 4000000u;  // > any valid cost (bi-pred origins: <= 3 142 656 + 65 535); + max SAD < 2^23
+constexpr int kIdxBits16 = 8;              // key = cost << 8 | iter(1) | lane(6) | j(1): 24-bit cost field
+// > any valid cost: bi-pred origins <= 3 142 656 + 65 535; shift-free 10-bit sums (hmme_search_params::shift_free, what
+// cl/sad.cl computes) <= 4 190 208 + 65 535; shift-free 9-bit bi-pred origins <= 6 279 168 + 65 535.  kInvCost16 + the
+// largest sum an invalid lane can add (6 279 168) stays < 2^24
+constexpr uint32_t kInvCost16 = 8000000u;
 constexpr int kIterPerTask16 = kIterPerTask < 2 ? kIterPerTask : 2;
 
 // a CTU search cut into several workgroups: the 16-bit path cuts by candidate rows (LDS capacity), the 8-bit path
@@ -405,7 +408,7 @@ __global__ void me_fill_plane_kernel(uint8_t* __restrict__ dst, int dst_pitch, i
 // ---- 16-bit sample path (bit depth 9..12) -----------------------------------------------------------------
 // Same task / key / butterfly / merge machinery as me_search_kernel; differences (see tools/gen_me_tree.py,
 // class Tree16): v_sad_u16 leaves on u16 samples, two candidates per lane, exact 32-bit sums and
-//   key = ((sum << fen_shift) >> (bitDepth-8)) << 10 + c     (reference TComRdCost.cpp:520-521),
+//   key = ((sum << fen_shift) >> (bitDepth-8)) << kIdxBits16 + c     (reference TComRdCost.cpp:520-521),
 // lanes packed linearly over the window (candidate pair q = iteration*64 + lane), and the window is cut into
 // horizontal strips of candidate rows so that one strip's reference rows fit LDS (SR 128: 320 x 322 samples);
 // strips of a CTU are separate workgroups that merge through 64-bit atomicMin on a global table.
@@ -448,7 +451,7 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const Re
     const int r = i >> 3, q = i & 7;
     curl[i] = *(const u32x4_t*)(cur_base + (long)(job.ctu_y + r) * cur_pitch + 2 * job.ctu_x + 16 * q);
   }
-  // key = ((sum & mask) << lsh) + c  ==  (((sum << fen_shift) >> sh) << 10) + c
+  // key = ((sum & mask) << lsh) + c  ==  (((sum << fen_shift) >> sh) << kIdxBits16) + c
   const uint32_t mask_a = ~((1u << sh) - 1u), lsh_a = kIdxBits16 - sh;
   const uint32_t mask_e = FEN ? ~((1u << (sh > 0 ? sh - 1 : 0)) - 1u) : mask_a, lsh_e = FEN ? kIdxBits16 + 1 - sh : lsh_a;
   const bool rb1 = lane & 2, rb0 = lane & 1;
@@ -498,7 +501,7 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const Re
       const bool vy = row < ny;
       const int mvy = job.lt_y + cy, mvx = job.lt_x + cx;
       const uint32_t by = me_component_bits((mvy << 2) - job.pred_y);
-      const uint32_t tag = ((uint32_t)it << 8) | ((uint32_t)lane << 2);
+      const uint32_t tag = ((uint32_t)it << 7) | ((uint32_t)lane << 1);
       uint32_t cc[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -519,9 +522,9 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const Re
       const uint32_t key = (key_);                                                                                 \
       const uint32_t cost = key >> kIdxBits16;                                                                       \
       if (slot >= 0 && cost < kInvCost16) {                                                                          \
-        const int kq = (it0 + (int)((key >> 8) & 1)) * 64 + (int)((key >> 2) & 63);                                \
+        const int kq = (it0 + (int)((key >> 7) & 1)) * 64 + (int)((key >> 1) & 63);                                \
         const int krow = kq / pairs;                                                                               \
-        const int bx = par + 4 * (kq - krow * pairs) + 2 * (int)(key & 3);                                         \
+        const int bx = par + 4 * (kq - krow * pairs) + 2 * (int)(key & 1);                                         \
         atomicMin(&best64[slot], ((unsigned long long)cost << 32) | ((unsigned long long)(jb.y0 + krow) << 16) |   \
                                      (unsigned long long)bx);                                                      \
       }                                                                                                            \

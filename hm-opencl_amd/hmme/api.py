@@ -30,7 +30,8 @@ class HmmeError(RuntimeError):
 
 class SearchParams(C.Structure):
     _fields_ = [("lt_x", C.c_int), ("lt_y", C.c_int), ("rb_x", C.c_int), ("rb_y", C.c_int),
-                ("pred_x", C.c_int), ("pred_y", C.c_int), ("fen", C.c_int), ("bit_depth", C.c_int)]
+                ("pred_x", C.c_int), ("pred_y", C.c_int), ("fen", C.c_int), ("bit_depth", C.c_int),
+                ("shift_free", C.c_int)]
 
 
 class FrameParams(C.Structure):

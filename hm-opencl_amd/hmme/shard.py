@@ -80,9 +80,9 @@ def gather_packed(buf, out=None, async_op=False):
     plane 1 = SADs) of this rank; returns (out int32 [world, 2, k, n_ctu, 593], work-or-None).
     With async_op=True the gather runs on RCCL's stream while the caller launches the next search
     (the handle's wait() is a stream-side dependency, not a host block)."""
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return buf.unsqueeze(0), None
+    world = dist.get_world_size()   # a world of 1 still goes through the collective (bench.py's one-GPU rehearsal of the RCCL calls)
     if out is None:
         out = torch.empty((world,) + tuple(buf.shape), dtype=buf.dtype, device=buf.device)
     flat_out = out.view((world * buf.shape[0],) + tuple(buf.shape[1:]))
@@ -93,6 +93,61 @@ def gather_packed(buf, out=None, async_op=False):
         return out, None
     work = dist.all_gather_into_tensor(flat_out, buf, async_op=async_op)
     return out, work
+
+
+class PipelinedGather:
+    """Double-buffered result exchange of a stream of search steps (bench.py --gpus N, an open-loop ME pass).
+
+    Step k writes its tables into local buffer k % 2 and starts their all-gather; the gather runs on the collective
+    backend's own stream / thread while step k+1 searches into the other buffer, so the 9.7 MB per rank and 2160p
+    pair never stall the search kernel.  Before buffer b is written again (step k+2) the gather that read it (step k)
+    is waited for -- with RCCL a stream-side dependency, not a host block -- and only then is its gathered block
+    handed to `consume` and recycled.
+
+    make_local() -> tensor            this rank's [2, k, n_ctu, 593] int32 block (plane 0 TComMv words, plane 1 SADs)
+    launch(buf, step)                 enqueue the search of step `step` writing into buf (engine call; tests: a stand-in)
+    consume(step, gathered) or None   gathered = [world, ...] block of `step`, valid only during the call
+    """
+
+    def __init__(self, make_local, distributed, async_op=True):
+        self.world = dist.get_world_size() if (distributed and dist.is_initialized()) else 1
+        self.distributed = bool(distributed)
+        self.async_op = async_op
+        self.bufs = [make_local(), make_local()]
+        self.gathered = [torch.empty((self.world,) + tuple(b.shape), dtype=b.dtype, device=b.device) if self.distributed else None
+                         for b in self.bufs]
+        self.pending = [None, None]     # (step, work-or-None) of the gather that last used buffer b
+        self.k = 0
+
+    def _retire(self, b, consume):
+        if self.pending[b] is None:
+            return
+        step, work = self.pending[b]
+        if work is not None:
+            work.wait()
+        self.pending[b] = None
+        if consume is not None:
+            consume(step, self.gathered[b] if self.distributed else self.bufs[b].unsqueeze(0))
+
+    def step(self, launch, consume=None):
+        b = self.k & 1
+        self._retire(b, consume)        # the gather that read bufs[b] (two steps ago) is done before bufs[b] is overwritten
+        launch(self.bufs[b], self.k)
+        work = None
+        if self.distributed:   # the one exchange step of the path: tables of all `world` pairs to every rank
+            _, work = gather_packed(self.bufs[b], self.gathered[b], async_op=self.async_op)
+        self.pending[b] = (self.k, work)
+        self.k += 1
+        return b
+
+    def drain(self, consume=None):
+        for b in ((self.k & 1), (self.k & 1) ^ 1):   # oldest first
+            self._retire(b, consume)
+
+    @property
+    def last_local(self):
+        """this rank's buffer of the most recent step"""
+        return self.bufs[(self.k - 1) & 1]
 
 
 def search_sequence(search_pair, n_pairs, n_ctu, device):

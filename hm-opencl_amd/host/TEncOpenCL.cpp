@@ -9,16 +9,19 @@
 
 TEncOpenCL::TEncOpenCL()
     : m_ctx(0), m_deviceId(0), m_deviceFound(false), m_enabled(false), m_lastOk(false), m_searchRange(0),
-      m_mode(ME_MODE_OCL_COMPAT), m_fen(false), m_bitDepth(8), m_lambda(0.0), m_calls(0), m_failed(0) {
-  std::memset(m_x, 0, sizeof m_x);
-  std::memset(m_y, 0, sizeof m_y);
-  std::memset(m_ruiCosts, 0, sizeof m_ruiCosts);
+      m_mode(ME_MODE_OCL_COMPAT), m_fen(false), m_bitDepth(0), m_bi(0), m_lambda(0.0), m_calls(0), m_failed(0), m_edgeCalls(0),
+      m_biCalls(0) {
+  for (Int b = 0; b < 2; b++) {
+    xPoison(m_tab[b]);   // tables nobody filled yet must not look like results either
+  }
+  for (Int l = 0; l < 2; l++)
+    for (Int r = 0; r < 33; r++) { m_tagPoc[l][r] = -0x7fffffff; m_tagCtu[l][r] = -1; }
 }
 
 TEncOpenCL::~TEncOpenCL() {
   if (std::getenv("HMME_TRACE"))   // one summary line for A/B harnesses (tests/test_hm_dropin.py)
-    fprintf(stderr, "TEncOpenCL(hmme): %ld calcMotionVectors calls, %ld failed, device: %s\n", m_calls, m_failed,
-            m_ctx ? hmme_device_info(m_ctx) : "none");
+    fprintf(stderr, "TEncOpenCL(hmme): %ld calcMotionVectors calls, %ld failed, %ld edge-CTU, %ld bi-pred, device: %s\n", m_calls, m_failed,
+            m_edgeCalls, m_biCalls, m_ctx ? hmme_device_info(m_ctx) : "none");
   if (m_ctx) hmme_destroy(m_ctx);
   m_ctx = 0;
 }
@@ -60,38 +63,88 @@ Void TEncOpenCL::setLambda(Double lambda) {   // reference TEncOpenCL.h:121
   if (m_ctx) hmme_set_lambda(m_ctx, lambda);
 }
 
+// A failed call must never leave the previous CTU's results behind: the reference caller copies the tables without looking
+// at any status (TEncSearch.cpp:3749-3765).  MV (0,0) and the largest Distortion cannot win a comparison by accident.
+Void TEncOpenCL::xPoison(Tables& t) {
+  for (Int i = 0; i < NUM_CTU_PARTS; i++) {
+    t.x[i] = 0; t.y[i] = 0;
+    t.cost[i] = (Distortion)~(Distortion)0;
+    t.mv[i].set(0, 0);
+  }
+}
+
 // reference TEncOpenCL.cpp:240-362.  pelSearch = reference plane at the CTU origin, i_areaSize = search range,
 // *pcMvSrchRngLT = integer-pel top-left of the window.
 Void TEncOpenCL::calcMotionVectors(Pel* pelCtu, Pel* pelSearch, Int iRefStride, Int iCtuStride, Int i_areaSize,
                                    TComMv* pcMvSrchRngLT) {
+  Tables& t = m_tab[m_bi];
   m_lastOk = false;
   ++m_calls;
   ++m_failed;
+  if (m_bi) ++m_biCalls;
   if (!m_ctx) {
     fprintf(stderr, "ERROR: TEncOpenCL::calcMotionVectors called without a device context\n");
+    xPoison(t);
     return;
   }
   hmme_search_params p;
   if (m_mode == ME_MODE_OCL_COMPAT) {
     hmme_params_ocl_compat(&p, pcMvSrchRngLT->getHor(), pcMvSrchRngLT->getVer(), i_areaSize);
+    p.bit_depth = m_bitDepth;
+    if (m_bitDepth <= 0) {
+      // nothing in the reference tree tells this class the bit depth (createBuffers has no such argument), and cl/sad.cl
+      // works on whatever Pel holds without a shift: take the sample width from the reference window itself
+      Int hi = 0;
+      const Int side = 2 * i_areaSize + 64;   // the window the reference copies, TEncOpenCL.cpp:253-277
+      const Pel* row = pelSearch + (long)p.lt_y * iRefStride + p.lt_x;
+      for (Int y = 0; y < side; y++, row += iRefStride)
+        for (Int x = 0; x < side; x++) hi = row[x] > hi ? row[x] : hi;
+      p.bit_depth = 8;
+      while (p.bit_depth < 12 && hi > (1 << p.bit_depth) - 1) ++p.bit_depth;
+    }
   } else {
     p.lt_x = pcMvSrchRngLT->getHor(); p.lt_y = pcMvSrchRngLT->getVer();
     p.rb_x = m_rb.getHor(); p.rb_y = m_rb.getVer();
     p.pred_x = m_pred.getHor(); p.pred_y = m_pred.getVer();
     p.fen = m_fen ? 1 : 0;
+    p.bit_depth = m_bitDepth > 0 ? m_bitDepth : 8;
+    p.shift_free = 0;
   }
-  p.bit_depth = m_bitDepth;
-  typedef char tcommv_is_two_shorts[sizeof(TComMv) == 4 ? 1 : -1];   // C++98-friendly static assert
-  (void)sizeof(tcommv_is_two_shorts);
-  if (hmme_search_ctu(m_ctx, pelCtu, iCtuStride, pelSearch, iRefStride, &p, reinterpret_cast<int16_t*>(m_mv), m_ruiCosts) !=
-      HMME_OK) {
+  typedef char tcommv_is_two_shorts[sizeof(TComMv) == 4 ? 1 : -1];   // C++98-friendly static asserts
+  typedef char distortion_is_u32[sizeof(Distortion) == 4 ? 1 : -1];
+  (void)sizeof(tcommv_is_two_shorts); (void)sizeof(distortion_is_u32);
+  if (hmme_search_ctu(m_ctx, pelCtu, iCtuStride, pelSearch, iRefStride, &p, reinterpret_cast<int16_t*>(t.mv),
+                      reinterpret_cast<uint32_t*>(t.cost)) != HMME_OK) {
     fprintf(stderr, "ERROR: TEncOpenCL::calcMotionVectors: %s\n", hmme_last_error(m_ctx));
+    xPoison(t);
     return;
   }
   for (Int i = 0; i < NUM_CTU_PARTS; i++) {   // the reference hands out Int arrays (TEncOpenCL.h:118-119)
-    m_x[i] = m_mv[i].getHor();
-    m_y[i] = m_mv[i].getVer();
+    t.x[i] = t.mv[i].getHor();
+    t.y[i] = t.mv[i].getVer();
   }
   m_lastOk = true;
   --m_failed;
+}
+
+Void TEncOpenCL::calcMotionVectorsEdge(const Pel* pelCtuInPic, Int iPicStride, Int validW, Int validH, Pel* pelSearch, Int iRefStride,
+                                       Int i_areaSize, const TComMv& pred, Int ctuX, Int ctuY, Int picW, Int picH) {
+  Pel block[HMME_CTU_SIZE * HMME_CTU_SIZE];
+  validW = validW < 1 ? 1 : (validW > HMME_CTU_SIZE ? HMME_CTU_SIZE : validW);
+  validH = validH < 1 ? 1 : (validH > HMME_CTU_SIZE ? HMME_CTU_SIZE : validH);
+  for (Int y = 0; y < HMME_CTU_SIZE; y++) {
+    const Pel* src = pelCtuInPic + (long)(y < validH ? y : validH - 1) * iPicStride;
+    for (Int x = 0; x < HMME_CTU_SIZE; x++) block[y * HMME_CTU_SIZE + x] = src[x < validW ? x : validW - 1];
+  }
+  Int ltx, lty, rbx, rby;   // xSetSearchRange + clipMv at the CTU origin (TEncSearch.cpp:3814-3830, TComDataCU.cpp:2907-2920)
+  hmme_set_search_range(pred.getHor(), pred.getVer(), i_areaSize, ctuX, ctuY, picW, picH, &ltx, &lty, &rbx, &rby);
+  const CostMode mode = m_mode;
+  const TComMv savePred = m_pred, saveRb = m_rb;
+  TComMv lt((Short)ltx, (Short)lty);
+  m_mode = ME_MODE_HM;
+  m_pred = pred;
+  m_rb.set((Short)rbx, (Short)rby);
+  ++m_edgeCalls;
+  calcMotionVectors(block, pelSearch, iRefStride, HMME_CTU_SIZE, i_areaSize, &lt);
+  m_mode = mode; m_pred = savePred; m_rb = saveRb;
 }

@@ -41,9 +41,9 @@ class TEncOpenCL {
   Int getDeviceId() { return m_deviceId; }
   Void setDeviceId(Int i) { m_deviceId = i; }
   const Char* getDeviceInfo();
-  Distortion* getRuiCost() { return m_ruiCosts; }
-  Int* getX() { return m_x; }
-  Int* getY() { return m_y; }
+  Distortion* getRuiCost() { return m_tab[m_bi].cost; }
+  Int* getX() { return m_tab[m_bi].x; }
+  Int* getY() { return m_tab[m_bi].y; }
   Void setLambda(Double lambda);
   Void setEnabled(Bool e) { m_enabled = e; }
 
@@ -52,12 +52,49 @@ class TEncOpenCL {
   Void setPredictor(const TComMv& pred) { m_pred = pred; }          // m_pcRdCost->setPredictor, TEncSearch.cpp:3737
   Void setSearchRangeRB(const TComMv& rb) { m_rb = rb; }            // cMvSrchRngRB, TEncSearch.cpp:3732
   Void setFastEnc(Bool b) { m_fen = b; }                            // getUseFastEnc(), TEncSearch.cpp:3853
+  /// sample bit depth (SPS).  0 = unknown (the default: nothing in the reference tree tells this class): ME_MODE_OCL_COMPAT
+  /// then derives the sample width from the reference window and, like cl/sad.cl, never shifts the SAD; ME_MODE_HM assumes 8.
   Void setBitDepth(Int b) { m_bitDepth = b; }
   /// results in TComMv layout, ready for memcpy into TEncSearch::allMotionVectors[list][refIdx]
-  const TComMv* getMvs() const { return m_mv; }
+  const TComMv* getMvs() const { return m_tab[m_bi].mv; }
   Bool lastCallOk() const { return m_lastOk; }
 
+  // ---- additive: bi-prediction refinement ----
+  /// The bi-prediction pass (bBi, TEncSearch.cpp:3221) searches 2*org - pred_other with BipredSearchRange around the
+  /// uni-prediction winner.  While setBiPred(true), calcMotionVectors fills -- and the getters return -- a SECOND table set,
+  /// so the uni-prediction tables of that [list][refIdx] (filled at TEncSearch.cpp:3760-3764) are not clobbered.
+  Void setBiPred(Bool b) { m_bi = b ? 1 : 0; }
+  Bool getBiPred() const { return m_bi != 0; }
+  const TComMv* getMvs(Bool bi) const { return m_tab[bi ? 1 : 0].mv; }
+  const Distortion* getRuiCost(Bool bi) const { return m_tab[bi ? 1 : 0].cost; }
+
+  // ---- additive: picture-edge CTUs ----
+  /// A CTU that crosses the picture border is never coded as one 64x64 CU (TEncCu.cpp:424-425), so the reference never
+  /// sends it to the GPU and its sub-CUs look up the PREVIOUS CTU's tables.  This runs the same search for such a CTU:
+  /// pelCtuInPic = original picture at the CTU origin (only validW x validH samples are read; the rest of the 64x64
+  /// block replicates the last valid column / row), window from xSetSearchRange + clipMv at the CTU origin
+  /// (ME_MODE_HM arithmetic, predictor = pred).  Only slots inside the picture are meaningful -- the only ones HM looks up.
+  Void calcMotionVectorsEdge(const Pel* pelCtuInPic, Int iPicStride, Int validW, Int validH, Pel* pelSearch, Int iRefStride,
+                             Int i_areaSize, const TComMv& pred, Int ctuX, Int ctuY, Int picW, Int picH);
+  /// which (picture, CTU) the caller's tables of [list][refIdx] were computed for (the caller owns the tables,
+  /// TEncSearch.h:114-115; the tags live here so that TEncSearch.h stays untouched)
+  Bool tablesValidFor(Int list, Int refIdx, Int poc, Int ctuAddr) const {
+    return list >= 0 && list < 2 && refIdx >= 0 && refIdx < 33 && m_tagPoc[list][refIdx] == poc && m_tagCtu[list][refIdx] == ctuAddr;
+  }
+  Void markTables(Int list, Int refIdx, Int poc, Int ctuAddr) {
+    if (list >= 0 && list < 2 && refIdx >= 0 && refIdx < 33) { m_tagPoc[list][refIdx] = poc; m_tagCtu[list][refIdx] = ctuAddr; }
+  }
+  long numCalls() const { return m_calls; }
+  long numFailed() const { return m_failed; }
+
  protected:
+  struct Tables {
+    Int x[NUM_CTU_PARTS], y[NUM_CTU_PARTS];
+    Distortion cost[NUM_CTU_PARTS];
+    TComMv mv[NUM_CTU_PARTS];
+  };
+  Void xPoison(Tables& t);
+
   hmme_ctx* m_ctx;
   Int m_deviceId;
   Bool m_deviceFound, m_enabled, m_lastOk;
@@ -66,11 +103,11 @@ class TEncOpenCL {
   TComMv m_pred, m_rb;
   Bool m_fen;
   Int m_bitDepth;
+  Int m_bi;
   Double m_lambda;
-  long m_calls, m_failed;
-  Int m_x[NUM_CTU_PARTS], m_y[NUM_CTU_PARTS];
-  Distortion m_ruiCosts[NUM_CTU_PARTS];
-  TComMv m_mv[NUM_CTU_PARTS];
+  long m_calls, m_failed, m_edgeCalls, m_biCalls;
+  Tables m_tab[2];                     // [0] uni-prediction, [1] bi-prediction refinement
+  Int m_tagPoc[2][33], m_tagCtu[2][33];
 };
 
 #endif

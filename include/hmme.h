@@ -31,6 +31,13 @@
  * window LT..LT+2*SR, all rows).
  *
  * Threading: a context is not thread-safe; use one per host thread / per GPU.
+ * Streams: a context owns scratch (job tables, merge tables, staging) that every call reuses, so at most ONE
+ * stream may have work of a given context in flight at a time: before a *_device call on stream B, work this
+ * context put on stream A must have completed (or B must wait on an event recorded on A after it).  The
+ * synchronous host-facing calls (hmme_search_ctu, hmme_search_frame*, hmme_refine_frame, hmme_plane_upload_*)
+ * run on a private non-blocking stream of the context and return when done; they are NOT ordered after work the
+ * caller queued on its own streams -- synchronise a hmme_plane_set_device_u8 (or any *_device call whose output
+ * they read) before calling them.
  * Every function returns HMME_OK (0) or a negative HMME_ERR_* code; nothing ever falls back
  * to a CPU implementation.
  */
@@ -51,7 +58,7 @@ extern "C" {
 
 enum {
   HMME_OK = 0,
-  HMME_ERR_ARG = -1,     /* invalid argument (null pointer, window larger than sr_max, ...) */
+  HMME_ERR_ARG = -1,     /* invalid argument (null pointer, window larger than sr_max, window / predictor beyond int16, ...) */
   HMME_ERR_DEVICE = -2,  /* no usable gfx950 device / HIP runtime error */
   HMME_ERR_RANGE = -3,   /* sample outside the range of the bit depth (bi-prediction origins of hmme_search_ctu excepted) */
   HMME_ERR_NOMEM = -4,
@@ -68,6 +75,8 @@ typedef struct hmme_search_params {
   int pred_x, pred_y;  /* m_pcRdCost->setPredictor(*pcMvPred), quarter pels (TEncSearch.cpp:3737) */
   int fen;             /* m_pcEncCfg->getUseFastEnc() (TEncSearch.cpp:3853-3859) */
   int bit_depth;       /* 8 (packed-byte path) or 9..12 (16-bit path): SAD >> (bitDepth-8), TComRdCost.cpp:520-521 */
+  int shift_free;      /* 1: no >> (bitDepth-8) on the SAD -- what cl/sad.cl computes for any Pel width;
+                          bit_depth then only states the sample range.  Bit depth <= 10 (<= 9 with bi-prediction origins) */
 } hmme_search_params;
 
 /* one whole-picture search: window derived per CTU from the predictor exactly like
@@ -83,7 +92,7 @@ typedef struct hmme_frame_params {
 /* ---- context ------------------------------------------------------------------------- */
 int hmme_create(int device, int sr_max, unsigned flags, hmme_ctx** out);
 void hmme_destroy(hmme_ctx* ctx);
-const char* hmme_last_error(const hmme_ctx* ctx); /* ctx may be NULL: error of the last failed hmme_create */
+const char* hmme_last_error(const hmme_ctx* ctx); /* ctx may be NULL: error of the calling thread's last failed hmme_create */
 const char* hmme_device_info(const hmme_ctx* ctx);
 int hmme_set_lambda(hmme_ctx* ctx, double lambda);         /* m_lambda = floor(65536*sqrt(lambda)) */
 int hmme_set_lambda_q16(hmme_ctx* ctx, uint32_t lambda_q16);

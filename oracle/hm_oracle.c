@@ -35,7 +35,7 @@ uint32_t hmo_lambda_q16(double lambda) { return (uint32_t)floor(65536.0 * sqrt(l
 /* TComRdCost::getCost(x,y) / getBits, TComRdCost.h:172-189:
  *   m_uiCost * (bits((x<<scale)-pred.x) + bits((y<<scale)-pred.y)) >> 16   in UInt (wraps). */
 uint32_t hmo_mv_cost(uint32_t lambda_q16, int x, int y, int pred_x, int pred_y, int scale) {
-  uint32_t bits = hmo_component_bits((x << scale) - pred_x) + hmo_component_bits((y << scale) - pred_y);
+  uint32_t bits = hmo_component_bits(x * (1 << scale) - pred_x) + hmo_component_bits(y * (1 << scale) - pred_y);
   return (uint32_t)(lambda_q16 * bits) >> 16;
 }
 
@@ -186,10 +186,11 @@ static int imax(int a, int b) { return a > b ? a : b; }
  * Short, so the result is narrowed like TComMv::setHor does. */
 void hmo_clip_mv(int* mvx_q, int* mvy_q, int cu_x, int cu_y, int pic_w, int pic_h, int max_cu) {
   const int shift = 2, offset = 8;
-  const int hor_max = (pic_w + offset - cu_x - 1) << shift;
-  const int hor_min = (-max_cu - offset - cu_x + 1) << shift;
-  const int ver_max = (pic_h + offset - cu_y - 1) << shift;
-  const int ver_min = (-max_cu - offset - cu_y + 1) << shift;
+  /* `* (1 << shift)`: the reference shifts negative values left (`<< mvShift`), which C leaves undefined; same arithmetic */
+  const int hor_max = (pic_w + offset - cu_x - 1) * (1 << shift);
+  const int hor_min = (-max_cu - offset - cu_x + 1) * (1 << shift);
+  const int ver_max = (pic_h + offset - cu_y - 1) * (1 << shift);
+  const int ver_min = (-max_cu - offset - cu_y + 1) * (1 << shift);
   *mvx_q = (int16_t)imin(hor_max, imax(hor_min, *mvx_q));
   *mvy_q = (int16_t)imin(ver_max, imax(ver_min, *mvy_q));
 }
@@ -461,11 +462,11 @@ long hmo_tz_search(const hmo_pel* org, int org_stride, int w, int h, const hmo_p
   tz_help(&t, sx, sy, 0, 0);      /* median predictor */
   tz_help(&t, 0, 0, 0, 0);        /* bTestZeroVector */
   if (int_mv_2nx2n) {
-    int ix = (int16_t)(int_mv_2nx2n[0] << 2), iy = (int16_t)(int_mv_2nx2n[1] << 2);
+    int ix = (int16_t)(int_mv_2nx2n[0] * 4), iy = (int16_t)(int_mv_2nx2n[1] * 4);
     hmo_clip_mv(&ix, &iy, tz->cu_x, tz->cu_y, tz->pic_w, tz->pic_h, tz->max_cu);
     ix >>= 2; iy >>= 2;
     tz_help(&t, ix, iy, 0, 0);
-    hmo_set_search_range((int16_t)(t.best_x << 2), (int16_t)(t.best_y << 2), tz->sr, tz->cu_x, tz->cu_y,
+    hmo_set_search_range((int16_t)(t.best_x * 4), (int16_t)(t.best_y * 4), tz->sr, tz->cu_x, tz->cu_y,
                          tz->pic_w, tz->pic_h, tz->max_cu, &rl, &rt, &rr, &rb);
   }
   int start_x = t.best_x, start_y = t.best_y;

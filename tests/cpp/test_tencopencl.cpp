@@ -73,12 +73,115 @@ int main() {
         }
     }
   }
+  // ---- bi-prediction tables: a bBi call (TEncSearch.cpp:3221: origin 2*org - pred_other, unclipped,
+  // TComYuv.cpp:409-440; SearchRange = BipredSearchRange = 4) must leave the uni-prediction tables alone
+  {
+    const int cu_x = 64, cu_y = 0, BSR = 4;
+    Pel* piCtu = &cur[(M + cu_y) * stride + M + cu_x];
+    Pel* piRefY = &ref[(M + cu_y) * stride + M + cu_x];
+    me.setCostMode(TEncOpenCL::ME_MODE_HM);
+    me.setFastEnc(true);
+    int ltx, lty, rbx, rby;
+    hmo_set_search_range(12, -8, SR, cu_x, cu_y, W, H, 64, &ltx, &lty, &rbx, &rby);
+    TComMv lt((Short)ltx, (Short)lty);
+    me.setPredictor(TComMv(12, -8));
+    me.setSearchRangeRB(TComMv((Short)rbx, (Short)rby));
+    me.calcMotionVectors(piCtu, piRefY, stride, stride, SR, &lt);
+    static TComMv uniMv[NUM_CTU_PARTS];
+    static Distortion uniCost[NUM_CTU_PARTS];
+    std::memcpy(uniMv, me.getMvs(), sizeof uniMv);
+    std::memcpy(uniCost, me.getRuiCost(), sizeof uniCost);
+    std::vector<Pel> bi(64 * 64);
+    for (int y = 0; y < 64; ++y)
+      for (int x = 0; x < 64; ++x) bi[y * 64 + x] = (Pel)(2 * piCtu[y * stride + x] - (Pel)(rnd() & 255));   // in [-255, 510]
+    const int cx = uniMv[592].getHor() << 2, cy = uniMv[592].getVer() << 2;   // xSetSearchRange(pcCU, rcMv, ...), TEncSearch.cpp:3725
+    hmo_set_search_range(cx, cy, BSR, cu_x, cu_y, W, H, 64, &ltx, &lty, &rbx, &rby);
+    TComMv ltb((Short)ltx, (Short)lty);
+    me.setBiPred(true);
+    me.setPredictor(TComMv(-3, 5));
+    me.setSearchRangeRB(TComMv((Short)rbx, (Short)rby));
+    me.calcMotionVectors(&bi[0], piRefY, stride, 64, BSR, &ltb);
+    if (!me.lastCallOk()) { fprintf(stderr, "bi-pred call failed\n"); ++failures; }
+    hmo_params p;
+    p.lt_x = ltx; p.lt_y = lty; p.rb_x = rbx; p.rb_y = rby; p.pred_x = -3; p.pred_y = 5;
+    p.lambda_q16 = hmo_lambda_q16(lambda); p.fen = 1; p.bit_depth = 8;
+    int32_t ox[HMO_NUM_CTU_PARTS], oy[HMO_NUM_CTU_PARTS];
+    uint32_t osad[HMO_NUM_CTU_PARTS];
+    hmo_search_ctu(&bi[0], 64, piRefY, stride, &p, ox, oy, osad, NULL);
+    for (int i = 0; i < NUM_CTU_PARTS; i++)
+      if (me.getMvs()[i].getHor() != ox[i] || me.getMvs()[i].getVer() != oy[i] || me.getRuiCost()[i] != osad[i] || me.getX()[i] != ox[i]) {
+        if (failures < 10) fprintf(stderr, "bi-pred slot %d differs from the oracle\n", i);
+        ++failures;
+      }
+    me.setBiPred(false);
+    if (std::memcmp(uniMv, me.getMvs(), sizeof uniMv) != 0 || std::memcmp(uniCost, me.getRuiCost(), sizeof uniCost) != 0 ||
+        std::memcmp(uniMv, me.getMvs(false), sizeof uniMv) != 0) {
+      fprintf(stderr, "the bi-prediction call clobbered the uni-prediction tables\n");
+      ++failures;
+    }
+    if (std::memcmp(me.getMvs(true), me.getMvs(false), sizeof uniMv) == 0) { fprintf(stderr, "bi tables equal uni tables?\n"); ++failures; }
+  }
+  // ---- picture-edge CTU: 192x128 has none, so pretend the picture ends inside CTU (2,1): 40 x 24 valid
+  {
+    const int cu_x = 128, cu_y = 64, vw = 40, vh = 24, pw = cu_x + vw, ph = cu_y + vh;
+    Pel* piCtu = &cur[(M + cu_y) * stride + M + cu_x];
+    Pel* piRefY = &ref[(M + cu_y) * stride + M + cu_x];
+    me.calcMotionVectorsEdge(piCtu, stride, vw, vh, piRefY, stride, SR, TComMv(-6, 9), cu_x, cu_y, pw, ph);
+    if (!me.lastCallOk()) { fprintf(stderr, "edge call failed\n"); ++failures; }
+    std::vector<Pel> blk(64 * 64);
+    for (int y = 0; y < 64; ++y)
+      for (int x = 0; x < 64; ++x) blk[y * 64 + x] = piCtu[(y < vh ? y : vh - 1) * stride + (x < vw ? x : vw - 1)];
+    hmo_params p;
+    hmo_set_search_range(-6, 9, SR, cu_x, cu_y, pw, ph, 64, &p.lt_x, &p.lt_y, &p.rb_x, &p.rb_y);
+    p.pred_x = -6; p.pred_y = 9; p.lambda_q16 = hmo_lambda_q16(lambda); p.fen = 1; p.bit_depth = 8;
+    int32_t ox[HMO_NUM_CTU_PARTS], oy[HMO_NUM_CTU_PARTS];
+    uint32_t osad[HMO_NUM_CTU_PARTS];
+    hmo_search_ctu(&blk[0], 64, piRefY, stride, &p, ox, oy, osad, NULL);
+    for (int i = 0; i < NUM_CTU_PARTS; i++)
+      if (me.getMvs()[i].getHor() != ox[i] || me.getMvs()[i].getVer() != oy[i] || me.getRuiCost()[i] != osad[i]) {
+        if (failures < 10) fprintf(stderr, "edge CTU slot %d differs from the oracle\n", i);
+        ++failures;
+      }
+    if (me.tablesValidFor(0, 1, 7, 5)) { fprintf(stderr, "tables valid before they were marked\n"); ++failures; }
+    me.markTables(0, 1, 7, 5);
+    if (!me.tablesValidFor(0, 1, 7, 5) || me.tablesValidFor(0, 1, 7, 6) || me.tablesValidFor(0, 1, 8, 5) || me.tablesValidFor(1, 1, 7, 5)) {
+      fprintf(stderr, "table tags\n"); ++failures;
+    }
+  }
+  // ---- unmodified reference call sites on 10-bit content: nothing tells the class the bit depth; it takes the sample width
+  // from the window and, like cl/sad.cl, does not shift the SAD (the oracle's compat preset: bit depth 8 = no shift)
+  {
+    std::vector<Pel> c10(cur.size()), r10(ref.size());
+    for (size_t i = 0; i < c10.size(); ++i) { c10[i] = (Pel)(rnd() & 1023); r10[i] = (Pel)(rnd() & 1023); }
+    TEncOpenCL me10;
+    if (!me10.findDevice(0) || !me10.compileKernelSource("cl/sad.cl", "calcSAD_AMP") || !me10.createBuffers(64, 64, SR)) return 2;
+    me10.setLambda(lambda);
+    const int cu_x = 64, cu_y = 64;
+    TComMv lt((Short)-SR, (Short)(-SR + 1));
+    me10.calcMotionVectors(&c10[(M + cu_y) * stride + M + cu_x], &r10[(M + cu_y) * stride + M + cu_x], stride, stride, SR, &lt);
+    if (!me10.lastCallOk()) { fprintf(stderr, "10-bit compat call failed\n"); ++failures; }
+    hmo_params p;
+    hmo_ocl_compat_params(&p, -SR, -SR + 1, SR, hmo_lambda_q16(lambda));
+    int32_t ox[HMO_NUM_CTU_PARTS], oy[HMO_NUM_CTU_PARTS];
+    uint32_t osad[HMO_NUM_CTU_PARTS];
+    hmo_search_ctu(&c10[(M + cu_y) * stride + M + cu_x], stride, &r10[(M + cu_y) * stride + M + cu_x], stride, &p, ox, oy, osad, NULL);
+    int bad = 0;
+    for (int i = 0; i < NUM_CTU_PARTS; i++)
+      bad += me10.getX()[i] != ox[i] || me10.getY()[i] != oy[i] || me10.getRuiCost()[i] != osad[i];
+    if (bad) { fprintf(stderr, "10-bit compat mode: %d slots differ from the oracle\n", bad); failures += bad; }
+    if (osad[592] < 300000) { fprintf(stderr, "10-bit sums look shifted (%u)\n", osad[592]); ++failures; }
+  }
   // error behaviour: a sample outside [0,255] is reported, results flagged not-ok, no crash
-  cur[(M)*stride + M] = 999;
+  cur[(M)*stride + M] = 9999;   // beyond any bit depth the class could derive
   TComMv lt0(-8, -8);
   me.setCostMode(TEncOpenCL::ME_MODE_OCL_COMPAT);
   me.calcMotionVectors(&cur[M * stride + M], &ref[M * stride + M], stride, stride, SR, &lt0);
   if (me.lastCallOk()) { fprintf(stderr, "out-of-range sample was not rejected\n"); ++failures; }
+  // ... and the tables are poisoned, not left at the previous CTU's values: the reference caller copies them unchecked
+  for (int i = 0; i < NUM_CTU_PARTS; i++)
+    if (me.getX()[i] != 0 || me.getY()[i] != 0 || me.getRuiCost()[i] != 0xFFFFFFFFu || me.getMvs()[i].getHor() != 0) {
+      fprintf(stderr, "slot %d not poisoned after a failed call\n", i); ++failures; break;
+    }
   printf("%s (%d mismatches)\n", failures ? "FAIL" : "PASS", failures);
   return failures ? 1 : 0;
 }

@@ -88,3 +88,49 @@ def test_generated_isa_has_no_dpp_hazard():
     r = subprocess.run(["make", "-C", csrc, "check-isa"], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 hazard(s)" in r.stdout
+
+
+def test_dpp_hazard_checker_treats_branch_targets_as_joins(tmp_path):
+    """tools/check_dpp_hazard.py: a DPP read right after a local label is a violation whatever the fall-through path did
+    (another path into the join may have written the register one branch ago); one padded instruction later it is not"""
+    import subprocess
+    import sys
+    tool = os.path.join(ROOT, "tools", "check_dpp_hazard.py")
+
+    def run(body):
+        p = tmp_path / "k.s"
+        p.write_text("kernel_a:\n" + body)
+        return subprocess.run([sys.executable, tool, str(p)], capture_output=True, text=True)
+    dpp = "\tv_min_u32_dpp v1, v2, v2 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+    ok_linear = "\tv_add_u32 v2, v3, v4\n\ts_nop 1\n" + dpp
+    assert run(ok_linear).returncode == 0
+    assert run("\tv_add_u32 v2, v3, v4\n\ts_nop 0\n" + dpp).returncode == 1                       # one wait state only
+    assert run("\tv_add_u32 v9, v3, v4\n\ts_nop 1\n.LBB0_3:\n" + dpp).returncode == 1             # join: unknown writer + branch
+    assert run("\tv_add_u32 v9, v3, v4\n.LBB0_3:\n\ts_nop 0\n" + dpp).returncode == 0             # ... padded once: fine
+    assert run("\tv_add_u32 v9, v3, v4\n.LBB0_3:\n\tv_mov_b32 v7, v8\n" + dpp).returncode == 0
+
+
+def test_cpu_side_code_is_clean_under_asan_and_ubsan(tmp_path):
+    """SURVEY 5 ("-fsanitize=address on host code"): the oracle and the TEncOpenCL host module + the GPU-free C-ABI entry points,
+    compiled with -fsanitize=address,undefined and driven by tests/cpp/asan_driver.cpp.  GPU sanitizers are not available on
+    this pool; here (no GPU) the driver also walks the failure paths of the class."""
+    import subprocess
+    import torch
+    from hmme import api
+    api.build()
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("CPU-build check; on the GPU box the class is covered by tests/cpp/test_tencopencl.cpp")
+    exe = str(tmp_path / "asan_driver")
+    csrc = os.path.join(ROOT, "hm-opencl_amd", "csrc")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++11", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
+                    "-o", exe, os.path.join(ROOT, "tests", "cpp", "asan_driver.cpp"), os.path.join(ROOT, "hm-opencl_amd", "host", "TEncOpenCL.cpp"),
+                    "-x", "c", os.path.join(ROOT, "oracle", "hm_oracle.c"), "-x", "none",
+                    "-L" + csrc, "-lhmme", "-Wl,-rpath," + csrc, "-lm", "-lpthread"], check=True)
+    supp = tmp_path / "lsan.supp"
+    supp.write_text("leak:libamdhip64\nleak:libhsa-runtime64\nleak:libamd_comgr\n")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", LSAN_OPTIONS=f"suppressions={supp}:print_suppressions=0",
+               UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-4000:]
+    assert "asan_driver: PASS" in r.stdout

@@ -743,3 +743,119 @@ def test_contexts_are_independent_and_do_not_leak(oracle_lib):
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info(0)[0]
     assert free0 - free1 < 64 << 20, (free0, free1)
+
+
+def test_2160p_10bit_sr128_whole_frame_properties_and_spot_checks(engine, oracle_lib):
+    """BASELINE config 5 at full size (3840x2160 10-bit, SearchRange 128, FEN 1: the 16-bit kernel, window strips merged through
+    global atomics): planted motion of up to 100 samples recovered wherever it is recoverable, idempotence, oracle equality on a
+    CTU sample incl. the corners and the partial bottom row -- the 16-bit twin of the 8-bit 2160p test above"""
+    from hmme import api, synth
+    w, h, sr, bd = 3840, 2160, 128, 10
+    cur, ref, true_mv = synth.make_pair(w, h, seed=510, bit_depth=bd, max_mv=100, region=256, noise_sigma=0.0)
+    m = synth.MARGIN
+    n_ctu = 60 * 34
+    pred = synth.random_predictors(n_ctu, seed=510, max_pel=20)
+    engine.set_lambda(238.5)
+    lq = engine.lambda_q16
+    with engine.plane(w, h, bd) as pc, engine.plane(w, h, bd) as pr:
+        pc.upload_pel(cur, (m, m)); pr.upload_pel(ref, (m, m))
+        mv, sad = engine.search_frame(pc, pr, sr, pred)
+        mv2, sad2 = engine.search_frame(pc, pr, sr, pred)
+    assert mv.shape == (n_ctu, 593, 2) and np.array_equal(mv, mv2) and np.array_equal(sad, sad2)
+    hits = far = 0
+    for cy in range(1, 32):
+        for cx in range(1, 59):
+            if (cx % 4) in (0, 3) or (cy % 4) in (0, 3):                  # CTUs strictly inside one 256x256 region
+                continue
+            dx, dy = (int(v) for v in true_mv[cy // 4, cx // 4])
+            ctu = cy * 60 + cx
+            px, py = int(pred[ctu, 0]) >> 2, int(pred[ctu, 1]) >> 2
+            lt_rb = api.set_search_range(int(pred[ctu, 0]), int(pred[ctu, 1]), sr, cx * 64, cy * 64, w, h)
+            if lt_rb[0] <= dx <= lt_rb[2] and lt_rb[1] <= dy <= lt_rb[3] and 0 <= cx * 64 + dx and cx * 64 + 64 + dx <= w \
+                    and 0 <= cy * 64 + dy and cy * 64 + 64 + dy <= h:      # planted MV inside the window and the block inside the picture
+                assert sad[ctu, 592] == 0 and tuple(mv[ctu, 592]) == (dx, dy), (cx, cy, dx, dy)
+                hits += 1
+                far += max(abs(dx - px), abs(dy - py)) > 64                # beyond what SearchRange 64 could reach
+    assert hits > 250 and far > 30
+    for ctu in (0, 59, 61, 1017, 2039, 1980, 33 * 60 + 30, 777):          # corners, interior, partial bottom row
+        ox, oy, osad = oracle_lib.search_frame(cur, ref, (m, m), w, h, sr, pred, lq, 1, bd, ctu_first=ctu, ctu_count=1)
+        assert np.array_equal(mv[ctu, :, 0], ox[0]) and np.array_equal(mv[ctu, :, 1], oy[0]) and np.array_equal(sad[ctu], osad[0]), ctu
+
+
+def test_shift_free_and_int16_argument_checks(engine, oracle_lib):
+    """hmme_search_params::shift_free (what cl/sad.cl computes on Pel of any width: no >> (bitDepth-8), SURVEY 8a quirk 3) against
+    the oracle's compat arithmetic; limits of the mode; window / predictor components beyond int16 are arguments errors, not
+    device faults"""
+    from hmme import api
+    rng = np.random.default_rng(99)
+    for bd, bipred in ((10, False), (9, True), (9, False), (8, True)):
+        maxv = (1 << bd) - 1
+        sr = 6
+        side = 64 + 2 * sr + 8
+        ref = rng.integers(0, maxv + 1, size=(side, side)).astype(np.int16)
+        cur = rng.integers(0, maxv + 1, size=(64, 64))
+        if bipred:
+            cur = 2 * cur - rng.integers(0, maxv + 1, size=(64, 64))
+        cur = cur.astype(np.int16)
+        o = sr + 4
+        engine.set_lambda(57.9)
+        for fen in (0, 1):
+            p = api.SearchParams(-sr, -sr, sr, sr - 1, 7, -9, fen, bd, 1)
+            mv, sad = engine.search_ctu(cur, (0, 0), ref, (o, o), p)
+            op = oracle_lib.make_params((-sr, -sr), (sr, sr - 1), (7, -9), engine.lambda_q16, fen, 8)   # depth 8 = no shift in the oracle
+            ox, oy, osad = oracle_lib.search_ctu(cur, (0, 0), ref, (o, o), op)
+            assert np.array_equal(mv[:, 0], ox) and np.array_equal(mv[:, 1], oy) and np.array_equal(sad, osad), (bd, bipred, fen)
+        shifted = engine.search_ctu(cur, (0, 0), ref, (o, o), api.SearchParams(-sr, -sr, sr, sr - 1, 7, -9, 0, bd, 0))[1]
+        if bd > 8:
+            assert int(shifted[592]) < int(sad[592])
+    cur = np.zeros((64, 64), np.int16)
+    ref = np.zeros((100, 100), np.int16)
+    with pytest.raises(api.HmmeError, match="shift-free"):
+        engine.search_ctu(cur, (0, 0), ref, (18, 18), api.SearchParams(-8, -8, 8, 8, 0, 0, 0, 12, 1))
+    cur2 = cur.copy(); cur2[0, 0] = -5
+    with pytest.raises(api.HmmeError, match="shift-free"):
+        engine.search_ctu(cur2, (0, 0), ref, (18, 18), api.SearchParams(-8, -8, 8, 8, 0, 0, 0, 10, 1))
+    for bad in (api.SearchParams(-8, -8, 8, 8, 40000, 0, 1, 8), api.SearchParams(-8, -8, 8, 8, 0, -40000, 1, 8),
+                api.SearchParams(-40000, -8, -39990, 8, 0, 0, 1, 8), api.SearchParams(-8, 70000, 8, 70010, 0, 0, 1, 8)):
+        with pytest.raises(api.HmmeError, match="int16"):
+            engine.search_ctu(cur, (0, 0), ref, (18, 18), bad)
+
+
+def test_bench_collective_path_under_torchrun_one_rank(tmp_path):
+    """bench.py's N > 1 code path (process group, PipelinedGather with RCCL all-gathers, barrier, max-over-ranks) rehearsed
+    with ONE rank on this one-GPU box: `torchrun --nproc-per-node 1` + HMME_BENCH_FORCE_DIST=1 (launcher started before any GPU call)"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HMME_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--size", "1080p", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 100 and d["roofline"]["kernel_ms"] > 0
+    assert d["config"]["collective"] == "all_gather_into_tensor (nccl), world 1"
+
+
+def test_sequence_driver_reads_a_yuv_file(tmp_path):
+    """tools/me_sequence.py --yuv: the frame feeder (planar 8-bit 4:2:0 reader, hmme/yuv.py) in front of the sharded sequence
+    search; the file holds a texture panning by (2, 1) per picture, which the 64x64 PUs must find"""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from hmme import synth, yuv
+    w, h, n = 320, 192, 5
+    pics = [synth.make_pair(w, h, seed=42, max_mv=0, noise_sigma=0.0, shift=(2 * t, t), pad=20, margin=0)[0].astype(np.uint8) for t in range(n)]
+    path = str(tmp_path / "pan.yuv")
+    yuv.write_luma_420(path, pics)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "me_sequence.py"), "--frames", str(n), "--gop", "lowdelay_P",
+                        "--size", f"{w}x{h}", "--search-range", "16", "--yuv", path], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["gpus"] == 1 and d["first_pairs"][0] == [1, 0] and d["first_pairs"][1] == [2, 1]
+    # picture t = texture shifted by (2t, t): cur(x) = ref(x + mv) with mv = (2, 1) * (cur - ref)
+    assert d["median_mv_64x64_of_first_pairs"][0] == [2, 1] and d["median_mv_64x64_of_first_pairs"][2] == [4, 2]

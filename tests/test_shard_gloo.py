@@ -91,3 +91,86 @@ def test_two_rank_gloo_matches_single_process(oracle_lib):
     mv1, sad1 = shard.search_sequence(_pair_search(oracle_lib, synth), N_PAIRS, 4, torch.device("cpu"))
     assert mv2.shape == (N_PAIRS, 4, 593, 2)
     assert np.array_equal(mv2, mv1.numpy()) and np.array_equal(sad2, sad1.numpy())
+
+
+# ---- the pipeline bench.py --gpus N actually runs: PipelinedGather (double-buffered step / drain) -------------------------
+N_STEPS, SHAPE = 9, (2, 1, 6, 593)
+
+
+def _expected_block(rank, step):
+    """what rank `rank` contributes at step `step`: a deterministic pattern over the whole [2, k, n_ctu, 593] block"""
+    g = torch.Generator().manual_seed(1000 * rank + step)
+    return torch.randint(-2**31, 2**31 - 1, SHAPE, dtype=torch.int32, generator=g)
+
+
+def _pipeline_worker(rank, world, port, q):
+    import time
+    sys.path.insert(0, os.path.join(ROOT, "hm-opencl_amd"))
+    from hmme import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pipe = shard.PipelinedGather(lambda: torch.zeros(SHAPE, dtype=torch.int32), distributed=True, async_op=True)
+        seen = {}
+
+        def launch(buf, k):
+            # a search kernel fills its output over time, not at once: write the block in slices with pauses, so that a gather
+            # still reading this buffer (the bug the retire-before-reuse rule prevents) would ship a torn block
+            want = _expected_block(rank, k)
+            for i in range(SHAPE[2]):
+                buf[:, :, i] = want[:, :, i]
+                if (k + rank + i) % 3 == 0:
+                    time.sleep(0.002)
+
+        def consume(k, gathered):
+            seen[k] = gathered.clone()
+
+        for _ in range(N_STEPS):
+            pipe.step(launch, consume)
+            assert sum(p is not None for p in pipe.pending) <= 2
+        pipe.drain(consume)
+        assert pipe.pending == [None, None]
+        ok = sorted(seen) == list(range(N_STEPS))
+        for k, g in seen.items():
+            ok = ok and tuple(g.shape) == (world,) + SHAPE
+            for r in range(world):
+                ok = ok and bool(torch.equal(g[r], _expected_block(r, k)))
+        q.put((rank, ok, sorted(seen)))
+        dist.barrier()
+    except Exception as e:
+        q.put((rank, repr(e), []))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_gather_two_ranks_gloo():
+    """the double-buffered step()/drain() logic of bench.py (hmme/shard.py PipelinedGather) under gloo, world size 2, async
+    collectives: every step's gathered block arrives complete and in order on both ranks although each local buffer is
+    rewritten two steps later"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, steps in got:
+        assert ok is True, (rank, ok)
+        assert steps == list(range(N_STEPS))
+
+
+def test_pipelined_gather_single_process_passthrough():
+    """world size 1 without a process group: consume sees the local block itself, one step late, then at drain"""
+    from hmme import shard
+    pipe = shard.PipelinedGather(lambda: torch.zeros((2, 1, 2, 593), dtype=torch.int32), distributed=False)
+    seen = []
+    for k in range(5):
+        pipe.step(lambda buf, kk: buf.fill_(kk + 1), lambda kk, g: seen.append((kk, int(g[0, 0, 0, 0, 0]))))
+    pipe.drain(lambda kk, g: seen.append((kk, int(g[0, 0, 0, 0, 0]))))
+    assert seen == [(k, k + 1) for k in range(5)]
+    assert int(pipe.last_local[0, 0, 0, 0]) == 5

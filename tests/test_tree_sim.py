@@ -115,7 +115,7 @@ def test_generated_tree_full_window_with_folded_last_row():
     assert np.array_equal(got, d["out"][0])
 
 
-INV16, IDX16 = 4000000, G.IDX_BITS16
+INV16, IDX16 = 8000000, G.IDX_BITS16
 
 
 def model_search16(tree, cur, ref, origin, lt, rb, pred, lq, bit_depth, iters_per_task=2):
@@ -147,7 +147,7 @@ def model_search16(tree, cur, ref, origin, lt, rb, pred, lq, bit_depth, iters_pe
                         x = int(cx[l]) + 2 * j
                         cost = ((lq * (cbits(((lt[0] + x) << 2) - pred[0]) + by)) & 0xFFFFFFFF) >> 16
                         valid = cy[l] < wy and x < wx
-                        c[j, l] = ((cost if valid else INV16) << IDX16) | (it << 8) | (l << 2) | j
+                        c[j, l] = ((cost if valid else INV16) << IDX16) | (it << 7) | (l << 1) | j
                 lane_off = np.minimum(cy, wy - 1) * pitch + (cx - par)
                 G.simulate16(tree, win, cur, lane_off, c, best, sh)
             for g in range(G.N_GROUPS):
@@ -156,7 +156,7 @@ def model_search16(tree, cur, ref, origin, lt, rb, pred, lq, bit_depth, iters_pe
                     cost = key >> IDX16
                     if s < 0 or cost >= INV16:
                         continue
-                    kit, kl, kj = (key >> 8) & 1, (key >> 2) & 63, key & 3
+                    kit, kl, kj = (key >> 7) & 1, (key >> 1) & 63, key & 1
                     q = (it0 + kit) * 64 + kl
                     v = np.uint64((cost << 32) | ((q // P) << 16) | (par + 4 * (q % P) + 2 * kj))
                     if v < best64[s]:

@@ -2,6 +2,10 @@
 """ISA check for the hand-written DPP instructions (inline asm is not padded by the compiler's hazard recognizer):
 a VALU write of a VGPR must be followed by 2 wait states before a DPP instruction reads that VGPR as its DPP source
 (gfx9 data hazard).  Every instruction the wave issues is one wait state, `s_nop N` is N + 1.
+Control flow: a local label (.LBB*) is a join -- some other path can reach it through a branch whose source the linear scan
+does not see.  Conservatively, every VGPR is taken to have been written by the instruction right before that branch; the
+branch itself is the one wait state in between.  So a DPP read within the first instruction after a label is a violation
+unless padded, whatever the fall-through path did.
 usage: check_dpp_hazard.py <file.s> [kernel-name-substring ...]   -> exit 1 on a violation"""
 import re
 import sys
@@ -18,6 +22,9 @@ def regs(tok):
     return set()
 
 
+ALL_VGPRS = frozenset(range(512))
+
+
 def check(path, names):
     bad = total = 0
     kernel = None
@@ -29,6 +36,11 @@ def check(path, names):
         if ln.endswith(":") and not ln.startswith("."):
             kernel = ln[:-1]
             hist = []
+            continue
+        if re.match(r"\.L[A-Za-z0-9_$.]*:$", ln) and kernel is not None:
+            hist.append((1, ALL_VGPRS))   # unknown writer on the other path into this join ...
+            hist.append((1, set()))       # ... then the branch that brought the wave here
+            hist = hist[-4:]
             continue
         if ln.startswith(".") or kernel is None or (names and not any(n in kernel for n in names)):
             continue

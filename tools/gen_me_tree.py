@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT_DIR = os.path.join(ROOT, "hm-opencl_amd", "csrc")
 
 IDX_BITS = 10          # key = cost << 10 | iter(2) | lane(6) | j(2)
-IDX_BITS16 = 9         # 16-bit path: cost << 9 | iter(1) | lane(6) | j(2)  (23-bit cost: bi-pred origins reach 3.2 M)
+IDX_BITS16 = 8         # 16-bit path: cost << 8 | iter(1) | lane(6) | j(1)  (24-bit cost: shift-free 9-bit bi-pred origins reach 6.3 M)
 MULT_A = 1 << IDX_BITS
 N_GROUPS = 10          # ceil(593 / 64)
 PDW = 49               # LDS window pitch in dwords (odd: conflict-free for every lane shape)
