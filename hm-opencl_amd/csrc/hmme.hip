@@ -185,7 +185,7 @@ int launch16_t(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const RefSet& r
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)hmme::me_search16_kernel<FEN, PDW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((hmme::me_search16_kernel<FEN, PDW>), dim3(n_wg), dim3(hmme::kThreads), lds, stream, cur, cur_pitch, ref,
+  hipLaunchKernelGGL((hmme::me_search16_kernel<FEN, PDW>), dim3(n_wg), dim3(hmme::kThreads16), lds, stream, cur, cur_pitch, ref,
                      ref_pitch, d_jobs, ctx->lambda_q16, sh, d_best);
   HIP_TRY(ctx, hipGetLastError());
   return HMME_OK;

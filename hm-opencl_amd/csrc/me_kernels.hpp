@@ -150,7 +150,20 @@ constexpr int kIdxBits16 = 8;              // key = cost << 8 | iter(1) | lane(6
 // cl/sad.cl computes) <= 4 190 208 + 65 535; shift-free 9-bit bi-pred origins <= 6 279 168 + 65 535.  kInvCost16 + the
 // largest sum an invalid lane can add (6 279 168) stays < 2^24
 constexpr uint32_t kInvCost16 = 8000000u;
-constexpr int kIterPerTask16 = kIterPerTask < 2 ? kIterPerTask : 2;
+#ifndef ME_ITER_PER_TASK16
+#define ME_ITER_PER_TASK16 2
+#endif
+constexpr int kIterPerTask16 = ME_ITER_PER_TASK16;   // <= 2 (one iteration bit in the key)
+// Workgroup shape of the 16-bit kernel.  The LDS window (78 KB) allows 2 workgroups per CU; at 4 waves each that is 2 waves per
+// SIMD with a 256-VGPR budget (the kernel uses 210 / 242).  ME_THREADS16=384 + ME_WAVES16=3 (6 waves share a window, 3 per SIMD,
+// 168 VGPRs) is an A/B knob: build with EXTRA="-DME_THREADS16=384 -DME_WAVES16=3 -DME_ITER_PER_TASK16=1".
+#ifndef ME_THREADS16
+#define ME_THREADS16 256
+#endif
+#ifndef ME_WAVES16
+#define ME_WAVES16 2
+#endif
+constexpr int kThreads16 = ME_THREADS16;
 
 // a CTU search cut into several workgroups: the 16-bit path cuts by candidate rows (LDS capacity), the 8-bit path
 // by task range (latency of the per-CTU drop-in call, small pictures)
@@ -428,7 +441,7 @@ typedef volatile __attribute__((address_space(3))) u32x4_t lds_vu32x4_t;
 #define ME_SAD16(a, b, acc) __builtin_amdgcn_sad_u16((a), (b), (acc))
 
 template <int FEN, int PDW>
-__global__ void __launch_bounds__(kThreads, 2)
+__global__ void __launch_bounds__(kThreads16, ME_WAVES16)
 me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet refs, int ref_pitch,
                    const MeJob16* __restrict__ jobs, uint32_t lambda_q16, int sh, unsigned long long* __restrict__ g_best) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -446,8 +459,8 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const Re
   const int wx = job.rb_x - job.lt_x + 1;
   const int ny = jb.y1 - jb.y0;                                        // candidate rows of this strip
 
-  for (int s = tid; s < kParts; s += kThreads) best64[s] = ~0ull;
-  for (int i = tid; i < 64 * 8; i += kThreads) {
+  for (int s = tid; s < kParts; s += kThreads16) best64[s] = ~0ull;
+  for (int i = tid; i < 64 * 8; i += kThreads16) {
     const int r = i >> 3, q = i & 7;
     curl[i] = *(const u32x4_t*)(cur_base + (long)(job.ctu_y + r) * cur_pitch + 2 * job.ctu_x + 16 * q);
   }
@@ -472,7 +485,7 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const Re
       const uint32_t* src_al = (const uint32_t*)(src - mis);
       const int pitch_dw = ref_pitch >> 2;
       const int n = (ny + 63) * PDW;
-      for (int i = tid; i < n; i += kThreads) {
+      for (int i = tid; i < n; i += kThreads16) {
         const int r = i / PDW, k = i - r * PDW;
         const uint32_t lo = src_al[(long)r * pitch_dw + k], hi = src_al[(long)r * pitch_dw + k + 1];
         win[i] = __builtin_amdgcn_alignbyte(hi, lo, mis);
@@ -535,7 +548,7 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const Re
   }
   }   // par
   __syncthreads();
-  for (int s = tid; s < kParts; s += kThreads) atomicMin(&g_best[(long)jb.job * kParts + s], best64[s]);
+  for (int s = tid; s < kParts; s += kThreads16) atomicMin(&g_best[(long)jb.job * kParts + s], best64[s]);
 }
 
 // strips of one CTU have merged into g_best: decode (cost, y, x) -> TComMv + pure SAD

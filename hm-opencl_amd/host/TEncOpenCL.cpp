@@ -10,7 +10,7 @@
 TEncOpenCL::TEncOpenCL()
     : m_ctx(0), m_deviceId(0), m_deviceFound(false), m_enabled(false), m_lastOk(false), m_searchRange(0),
       m_mode(ME_MODE_OCL_COMPAT), m_fen(false), m_bitDepth(0), m_bi(0), m_lambda(0.0), m_calls(0), m_failed(0), m_edgeCalls(0),
-      m_biCalls(0) {
+      m_biCalls(0), m_verified(0), m_verifyFailed(0) {
   for (Int b = 0; b < 2; b++) {
     xPoison(m_tab[b]);   // tables nobody filled yet must not look like results either
   }
@@ -20,10 +20,20 @@ TEncOpenCL::TEncOpenCL()
 
 TEncOpenCL::~TEncOpenCL() {
   if (std::getenv("HMME_TRACE"))   // one summary line for A/B harnesses (tests/test_hm_dropin.py)
-    fprintf(stderr, "TEncOpenCL(hmme): %ld calcMotionVectors calls, %ld failed, %ld edge-CTU, %ld bi-pred, device: %s\n", m_calls, m_failed,
-            m_edgeCalls, m_biCalls, m_ctx ? hmme_device_info(m_ctx) : "none");
+    fprintf(stderr, "TEncOpenCL(hmme): %ld calcMotionVectors calls, %ld failed, %ld edge-CTU, %ld bi-pred, %ld results verified against xPatternSearch, "
+            "%ld differ, device: %s\n", m_calls, m_failed, m_edgeCalls, m_biCalls, m_verified, m_verifyFailed, m_ctx ? hmme_device_info(m_ctx) : "none");
   if (m_ctx) hmme_destroy(m_ctx);
   m_ctx = 0;
+}
+
+Bool TEncOpenCL::slotRect(Int slot, Int& x, Int& y, Int& w, Int& h) { return hmme_slot_rect(slot, &x, &y, &w, &h) == HMME_OK; }
+Bool TEncOpenCL::hmModeEnabled() {
+  static const Int on = (std::getenv("HMME_HM_MODE") && std::getenv("HMME_HM_MODE")[0] == '0') ? 0 : 1;
+  return on != 0;
+}
+Bool TEncOpenCL::verifyEnabled() {
+  static const Int on = (std::getenv("HMME_VERIFY") && std::getenv("HMME_VERIFY")[0] == '1') ? 1 : 0;
+  return on != 0;
 }
 
 // reference: scans OpenCL platforms for GPUs and remembers the device (TEncOpenCL.cpp:69-137).  Here the
@@ -87,6 +97,7 @@ Void TEncOpenCL::calcMotionVectors(Pel* pelCtu, Pel* pelSearch, Int iRefStride, 
     xPoison(t);
     return;
   }
+  m_lastLT = *pcMvSrchRngLT;
   hmme_search_params p;
   if (m_mode == ME_MODE_OCL_COMPAT) {
     hmme_params_ocl_compat(&p, pcMvSrchRngLT->getHor(), pcMvSrchRngLT->getVer(), i_areaSize);
@@ -110,6 +121,7 @@ Void TEncOpenCL::calcMotionVectors(Pel* pelCtu, Pel* pelSearch, Int iRefStride, 
     p.bit_depth = m_bitDepth > 0 ? m_bitDepth : 8;
     p.shift_free = 0;
   }
+  m_lastRB.set((Short)p.rb_x, (Short)p.rb_y);
   typedef char tcommv_is_two_shorts[sizeof(TComMv) == 4 ? 1 : -1];   // C++98-friendly static asserts
   typedef char distortion_is_u32[sizeof(Distortion) == 4 ? 1 : -1];
   (void)sizeof(tcommv_is_two_shorts); (void)sizeof(distortion_is_u32);

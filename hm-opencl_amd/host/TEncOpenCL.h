@@ -86,6 +86,19 @@ class TEncOpenCL {
   }
   long numCalls() const { return m_calls; }
   long numFailed() const { return m_failed; }
+  /// window of the last call (calcMotionVectorsEdge derives it itself)
+  const TComMv& getLastLT() const { return m_lastLT; }
+  const TComMv& getLastRB() const { return m_lastRB; }
+  /// A/B and self-check switches of the in-tree integration (tools/hm_patch): HMME_HM_MODE=0 keeps the reference call
+  /// sequence (ME_MODE_OCL_COMPAT) in a patched encoder; HMME_VERIFY=1 makes the patched encoder re-run HM's own CPU
+  /// xPatternSearch beside engine results and report the comparison through noteVerify (summary line in the destructor)
+  /// rectangle of table slot 0..592 inside the CTU (TComDataCU::getIndexBlock order); false if out of range
+  static Bool slotRect(Int slot, Int& x, Int& y, Int& w, Int& h);
+  static Bool hmModeEnabled();
+  static Bool verifyEnabled();
+  Void noteVerify(Bool match) { ++m_verified; if (!match) ++m_verifyFailed; }
+  long numVerified() const { return m_verified; }
+  long numVerifyFailed() const { return m_verifyFailed; }
 
  protected:
   struct Tables {
@@ -105,7 +118,8 @@ class TEncOpenCL {
   Int m_bitDepth;
   Int m_bi;
   Double m_lambda;
-  long m_calls, m_failed, m_edgeCalls, m_biCalls;
+  long m_calls, m_failed, m_edgeCalls, m_biCalls, m_verified, m_verifyFailed;
+  TComMv m_lastLT, m_lastRB;
   Tables m_tab[2];                     // [0] uni-prediction, [1] bi-prediction refinement
   Int m_tagPoc[2][33], m_tagCtu[2][33];
 };

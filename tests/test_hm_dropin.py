@@ -16,10 +16,12 @@ import pytest
 from conftest import ROOT
 
 EXE = os.path.join(ROOT, "oracle", "_ref", "TAppEncoder_hmme")
+EXE_HM = os.path.join(ROOT, "oracle", "_ref", "TAppEncoder_hmme_hm")   # + tools/hm_patch (CPU-exact mode, bi-pred tables, edge CTUs)
 CFG = os.path.join(ROOT, "tests", "hm", "lowdelay_P_small.cfg")
+CFG_B = os.path.join(ROOT, "tests", "hm", "lowdelay_B_small.cfg")
 
 
-def _encode(tmp_path, opencl, frames=3, w=192, h=128, extra=()):
+def _encode(tmp_path, opencl, frames=3, w=192, h=128, extra=(), exe=None, cfg=None, env_extra=None):
     from hmme import synth, yuv
     src = str(tmp_path / "in.yuv")
     pics = []
@@ -27,8 +29,8 @@ def _encode(tmp_path, opencl, frames=3, w=192, h=128, extra=()):
         cur, _, _ = synth.make_pair(w, h, seed=5, max_mv=0, noise_sigma=1.0, shift=(2 * t, t), margin=0)
         pics.append(cur.astype(np.uint8))
     yuv.write_luma_420(src, pics)
-    env = dict(os.environ, HMME_TRACE="1")
-    r = subprocess.run([EXE, "-c", CFG, "-i", src, "-wdt", str(w), "-hgt", str(h), "-fr", "30", "-f", str(frames),
+    env = dict(os.environ, HMME_TRACE="1", **(env_extra or {}))
+    r = subprocess.run([exe or EXE, "-c", cfg or CFG, "-i", src, "-wdt", str(w), "-hgt", str(h), "-fr", "30", "-f", str(frames),
                         "-b", str(tmp_path / f"s{opencl}.bin"), f"--OpenCL={opencl}", "--KernelOpenCL=embedded", *extra],
                        capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -40,8 +42,8 @@ def _build():
     if os.path.isdir("/root/reference/source"):
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "hm-opencl_amd", "csrc")], check=True)
         subprocess.run(["make", "-s", "-j8", "-C", os.path.join(ROOT, "oracle"), "ref", "dropin"], check=True)
-    if not os.path.exists(EXE):
-        pytest.skip("oracle/_ref/TAppEncoder_hmme not built (needs /root/reference)")
+    if not (os.path.exists(EXE) and os.path.exists(EXE_HM)):
+        pytest.skip("oracle/_ref/TAppEncoder_hmme{,_hm} not built (needs /root/reference)")
 
 
 def test_reference_encoder_builds_and_degrades_cleanly_without_gpu(tmp_path):
@@ -53,6 +55,8 @@ def test_reference_encoder_builds_and_degrades_cleanly_without_gpu(tmp_path):
     r1, p1 = _encode(tmp_path, 1)
     assert "Create Buffers error" in r1.stdout and "OpenCL Motion Estimation Disabled" in r1.stdout
     assert p0 == p1 and len(p0) == 3          # feature disabled -> identical CPU encode
+    r2, p2 = _encode(tmp_path, 1, exe=EXE_HM)  # the patched encoder degrades the same way: the inserted block is never entered
+    assert "OpenCL Motion Estimation Disabled" in r2.stdout and p2 == p0
 
 
 @pytest.mark.gpu
@@ -67,3 +71,34 @@ def test_reference_encoder_runs_on_the_hip_engine(tmp_path):
     for (_, b0, y0), (_, b1, y1) in zip(p0[1:], p1[1:]):         # exhaustive GPU search vs TZ: same ballpark
         assert abs(y1 - y0) < 1.5 and b1 < 2 * b0 + 2000
     print("OpenCL=0:", p0, "\\nOpenCL=1 (hmme):", p1, "\\n", m.group(0))
+
+
+_TRACE = re.compile(r"TEncOpenCL\(hmme\): (\d+) calcMotionVectors calls, (\d+) failed, (\d+) edge-CTU, (\d+) bi-pred, (\d+) results verified "
+                    r"against xPatternSearch, (\d+) differ")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,bipred", [(CFG, False), (CFG_B, True)])
+def test_patched_encoder_hm_mode_equals_hm_cpu_search(tmp_path, cfg, bipred):
+    """tools/hm_patch applied (oracle/_ref/TAppEncoder_hmme_hm), 208x120 = 4 x 2 CTUs of which only 3 are whole.  HMME_VERIFY=1 makes
+    the encoder run HM's OWN xPatternSearch beside every engine call: the 64x64 2Nx2N PU and three more slots per call must
+    come out identical (MV and ruiCost) -- i.e. what --FastSearch=0 computes for those PUs on the same inputs -- for uni- and
+    bi-prediction calls.  Edge CTUs are searched (not served from the previous CTU's tables), bi-prediction uses its own tables."""
+    _build()
+    r, p = _encode(tmp_path, 1, frames=4, w=208, h=120, exe=EXE_HM, cfg=cfg, env_extra={"HMME_VERIFY": "1"}, extra=("--SearchRange=24",))
+    m = _TRACE.search(r.stderr)
+    assert m, r.stderr[-1500:]
+    calls, failed, edge, bi, verified, differ = (int(v) for v in m.groups())
+    assert failed == 0 and differ == 0, m.group(0)
+    assert calls > 0 and edge > 0 and verified >= 4 * (calls - edge - bi)
+    assert (bi > 0) == bipred, m.group(0)
+    assert len(p) == 4
+    # the same binary with HMME_HM_MODE=0 is the unmodified reference call sequence
+    r0, p0 = _encode(tmp_path, 1, frames=4, w=208, h=120, exe=EXE_HM, cfg=cfg, env_extra={"HMME_HM_MODE": "0"}, extra=("--SearchRange=24",))
+    rc, pc = _encode(tmp_path, 1, frames=4, w=208, h=120, exe=EXE, cfg=cfg, extra=("--SearchRange=24",))
+    assert p0 == pc and int(_TRACE.search(r0.stderr).group(3)) == 0
+    # against HM's own searches: exhaustive-search quality (bits within a few per cent of --FastSearch=0)
+    rf, pf = _encode(tmp_path, 0, frames=4, w=208, h=120, exe=EXE_HM, cfg=cfg, extra=("--SearchRange=24", "--FastSearch=0"))
+    bits, bits_full = sum(b for _, b, _ in p[1:]), sum(b for _, b, _ in pf[1:])
+    assert bits < 1.06 * bits_full + 500, (bits, bits_full)
+    print("hm mode:", p, "\nFastSearch=0:", pf, "\n", m.group(0))

@@ -18,7 +18,8 @@ sys.path.insert(0, os.path.join(ROOT, "hm-opencl_amd"))
 from hmme import synth, yuv  # noqa: E402
 
 EXE = os.path.join(ROOT, "oracle", "_ref", "TAppEncoder_hmme")
-CFG = os.path.join(ROOT, "tests", "hm", "lowdelay_P_small.cfg")
+EXE_HM = os.path.join(ROOT, "oracle", "_ref", "TAppEncoder_hmme_hm")   # with tools/hm_patch applied
+CFGS = {"P": os.path.join(ROOT, "tests", "hm", "lowdelay_P_small.cfg"), "B": os.path.join(ROOT, "tests", "hm", "lowdelay_B_small.cfg")}
 
 
 def main():
@@ -26,7 +27,10 @@ def main():
     ap.add_argument("--size", default="416x240")
     ap.add_argument("--frames", type=int, default=5)
     ap.add_argument("--search-range", type=int, default=64)
+    ap.add_argument("--gop", default="P", choices=sorted(CFGS), help="low-delay P (one reference) or B (two references, bi-prediction)")
+    ap.add_argument("--verify", action="store_true", help="HMME_VERIFY=1 on the patched encoder (slower: runs HM's xPatternSearch beside the engine)")
     args = ap.parse_args()
+    CFG = CFGS[args.gop]
     w, h = (int(v) for v in args.size.split("x"))
     tmp = tempfile.mkdtemp()
     src = os.path.join(tmp, "in.yuv")
@@ -37,13 +41,17 @@ def main():
         pics.append(cur.astype(np.uint8))
     yuv.write_luma_420(src, pics)
     rows = []
-    for name, extra in (("CPU TZ search (FastSearch=1)", ["--OpenCL=0", "--FastSearch=1"]),
-                        ("CPU full search (FastSearch=0)", ["--OpenCL=0", "--FastSearch=0"]),
-                        ("hmme behind TEncOpenCL (OpenCL=1)", ["--OpenCL=1", "--FastSearch=1", "--KernelOpenCL=embedded"])):
+    for name, exe, extra in (("CPU TZ search (FastSearch=1)", EXE, ["--OpenCL=0", "--FastSearch=1"]),
+                             ("CPU full search (FastSearch=0)", EXE, ["--OpenCL=0", "--FastSearch=0"]),
+                             ("hmme, reference call sites (ME_MODE_OCL_COMPAT)", EXE, ["--OpenCL=1", "--FastSearch=1", "--KernelOpenCL=embedded"]),
+                             ("hmme, tools/hm_patch (ME_MODE_HM, bi-pred tables, edge CTUs)", EXE_HM, ["--OpenCL=1", "--FastSearch=1", "--KernelOpenCL=embedded"])):
         t0 = time.time()
-        r = subprocess.run([EXE, "-c", CFG, "-i", src, "-wdt", str(w), "-hgt", str(h), "-fr", "30", "-f", str(args.frames),
+        env = dict(os.environ, HMME_TRACE="1")
+        if args.verify and exe == EXE_HM:
+            env["HMME_VERIFY"] = "1"
+        r = subprocess.run([exe, "-c", CFG, "-i", src, "-wdt", str(w), "-hgt", str(h), "-fr", "30", "-f", str(args.frames),
                             f"--SearchRange={args.search_range}", "-b", os.path.join(tmp, "s.bin"), *extra],
-                           capture_output=True, text=True, env=dict(os.environ, HMME_TRACE="1"), cwd=tmp)
+                           capture_output=True, text=True, env=env, cwd=tmp)
         dt = time.time() - t0
         if r.returncode != 0:
             rows.append({"config": name, "error": r.stderr[-300:]})
@@ -51,10 +59,12 @@ def main():
         pocs = re.findall(r"POC\s+(\d+).*?(\d+) bits \[Y ([0-9.]+) dB", r.stdout)
         p_bits = sum(int(b) for p, b, y in pocs if int(p) > 0)
         p_psnr = float(np.mean([float(y) for p, b, y in pocs if int(p) > 0]))
-        m = re.search(r"(\d+) calcMotionVectors calls, (\d+) failed", r.stderr)
-        rows.append({"config": name, "P_bits": p_bits, "P_psnr_y": round(p_psnr, 3), "wall_s": round(dt, 2),
-                     "engine_calls": int(m.group(1)) if m else 0})
-    print(json.dumps({"clip": f"{w}x{h} x {args.frames} synthetic", "search_range": args.search_range, "runs": rows}, indent=1))
+        m = re.search(r"(\d+) calcMotionVectors calls, (\d+) failed, (\d+) edge-CTU, (\d+) bi-pred, (\d+) results verified against xPatternSearch, (\d+) differ", r.stderr)
+        row = {"config": name, "inter_bits": p_bits, "inter_psnr_y": round(p_psnr, 3), "wall_s": round(dt, 2)}
+        if m and int(m.group(1)):
+            row.update(dict(zip(("engine_calls", "failed", "edge_ctu_calls", "bipred_calls", "verified", "verify_mismatches"), (int(v) for v in m.groups()))))
+        rows.append(row)
+    print(json.dumps({"clip": f"{w}x{h} x {args.frames} synthetic", "gop": "low-delay " + args.gop, "search_range": args.search_range, "runs": rows}, indent=1))
 
 
 if __name__ == "__main__":
