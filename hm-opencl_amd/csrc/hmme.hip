@@ -21,13 +21,18 @@ namespace {
 constexpr int kMarginX = 128;  // samples; >= 72 needed by clipMv's bounds (+3 for dword staging); keeps CTU rows 64B-aligned
 constexpr int kMarginY = 80;   // TComPicYuv: maxCUHeight + 16 (reference TComPicYuv.cpp:91-92)
 constexpr int kWinPitch = 1024;  // per-CTU path: bytes per packed window row (>= 2 * (257 + 63) + 8)
-constexpr int kWinRows = 2 * 128 + 1 + 63;
+constexpr int kRefineHalo = 4;   // samples the 8-tap interpolation reaches beyond the window on every side (TComInterpolationFilter.cpp:170-260)
+constexpr int kWinRows = 2 * 128 + 1 + 63 + 2 * kRefineHalo;
 // per-CTU call block: up to 64 MeJob16, the job's first strip (always 0), the 593-entry 64-bit merge table (all ones),
-// the 64 x 64 current block (1 or 2 bytes per sample), the packed window
-constexpr size_t kCallJobs = 0, kCallFirst = 1536, kCallBest = 2048, kCallCtu = 7168, kCallWin = 15360;
+// the 64 x 64 current block (1 or 2 bytes per sample), the caller's integer MVs (refine-only call), the packed window.
+// kCallFracJob: the whole-window MeJob of the refinement kernel (jobs[] may hold window tiles)
+constexpr size_t kCallJobs = 0, kCallFirst = 1536, kCallFracJob = 1600, kCallBest = 2048, kCallCtu = 7168, kCallImv = 15360, kCallWin = 17920;
 constexpr int kCallMaxJobs = 64;
-static_assert(sizeof(MeJob16) * kCallMaxJobs <= kCallFirst && kCallBest + 8 * HMME_NUM_CTU_PARTS <= kCallCtu && kCallCtu + 64 * 64 * 2 <= kCallWin,
-              "per-CTU call block layout");
+static_assert(sizeof(MeJob16) * kCallMaxJobs <= kCallFirst && kCallFracJob + sizeof(MeJob) <= kCallBest && kCallBest + 8 * HMME_NUM_CTU_PARTS <= kCallCtu &&
+              kCallCtu + 64 * 64 * 2 <= kCallImv && kCallImv + 4 * HMME_NUM_CTU_PARTS <= kCallWin && kCallWin % 256 == 0, "per-CTU call block layout");
+// pinned result block: 593 MVs, 593 SADs, completion word of the search; 593 quarter-pel MVs, 593 costs, completion word of the refinement
+constexpr size_t kResMv = 0, kResSad = 4 * HMME_NUM_CTU_PARTS, kResDone = 8 * HMME_NUM_CTU_PARTS, kResQmv = kResDone + 64,
+                 kResCost = kResQmv + 4 * HMME_NUM_CTU_PARTS, kResDone2 = kResCost + 4 * HMME_NUM_CTU_PARTS, kResBytes = kResDone2 + 64;
 constexpr size_t kLdsBudget16 = 78 * 1024;   // per workgroup of the 16-bit path -> 2 workgroups per CU
 // 16-bit window pitch in dwords for windows up to 129 / 257 candidates wide.  Even: rows stay 8-byte aligned for ds_read_b64.
 // 130 = 2 * 33 lanes-per-row + 64: with the kernel's linear lane packing every lane of a 129-wide even-column pass lands on
@@ -314,8 +319,8 @@ int hmme_create(int device, int sr_max, unsigned flags, hmme_ctx** out) {
   CREATE_TRY(hipHostGetDevicePointer((void**)&ctx->h_call_dev, ctx->h_call, 0));
   std::memset(ctx->h_call, 0, kCallWin);
   std::memset(ctx->h_call + kCallBest, 0xFF, 8 * HMME_NUM_CTU_PARTS);
-  CREATE_TRY(hipHostMalloc(&ctx->h_res, 8 * HMME_NUM_CTU_PARTS + 64, hipHostMallocMapped));
-  std::memset(ctx->h_res, 0, 8 * HMME_NUM_CTU_PARTS + 64);
+  CREATE_TRY(hipHostMalloc(&ctx->h_res, kResBytes, hipHostMallocMapped));
+  std::memset(ctx->h_res, 0, kResBytes);
   CREATE_TRY(hipHostGetDevicePointer((void**)&ctx->d_res, ctx->h_res, 0));
   CREATE_TRY(hipMalloc(&ctx->d_flag, sizeof(int)));
   CREATE_TRY(hipMemset(ctx->d_flag, 0, sizeof(int)));
@@ -423,10 +428,18 @@ int hmme_slot_rect(int slot, int* x, int* y, int* w, int* h) {
 }
 
 // ---- per-CTU drop-in ---------------------------------------------------------------------------------
-int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref0, int ref_stride,
-                    const hmme_search_params* p, int16_t* out_mv, uint32_t* out_sad) {
+namespace {
+int build_frac_cover(hmme_ctx* ctx);
+
+// One (CTU, reference) call: search (out_mv / out_sad), refinement of the winners or of the caller's integer MVs
+// (refine_had >= 0: out_qmv / out_cost), or both.  With refinement the staged window carries a halo of kRefineHalo samples.
+int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref0, int ref_stride, const hmme_search_params* p,
+             bool do_search, const int16_t* int_mv, int refine_had, int16_t* out_mv, uint32_t* out_sad, int16_t* out_qmv, uint32_t* out_cost) {
   if (!ctx) return HMME_ERR_ARG;
-  if (!ctu || !ref0 || !p || !out_mv || !out_sad) return fail(ctx, HMME_ERR_ARG, "hmme_search_ctu: null argument");
+  const bool refine = refine_had >= 0;
+  if (!ctu || !ref0 || !p || (do_search && (!out_mv || !out_sad)) || (refine && (!out_qmv || !out_cost)) || (!do_search && !int_mv))
+    return fail(ctx, HMME_ERR_ARG, "hmme_search_ctu: null argument");
+  const int halo = refine ? kRefineHalo : 0;
   if (p->bit_depth < 8 || p->bit_depth > 12) return fail(ctx, HMME_ERR_UNSUPPORTED, "bit depth %d outside 8..12", p->bit_depth);
   // MeJob carries the window and the predictor as int16 (what TComMv holds, TComMv.h:51-55): anything wider would address
   // the staged window at a truncated offset
@@ -451,6 +464,8 @@ int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
     return fail(ctx, HMME_ERR_RANGE, "hmme_search_ctu: current-block sample outside [%d, %d] (bit depth %d)", -maxv, 2 * maxv, p->bit_depth);
   const bool wide = p->bit_depth > 8 || bipred_origin;
   const int bias = bipred_origin ? (1 << p->bit_depth) : 0;
+  // xPatternSearchFracDIF on 2*org - pred_other (the bBi pass) stays with the caller: the refinement kernel works on samples
+  if (refine && bipred_origin) return fail(ctx, HMME_ERR_UNSUPPORTED, "refinement of a bi-prediction origin (current-block samples outside [0, %d])", maxv);
   // unshifted sums must fit the 24-bit cost field of the 16-bit kernel's keys (me_kernels.hpp kInvCost16)
   if (p->shift_free && p->bit_depth > (bipred_origin ? 9 : 10))
     return fail(ctx, HMME_ERR_UNSUPPORTED, "shift-free SADs at bit depth %d%s", p->bit_depth, bipred_origin ? " with a bi-prediction origin" : "");
@@ -464,8 +479,8 @@ int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
   const int bps = wide ? 2 : 1;
   uint8_t* h_ctu = ctx->h_call + kCallCtu;
   uint8_t* h_win = ctx->h_call + kCallWin;
-  const int rows = wy + 63, cols = wx + 63;
-  const int16_t* src = ref0 + (long)p->lt_y * ref_stride + p->lt_x;
+  const int rows = wy + 63 + 2 * halo, cols = wx + 63 + 2 * halo;
+  const int16_t* src = ref0 + (long)(p->lt_y - halo) * ref_stride + (p->lt_x - halo);
   int vlo = 0, vhi = 0;
   for (int y = 0; y < 64; ++y)
     for (int x = 0; x < 64; ++x) {
@@ -492,7 +507,10 @@ int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
   // the 8-bit path, strips of candidate rows on the 16-bit path) that merge through the 64-bit atomicMin table
   MeJob16* js = (MeJob16*)(ctx->h_call + kCallJobs);
   int n_wg = 0, pdw = 0, smax = 0;
-  if (!wide) {
+  if (!do_search) {
+    js[0].j = job; js[0].job = 0; js[0].y0 = js[0].y1 = 0;
+    std::memcpy(ctx->h_call + kCallImv, int_mv, sizeof(int16_t) * 2 * HMME_NUM_CTU_PARTS);
+  } else if (!wide) {
     // windows beyond 129 x 129 candidates: up to 2 x 2 tiles (tile (0,0) first: finalize decodes against its top-left)
     const int tiles_x = (wx + hmme::kTileStep - 1) / hmme::kTileStep, tiles_y = (wy + hmme::kTileStep - 1) / hmme::kTileStep;
     const int per_tile = kCallMaxJobs / (tiles_x * tiles_y);
@@ -521,40 +539,80 @@ int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
       if (js[i].y1 - js[i].y0 > smax) smax = js[i].y1 - js[i].y0;
     }
   }
+  std::memcpy(ctx->h_call + kCallFracJob, &job, sizeof job);
   {
     const int n16 = (int)((kCallWin + (size_t)rows * kWinPitch + 64 + 15) / 16);
     hipLaunchKernelGGL(hmme::me_stage_call_kernel, dim3((n16 + 255) / 256), dim3(256), 0, s, (const uint4*)ctx->h_call_dev, (uint4*)ctx->d_call, n16);
     HIP_TRY(ctx, hipGetLastError());
   }
   // the kernel addresses ref(ctu + lt): bias the base so that (lt_x, lt_y) lands on the window copy's first sample
-  const uint8_t* ref_base = ctx->d_call + kCallWin - (long)p->lt_y * kWinPitch - (long)p->lt_x * bps;
+  const uint8_t* ref_base = ctx->d_call + kCallWin - (long)(p->lt_y - halo) * kWinPitch - (long)(p->lt_x - halo) * bps;
   const MeJob16* d_js = (const MeJob16*)(ctx->d_call + kCallJobs);
   const int* d_first = (const int*)(ctx->d_call + kCallFirst);
   unsigned long long* d_best1 = (unsigned long long*)(ctx->d_call + kCallBest);
   // the 4.7 KB of results go straight into pinned host memory (mapped into the device's address space): no download step
-  int16_t* d_mv1 = (int16_t*)ctx->d_res;
-  uint32_t* d_sad1 = (uint32_t*)(ctx->d_res + 4 * HMME_NUM_CTU_PARTS);
-  int rc;
+  int16_t* d_mv1 = (int16_t*)(ctx->d_res + kResMv);
+  uint32_t* d_sad1 = (uint32_t*)(ctx->d_res + kResSad);
+  int rc = HMME_OK;
+  const uint32_t seq = ++ctx->call_seq ? ctx->call_seq : ++ctx->call_seq;   // never 0, the words' initial value
+  if (do_search) {
   if (!wide)
     rc = launch_search8_split(ctx, ctx->d_call + kCallCtu, 64, one_ref(ref_base), kWinPitch, d_js, d_first, 1, n_wg, p->fen, d_mv1, d_sad1, s, d_best1, false);
   else
     rc = launch_search16(ctx, ctx->d_call + kCallCtu, 128, one_ref(ref_base), kWinPitch, d_js, d_first, 1, n_wg, pdw, smax, p->fen, shift_bd,
                          d_mv1, d_sad1, s, d_best1, false);
   if (rc) return rc;
-  volatile uint32_t* done = (volatile uint32_t*)(ctx->h_res + 8 * HMME_NUM_CTU_PARTS);
-  const uint32_t seq = ++ctx->call_seq ? ctx->call_seq : ++ctx->call_seq;   // never 0, the word's initial value
   hipLaunchKernelGGL(hmme::me_finalize1_kernel, dim3(1), dim3(640), 0, s, d_best1, d_js, ctx->lambda_q16, d_mv1, d_sad1,
-                     (volatile uint32_t*)(ctx->d_res + 8 * HMME_NUM_CTU_PARTS), seq);
+                     (volatile uint32_t*)(ctx->d_res + kResDone), seq);
   HIP_TRY(ctx, hipGetLastError());
+  }
+  if (refine) {
+    // xPatternSearchFracDIF for the 593 slots on the block and window that are staged anyway: one more workgroup-sized kernel,
+    // its input the integer tables the finalize kernel just wrote (or the caller's), its output in the same pinned block
+    rc = build_frac_cover(ctx);
+    if (rc) return rc;
+    using frac_fn = void (*)(const uint8_t*, int, const RefSet, int, const MeJob*, const uint16_t*, const int16_t*, uint32_t, int, int16_t*, uint32_t*);
+    static const frac_fn fns[2][2] = {{hmme::me_frac_kernel<0, 1>, hmme::me_frac_kernel<1, 1>}, {hmme::me_frac_kernel<0, 2>, hmme::me_frac_kernel<1, 2>}};
+    const int16_t* d_imv = do_search ? d_mv1 : (const int16_t*)(ctx->d_call + kCallImv);
+    hipLaunchKernelGGL(fns[wide ? 1 : 0][refine_had ? 1 : 0], dim3(1), dim3(hmme::frac_threads(bps)), hmme::frac_lds_bytes(bps), s, ctx->d_call + kCallCtu,
+                       64 * bps, one_ref(ref_base), kWinPitch, (const MeJob*)(ctx->d_call + kCallFracJob), ctx->d_frac_cover, d_imv, ctx->lambda_q16,
+                       p->bit_depth, (int16_t*)(ctx->d_res + kResQmv), (uint32_t*)(ctx->d_res + kResCost));
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(hmme::me_publish_kernel, dim3(1), dim3(1), 0, s, (volatile uint32_t*)(ctx->d_res + kResDone2), seq);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  volatile uint32_t* done = (volatile uint32_t*)(ctx->h_res + (refine ? kResDone2 : kResDone));
   // the caller blocks on this call anyway (TEncSearch.cpp:3749-3758): poll the completion word for a while instead of paying the
   // interrupt wake-up of hipStreamSynchronize, then fall back to it (a faulted kernel never publishes)
   for (int spin = 0; *done != seq && spin < 200000; ++spin) __builtin_ia32_pause();
   if (*done != seq) HIP_TRY(ctx, hipStreamSynchronize(s));
   if (*done != seq) return fail(ctx, HMME_ERR_DEVICE, "hmme_search_ctu: the device did not publish results");
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  std::memcpy(out_mv, ctx->h_res, sizeof(int16_t) * 2 * HMME_NUM_CTU_PARTS);
-  std::memcpy(out_sad, ctx->h_res + 4 * HMME_NUM_CTU_PARTS, sizeof(uint32_t) * HMME_NUM_CTU_PARTS);
+  if (do_search) {
+    std::memcpy(out_mv, ctx->h_res + kResMv, sizeof(int16_t) * 2 * HMME_NUM_CTU_PARTS);
+    std::memcpy(out_sad, ctx->h_res + kResSad, sizeof(uint32_t) * HMME_NUM_CTU_PARTS);
+  }
+  if (refine) {
+    std::memcpy(out_qmv, ctx->h_res + kResQmv, sizeof(int16_t) * 2 * HMME_NUM_CTU_PARTS);
+    std::memcpy(out_cost, ctx->h_res + kResCost, sizeof(uint32_t) * HMME_NUM_CTU_PARTS);
+  }
   return HMME_OK;
+}
+}  // namespace
+
+int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref0, int ref_stride,
+                    const hmme_search_params* p, int16_t* out_mv, uint32_t* out_sad) {
+  return ctu_call(ctx, ctu, ctu_stride, ref0, ref_stride, p, true, nullptr, -1, out_mv, out_sad, nullptr, nullptr);
+}
+
+int hmme_search_refine_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref0, int ref_stride, const hmme_search_params* p,
+                           int use_hadamard, int16_t* out_mv, uint32_t* out_sad, int16_t* out_qmv, uint32_t* out_cost) {
+  return ctu_call(ctx, ctu, ctu_stride, ref0, ref_stride, p, true, nullptr, use_hadamard ? 1 : 0, out_mv, out_sad, out_qmv, out_cost);
+}
+
+int hmme_refine_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref0, int ref_stride, const hmme_search_params* p,
+                    const int16_t* int_mv, int use_hadamard, int16_t* out_qmv, uint32_t* out_cost) {
+  return ctu_call(ctx, ctu, ctu_stride, ref0, ref_stride, p, false, int_mv, use_hadamard ? 1 : 0, nullptr, nullptr, out_qmv, out_cost);
 }
 
 // ---- planes ----------------------------------------------------------------------------------------------

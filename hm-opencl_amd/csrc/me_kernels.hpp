@@ -592,6 +592,13 @@ me_finalize1_kernel(const unsigned long long* __restrict__ g_best, const MeJob16
   if (o == 0) { *done_flag = seq; __threadfence_system(); }
 }
 
+// completion word of a per-CTU call whose last kernel is not the finalize kernel (search + refinement)
+__global__ void me_publish_kernel(volatile uint32_t* done_flag, uint32_t seq) {
+  __threadfence_system();
+  *done_flag = seq;
+  __threadfence_system();
+}
+
 __global__ void me_prep_jobs16_kernel(MeJob16* jobs, int* first_strip_of_job, const int16_t* __restrict__ pred_q,
                                       int ctu_first, int ctu_count, int n_refs, int pic_w, int pic_h, int sr, int n_strips) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

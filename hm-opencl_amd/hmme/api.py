@@ -17,7 +17,7 @@ NUM_PARTS = 593
 # every symbol include/hmme.h declares (tests check the library exports all of them)
 SYMBOLS = ["hmme_create", "hmme_destroy", "hmme_last_error", "hmme_device_info", "hmme_set_lambda",
            "hmme_set_lambda_q16", "hmme_get_lambda_q16", "hmme_params_ocl_compat", "hmme_set_search_range",
-           "hmme_slot_index", "hmme_slot_rect", "hmme_search_ctu", "hmme_plane_create", "hmme_plane_create_ex", "hmme_plane_bit_depth", "hmme_plane_destroy", "hmme_plane_upload_pel",
+           "hmme_slot_index", "hmme_slot_rect", "hmme_search_ctu", "hmme_search_refine_ctu", "hmme_refine_ctu", "hmme_plane_create", "hmme_plane_create_ex", "hmme_plane_bit_depth", "hmme_plane_destroy", "hmme_plane_upload_pel",
            "hmme_plane_upload_u8", "hmme_host_register", "hmme_host_unregister", "hmme_plane_set_device_u8", "hmme_plane_width", "hmme_plane_height",
            "hmme_num_ctus", "hmme_search_frame", "hmme_search_frame_device", "hmme_search_frame_multi",
            "hmme_search_frame_multi_device", "hmme_refine_frame", "hmme_refine_frame_multi_device",
@@ -74,6 +74,8 @@ def load():
     L.hmme_slot_index.argtypes = [i, i, i, i]
     L.hmme_slot_rect.argtypes = [i] + [C.POINTER(i)] * 4
     L.hmme_search_ctu.argtypes = [vp, vp, i, vp, i, C.POINTER(SearchParams), vp, vp]
+    L.hmme_search_refine_ctu.argtypes = [vp, vp, i, vp, i, C.POINTER(SearchParams), i, vp, vp, vp, vp]
+    L.hmme_refine_ctu.argtypes = [vp, vp, i, vp, i, C.POINTER(SearchParams), vp, i, vp, vp]
     L.hmme_plane_create.argtypes = [vp, i, i, C.POINTER(vp)]
     L.hmme_plane_create_ex.argtypes = [vp, i, i, i, C.POINTER(vp)]
     L.hmme_plane_bit_depth.argtypes = [vp]
@@ -194,6 +196,32 @@ class Engine:
         self._check(self.L.hmme_search_ctu(self.h, cp, cur.shape[1], rp, ref.shape[1], C.byref(params),
                                            mv.ctypes.data, sad.ctypes.data))
         return mv, sad
+
+    def search_refine_ctu(self, cur_plane, cur_xy, ref_plane, ref_xy, params, use_hadamard=True):
+        """hmme_search_ctu + xPatternSearchFracDIF of its winners in one call
+        -> (mv int16[593,2], sad uint32[593], qmv int16[593,2] quarter-pel, cost uint32[593])"""
+        cur = np.ascontiguousarray(cur_plane, dtype=np.int16)
+        ref = np.ascontiguousarray(ref_plane, dtype=np.int16)
+        mv, qmv = np.zeros((NUM_PARTS, 2), np.int16), np.zeros((NUM_PARTS, 2), np.int16)
+        sad, cost = np.zeros(NUM_PARTS, np.uint32), np.zeros(NUM_PARTS, np.uint32)
+        cp = cur.ctypes.data + 2 * (cur_xy[1] * cur.shape[1] + cur_xy[0])
+        rp = ref.ctypes.data + 2 * (ref_xy[1] * ref.shape[1] + ref_xy[0])
+        self._check(self.L.hmme_search_refine_ctu(self.h, cp, cur.shape[1], rp, ref.shape[1], C.byref(params), int(use_hadamard),
+                                                  mv.ctypes.data, sad.ctypes.data, qmv.ctypes.data, cost.ctypes.data))
+        return mv, sad, qmv, cost
+
+    def refine_ctu(self, cur_plane, cur_xy, ref_plane, ref_xy, params, int_mv, use_hadamard=True):
+        """xPatternSearchFracDIF for the 593 slots of one CTU at the caller's integer MVs -> (qmv int16[593,2], cost uint32[593])"""
+        cur = np.ascontiguousarray(cur_plane, dtype=np.int16)
+        ref = np.ascontiguousarray(ref_plane, dtype=np.int16)
+        imv = np.ascontiguousarray(int_mv, dtype=np.int16)
+        assert imv.shape == (NUM_PARTS, 2)
+        qmv, cost = np.zeros((NUM_PARTS, 2), np.int16), np.zeros(NUM_PARTS, np.uint32)
+        cp = cur.ctypes.data + 2 * (cur_xy[1] * cur.shape[1] + cur_xy[0])
+        rp = ref.ctypes.data + 2 * (ref_xy[1] * ref.shape[1] + ref_xy[0])
+        self._check(self.L.hmme_refine_ctu(self.h, cp, cur.shape[1], rp, ref.shape[1], C.byref(params), imv.ctypes.data, int(use_hadamard),
+                                           qmv.ctypes.data, cost.ctypes.data))
+        return qmv, cost
 
     def search_frame(self, cur, ref, sr, pred_q=None, fen=1, bit_depth=None, ctu_first=0, ctu_count=-1):
         """-> (mv int16[count,593,2], sad uint32[count,593])"""

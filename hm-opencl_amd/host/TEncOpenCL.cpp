@@ -10,12 +10,13 @@
 TEncOpenCL::TEncOpenCL()
     : m_ctx(0), m_deviceId(0), m_deviceFound(false), m_enabled(false), m_lastOk(false), m_searchRange(0),
       m_mode(ME_MODE_OCL_COMPAT), m_fen(false), m_bitDepth(0), m_bi(0), m_lambda(0.0), m_calls(0), m_failed(0), m_edgeCalls(0),
-      m_biCalls(0), m_verified(0), m_verifyFailed(0) {
+      m_biCalls(0), m_verified(0), m_verifyFailed(0), m_refine(false), m_refineHad(true), m_fracOk(false),
+      m_fracMvTab(0), m_fracDistTab(0), m_fracCostTab(0) {
   for (Int b = 0; b < 2; b++) {
     xPoison(m_tab[b]);   // tables nobody filled yet must not look like results either
   }
   for (Int l = 0; l < 2; l++)
-    for (Int r = 0; r < 33; r++) { m_tagPoc[l][r] = -0x7fffffff; m_tagCtu[l][r] = -1; }
+    for (Int r = 0; r < 33; r++) { m_tagPoc[l][r] = -0x7fffffff; m_tagCtu[l][r] = -1; m_fracTag[l][r] = false; }
 }
 
 TEncOpenCL::~TEncOpenCL() {
@@ -24,11 +25,16 @@ TEncOpenCL::~TEncOpenCL() {
             "%ld differ, device: %s\n", m_calls, m_failed, m_edgeCalls, m_biCalls, m_verified, m_verifyFailed, m_ctx ? hmme_device_info(m_ctx) : "none");
   if (m_ctx) hmme_destroy(m_ctx);
   m_ctx = 0;
+  delete[] m_fracMvTab; delete[] m_fracDistTab; delete[] m_fracCostTab;
 }
 
 Bool TEncOpenCL::slotRect(Int slot, Int& x, Int& y, Int& w, Int& h) { return hmme_slot_rect(slot, &x, &y, &w, &h) == HMME_OK; }
 Bool TEncOpenCL::hmModeEnabled() {
   static const Int on = (std::getenv("HMME_HM_MODE") && std::getenv("HMME_HM_MODE")[0] == '0') ? 0 : 1;
+  return on != 0;
+}
+Bool TEncOpenCL::gpuFracEnabled() {
+  static const Int on = (std::getenv("HMME_GPU_FRAC") && std::getenv("HMME_GPU_FRAC")[0] == '1') ? 1 : 0;
   return on != 0;
 }
 Bool TEncOpenCL::verifyEnabled() {
@@ -125,8 +131,20 @@ Void TEncOpenCL::calcMotionVectors(Pel* pelCtu, Pel* pelSearch, Int iRefStride, 
   typedef char tcommv_is_two_shorts[sizeof(TComMv) == 4 ? 1 : -1];   // C++98-friendly static asserts
   typedef char distortion_is_u32[sizeof(Distortion) == 4 ? 1 : -1];
   (void)sizeof(tcommv_is_two_shorts); (void)sizeof(distortion_is_u32);
-  if (hmme_search_ctu(m_ctx, pelCtu, iCtuStride, pelSearch, iRefStride, &p, reinterpret_cast<int16_t*>(t.mv),
-                      reinterpret_cast<uint32_t*>(t.cost)) != HMME_OK) {
+  // refinement rides along on uni-prediction calls with HM's arithmetic; where the engine cannot refine (a bi-prediction origin
+  // slipped in, ...) the integer search still runs and fracOk() says so
+  const Bool wantFrac = m_refine && !m_bi && m_mode == ME_MODE_HM;
+  m_fracOk = false;
+  Int rc = HMME_ERR_UNSUPPORTED;
+  if (wantFrac) {
+    rc = hmme_search_refine_ctu(m_ctx, pelCtu, iCtuStride, pelSearch, iRefStride, &p, m_refineHad ? 1 : 0, reinterpret_cast<int16_t*>(t.mv),
+                                reinterpret_cast<uint32_t*>(t.cost), reinterpret_cast<int16_t*>(m_qmv), reinterpret_cast<uint32_t*>(m_fracCost));
+    m_fracOk = rc == HMME_OK;
+    m_fracPred = m_pred;
+  }
+  if (rc != HMME_OK)
+    rc = hmme_search_ctu(m_ctx, pelCtu, iCtuStride, pelSearch, iRefStride, &p, reinterpret_cast<int16_t*>(t.mv), reinterpret_cast<uint32_t*>(t.cost));
+  if (rc != HMME_OK) {
     fprintf(stderr, "ERROR: TEncOpenCL::calcMotionVectors: %s\n", hmme_last_error(m_ctx));
     xPoison(t);
     return;
@@ -159,4 +177,34 @@ Void TEncOpenCL::calcMotionVectorsEdge(const Pel* pelCtuInPic, Int iPicStride, I
   ++m_edgeCalls;
   calcMotionVectors(block, pelSearch, iRefStride, HMME_CTU_SIZE, i_areaSize, &lt);
   m_mode = mode; m_pred = savePred; m_rb = saveRb;
+}
+
+namespace {
+// TComRdCost::xGetComponentBits (TComRdCost.cpp:278-292)
+UInt componentBits(Int v) {
+  UInt len = 1;
+  UInt t = (v <= 0) ? ((UInt)(-v) << 1) + 1 : ((UInt)v << 1);
+  while (t != 1) { t >>= 1; len += 2; }
+  return len;
+}
+}  // namespace
+
+Void TEncOpenCL::storeFrac(Int list, Int refIdx) {
+  if (list < 0 || list > 1 || refIdx < 0 || refIdx >= 33) return;
+  m_fracTag[list][refIdx] = false;
+  if (!m_fracOk || !m_ctx) return;
+  if (!m_fracMvTab) {
+    m_fracMvTab = new TComMv[2][33][NUM_CTU_PARTS];
+    m_fracDistTab = new Distortion[2][33][NUM_CTU_PARTS];
+    m_fracCostTab = new Distortion[2][33][NUM_CTU_PARTS];
+  }
+  const UInt lq = hmme_get_lambda_q16(m_ctx);
+  for (Int i = 0; i < NUM_CTU_PARTS; i++) {
+    // TComRdCost::getCost(x, y) at cost scale 0 (TComRdCost.h:172-189): uint32 product, >> 16
+    const UInt mvCost = (lq * (componentBits(m_qmv[i].getHor() - m_fracPred.getHor()) + componentBits(m_qmv[i].getVer() - m_fracPred.getVer()))) >> 16;
+    m_fracMvTab[list][refIdx][i] = m_qmv[i];
+    m_fracCostTab[list][refIdx][i] = m_fracCost[i];
+    m_fracDistTab[list][refIdx][i] = m_fracCost[i] - mvCost;
+  }
+  m_fracTag[list][refIdx] = true;
 }

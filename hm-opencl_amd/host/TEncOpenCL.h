@@ -68,6 +68,28 @@ class TEncOpenCL {
   const TComMv* getMvs(Bool bi) const { return m_tab[bi ? 1 : 0].mv; }
   const Distortion* getRuiCost(Bool bi) const { return m_tab[bi ? 1 : 0].cost; }
 
+  // ---- additive: fractional-pel refinement tables ----
+  /// While on, every uni-prediction ME_MODE_HM call also runs TEncSearch::xPatternSearchFracDIF (TEncSearch.cpp:4294-4331) for the
+  /// 593 slots on the device (one engine call, hmme_search_refine_ctu): getQMvs() / getFracCost() then hold, per slot, the
+  /// quarter-pel MV (int << 2) + (half << 1) + quarter and the ruiCost that function returns, MV cost priced against the CTU's
+  /// predictor.  fracOk() tells whether the last call produced them (bi-prediction origins and failed calls do not).
+  Void setRefine(Bool on, Bool hadamard = true) { m_refine = on; m_refineHad = hadamard; }
+  Bool fracOk() const { return m_fracOk; }
+  const TComMv* getQMvs() const { return m_qmv; }
+  const Distortion* getFracCost() const { return m_fracCost; }
+  /// keep the refinement tables of the last call for [list][refIdx] (the caller's allMotionVectors / allRuiCost have no room for
+  /// them, TEncSearch.h:114-115); the stored distortion is the cost minus the MV cost against the CTU predictor, so that a PU can
+  /// add the MV cost against ITS predictor (TEncSearch.cpp:3806-3808 does the same with the bits)
+  Void storeFrac(Int list, Int refIdx);
+  Bool fracStored(Int list, Int refIdx, Int poc, Int ctuAddr) const {
+    return tablesValidFor(list, refIdx, poc, ctuAddr) && m_fracTag[list][refIdx];
+  }
+  const TComMv& getFracMv(Int list, Int refIdx, Int slot) const { return m_fracMvTab[list][refIdx][slot]; }
+  Distortion getFracDist(Int list, Int refIdx, Int slot) const { return m_fracDistTab[list][refIdx][slot]; }
+  Distortion getFracCostStored(Int list, Int refIdx, Int slot) const { return m_fracCostTab[list][refIdx][slot]; }
+  /// HMME_GPU_FRAC=1: the patched encoder serves xPatternSearchFracDIF (TEncSearch.cpp:3798) from these tables
+  static Bool gpuFracEnabled();
+
   // ---- additive: picture-edge CTUs ----
   /// A CTU that crosses the picture border is never coded as one 64x64 CU (TEncCu.cpp:424-425), so the reference never
   /// sends it to the GPU and its sub-CUs look up the PREVIOUS CTU's tables.  This runs the same search for such a CTU:
@@ -82,7 +104,7 @@ class TEncOpenCL {
     return list >= 0 && list < 2 && refIdx >= 0 && refIdx < 33 && m_tagPoc[list][refIdx] == poc && m_tagCtu[list][refIdx] == ctuAddr;
   }
   Void markTables(Int list, Int refIdx, Int poc, Int ctuAddr) {
-    if (list >= 0 && list < 2 && refIdx >= 0 && refIdx < 33) { m_tagPoc[list][refIdx] = poc; m_tagCtu[list][refIdx] = ctuAddr; }
+    if (list >= 0 && list < 2 && refIdx >= 0 && refIdx < 33) { m_tagPoc[list][refIdx] = poc; m_tagCtu[list][refIdx] = ctuAddr; m_fracTag[list][refIdx] = false; }
   }
   long numCalls() const { return m_calls; }
   long numFailed() const { return m_failed; }
@@ -122,6 +144,14 @@ class TEncOpenCL {
   TComMv m_lastLT, m_lastRB;
   Tables m_tab[2];                     // [0] uni-prediction, [1] bi-prediction refinement
   Int m_tagPoc[2][33], m_tagCtu[2][33];
+  Bool m_refine, m_refineHad, m_fracOk;
+  TComMv m_qmv[NUM_CTU_PARTS];
+  Distortion m_fracCost[NUM_CTU_PARTS];
+  TComMv m_fracPred;                   // predictor the refinement of the last call priced its MVs against
+  Bool m_fracTag[2][33];
+  TComMv (*m_fracMvTab)[33][NUM_CTU_PARTS];          // [2][33][593], allocated on first use (313 KB + 2 x 157 KB)
+  Distortion (*m_fracDistTab)[33][NUM_CTU_PARTS];
+  Distortion (*m_fracCostTab)[33][NUM_CTU_PARTS];
 };
 
 #endif

@@ -12,6 +12,8 @@
  *   hmme_search_ctu        <- TEncOpenCL::calcMotionVectors + getX/getY/getRuiCost
  *                             (TEncOpenCL.cpp:240-362, TEncOpenCL.h:117-119; caller
  *                             TEncSearch::xMotionEstimation, TEncSearch.cpp:3743-3765)
+ *   hmme_refine_ctu,       <- TEncSearch::xPatternSearchFracDIF (TEncSearch.cpp:4294-4331) for the 593 slots of that CTU,
+ *   hmme_search_refine_ctu    the per-PU call at TEncSearch.cpp:3798 turned into a table lookup like the integer search
  *   hmme_search_frame*     <- the same search batched over every CTU of a picture (the
  *                             reference has no batched form: it launches 2*(2SR+1)^2 kernels per
  *                             CTU from the host, TEncOpenCL.cpp:312-333)
@@ -119,6 +121,21 @@ int hmme_slot_rect(int slot, int* x, int* y, int* w, int* h);
  * out_mv: int16[593][2] (hor, ver), out_sad: uint32[593] (pure SAD at the arg-min = ruiCost). */
 int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref_at_ctu_origin,
                     int ref_stride, const hmme_search_params* p, int16_t* out_mv, uint32_t* out_sad);
+
+/* The step after the search, for the same CTU: TEncSearch::xPatternSearchFracDIF (TEncSearch.cpp:4294-4331, called per PU at :3798)
+ * for all 593 slots -- half- then quarter-pel refinement around each slot's integer MV, HM's 8-tap interpolation, Hadamard
+ * (use_hadamard, HadamardME) or SAD distortion, MV cost against p->pred.  out_qmv: int16[593][2] quarter-pel MVs
+ * (int << 2) + (half << 1) + quarter; out_cost: uint32[593], the ruiCost xPatternSearchFracDIF returns (distortion + MV cost).
+ * hmme_search_refine_ctu = hmme_search_ctu + the refinement of its winners in ONE call (block and window are staged once);
+ * hmme_refine_ctu refines the caller's integer MVs int_mv[593][2] (entries outside the window LT..RB are clamped to it).
+ * Unlike hmme_search_ctu these read the reference 4 samples (+ up to 3 for alignment) beyond the window (64 + 2*SR)^2 on every
+ * side -- the interpolation filter's support, which xPatternSearchFracDIF reads as well (HM planes carry an 80-sample margin).
+ * Bi-prediction origins (current-block samples outside [0, maxv]) are HMME_ERR_UNSUPPORTED here; shift_free is ignored. */
+int hmme_search_refine_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref_at_ctu_origin, int ref_stride,
+                           const hmme_search_params* p, int use_hadamard, int16_t* out_mv, uint32_t* out_sad, int16_t* out_qmv,
+                           uint32_t* out_cost);
+int hmme_refine_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref_at_ctu_origin, int ref_stride,
+                    const hmme_search_params* p, const int16_t* int_mv, int use_hadamard, int16_t* out_qmv, uint32_t* out_cost);
 
 /* ---- frame path ------------------------------------------------------------------------ */
 /* device-resident luma plane with edge-replicated margins; 8-bit planes store bytes, 9..12-bit planes u16 */

@@ -121,6 +121,47 @@ int main() {
     }
     if (std::memcmp(me.getMvs(true), me.getMvs(false), sizeof uniMv) == 0) { fprintf(stderr, "bi tables equal uni tables?\n"); ++failures; }
   }
+  // ---- refinement tables: setRefine makes a uni-prediction ME_MODE_HM call also run xPatternSearchFracDIF for
+  // the 593 slots; storeFrac keeps them per [list][refIdx] with the MV cost taken out
+  {
+    const int cu_x = 64, cu_y = 64;
+    Pel* piCtu = &cur[(M + cu_y) * stride + M + cu_x];
+    Pel* piRefY = &ref[(M + cu_y) * stride + M + cu_x];
+    me.setCostMode(TEncOpenCL::ME_MODE_HM);
+    me.setFastEnc(true);
+    me.setRefine(true, true);
+    int ltx, lty, rbx, rby;
+    hmo_set_search_range(-9, 14, SR, cu_x, cu_y, W, H, 64, &ltx, &lty, &rbx, &rby);
+    TComMv lt((Short)ltx, (Short)lty);
+    me.setPredictor(TComMv(-9, 14));
+    me.setSearchRangeRB(TComMv((Short)rbx, (Short)rby));
+    me.calcMotionVectors(piCtu, piRefY, stride, stride, SR, &lt);
+    if (!me.lastCallOk() || !me.fracOk()) { fprintf(stderr, "search + refine call failed\n"); ++failures; }
+    me.markTables(1, 2, 40, 9);
+    me.storeFrac(1, 2);
+    if (!me.fracStored(1, 2, 40, 9) || me.fracStored(1, 2, 40, 8) || me.fracStored(0, 2, 40, 9)) { fprintf(stderr, "frac table tags\n"); ++failures; }
+    const uint32_t lq = hmo_lambda_q16(lambda);
+    for (int slot = 0; slot < NUM_CTU_PARTS; slot += 16) {
+      hmo_rect r;
+      hmo_slot_rect(slot, &r);
+      const TComMv imv = me.getMvs()[slot];
+      int hx, hy, qx, qy;
+      uint32_t cost;
+      hmo_frac_refine(piCtu + r.y * stride + r.x, stride, r.w, r.h, piRefY + r.y * stride + r.x, stride, imv.getHor(), imv.getVer(), -9, 14, lq, 1, 8,
+                      &hx, &hy, &qx, &qy, &cost);
+      const int wx = 4 * imv.getHor() + 2 * hx + qx, wy = 4 * imv.getVer() + 2 * hy + qy;
+      if (me.getQMvs()[slot].getHor() != wx || me.getQMvs()[slot].getVer() != wy || me.getFracCost()[slot] != cost) {
+        if (failures < 10) fprintf(stderr, "refinement slot %d: got (%d,%d,%u) want (%d,%d,%u)\n", slot, me.getQMvs()[slot].getHor(), me.getQMvs()[slot].getVer(),
+                                   me.getFracCost()[slot], wx, wy, cost);
+        ++failures;
+      }
+      const uint32_t mvc = hmo_mv_cost(lq, wx, wy, -9, 14, 0);
+      if (me.getFracDist(1, 2, slot) + mvc != cost || me.getFracCostStored(1, 2, slot) != cost || me.getFracMv(1, 2, slot).getHor() != wx) {
+        fprintf(stderr, "stored refinement slot %d\n", slot); ++failures;
+      }
+    }
+    me.setRefine(false);
+  }
   // ---- picture-edge CTU: 192x128 has none, so pretend the picture ends inside CTU (2,1): 40 x 24 valid
   {
     const int cu_x = 128, cu_y = 64, vw = 40, vh = 24, pw = cu_x + vw, ph = cu_y + vh;

@@ -859,3 +859,57 @@ def test_sequence_driver_reads_a_yuv_file(tmp_path):
     assert d["gpus"] == 1 and d["first_pairs"][0] == [1, 0] and d["first_pairs"][1] == [2, 1]
     # picture t = texture shifted by (2t, t): cur(x) = ref(x + mv) with mv = (2, 1) * (cur - ref)
     assert d["median_mv_64x64_of_first_pairs"][0] == [2, 1] and d["median_mv_64x64_of_first_pairs"][2] == [4, 2]
+
+
+def test_refine_ctu_matches_reference_goldens(engine):
+    """hmme_refine_ctu == the reference's own TEncSearch::xPatternSearchFracDIF (tests/golden/frac.npz: 160 PUs of all shapes, 8/10 bit,
+    Hadamard / SAD, generated from the compiled reference): per-CTU refinement at the caller's integer MVs"""
+    from hmme import api
+    d = np.load(os.path.join(GOLDEN, "frac.npz"))
+    planes = {8: (np.ascontiguousarray(d["cur8"]), np.ascontiguousarray(d["ref8"])),
+              10: (np.ascontiguousarray(d["cur10"]), np.ascontiguousarray(d["ref10"]))}
+    n = 0
+    for row, want in zip(d["rows"], d["out"]):
+        slot, x, y, w, h, ix, iy, px, py, had, bd, lq, o = (int(v) for v in row)
+        cur, ref = planes[bd]
+        engine.set_lambda_q16(lq)
+        imv = np.zeros((593, 2), np.int16)
+        imv[slot] = (ix, iy)
+        p = api.SearchParams(-8, -8, 8, 8, px, py, 1, bd)
+        qmv, cost = engine.refine_ctu(cur, (o, o), ref, (o, o), p, imv, use_hadamard=bool(had))
+        hx, hy, qx, qy, c = (int(v) for v in want)
+        assert (int(qmv[slot, 0]), int(qmv[slot, 1]), int(cost[slot])) == (4 * ix + 2 * hx + qx, 4 * iy + 2 * hy + qy, c), row
+        n += 1
+    assert n == 160
+
+
+@pytest.mark.parametrize("bd,sr,had", [(8, 16, 1), (8, 64, 0), (10, 24, 1), (8, 100, 1), (12, 128, 0)])
+def test_search_refine_ctu_vs_oracle(engine, oracle_lib, bd, sr, had):
+    """hmme_search_refine_ctu: one call = hmme_search_ctu (identical integer tables) + xPatternSearchFracDIF of the winners for all 593
+    slots, on the block and window staged once (8-bit windows beyond 129 x 129 run as tiles, 9..12 bit on the 16-bit kernels)"""
+    from hmme import api, synth
+    w = h = 64 + 2 * sr + 16
+    cur_p, ref_p, _ = synth.make_pair(w, h, seed=bd * 1000 + sr, bit_depth=bd, max_mv=min(sr, 20), region=48, noise_sigma=2.0, margin=0)
+    o = sr + 8                                             # CTU origin: window + 4-sample halo + alignment slack stay inside the plane
+    engine.set_lambda(57.9)
+    pred = (13, -22)
+    p = api.SearchParams(-sr, -sr, sr, sr - 1, pred[0], pred[1], 1, bd)
+    mv, sad, qmv, cost = engine.search_refine_ctu(cur_p, (o, o), ref_p, (o, o), p, use_hadamard=bool(had))
+    mv0, sad0 = engine.search_ctu(cur_p, (o, o), ref_p, (o, o), p)
+    assert np.array_equal(mv, mv0) and np.array_equal(sad, sad0)
+    ox, oy, osad = oracle_lib.search_ctu(cur_p, (o, o), ref_p, (o, o), oracle_lib.make_params((-sr, -sr), (sr, sr - 1), pred, engine.lambda_q16, 1, bd))
+    assert np.array_equal(mv[:, 0], ox) and np.array_equal(mv[:, 1], oy) and np.array_equal(sad, osad)
+    table = oracle_lib.slot_table()
+    rng = np.random.default_rng(sr)
+    for s in list(rng.choice(593, size=60, replace=False)) + [592, 588, 576, 0, 128, 256, 300, 384]:
+        x, y, bw, bh = (int(v) for v in table[s])
+        imv = (int(mv[s, 0]), int(mv[s, 1]))
+        hx, hy, qx, qy, c = oracle_lib.frac_refine(cur_p, (o + x, o + y), ref_p, (o + x, o + y), bw, bh, imv, pred, engine.lambda_q16, had, bd)
+        assert (int(qmv[s, 0]), int(qmv[s, 1]), int(cost[s])) == (4 * imv[0] + 2 * hx + qx, 4 * imv[1] + 2 * hy + qy, c), (s, imv)
+    # refinement of a bi-prediction origin stays with the caller
+    cur2 = cur_p.copy()
+    cur2[o + 3, o + 3] = -7
+    with pytest.raises(api.HmmeError, match="bi-prediction"):
+        engine.search_refine_ctu(cur2, (o, o), ref_p, (o, o), p)
+    mv2, sad2 = engine.search_ctu(cur2, (o, o), ref_p, (o, o), p)     # ... the search itself takes it
+    assert mv2.shape == (593, 2)

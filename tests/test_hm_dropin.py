@@ -102,3 +102,23 @@ def test_patched_encoder_hm_mode_equals_hm_cpu_search(tmp_path, cfg, bipred):
     bits, bits_full = sum(b for _, b, _ in p[1:]), sum(b for _, b, _ in pf[1:])
     assert bits < 1.06 * bits_full + 500, (bits, bits_full)
     print("hm mode:", p, "\nFastSearch=0:", pf, "\n", m.group(0))
+
+
+@pytest.mark.gpu
+def test_patched_encoder_gpu_refinement_tables(tmp_path):
+    """HMME_GPU_FRAC=1: xPatternSearchFracDIF (TEncSearch.cpp:3798) served from the tables hmme_search_refine_ctu fills in the
+    same engine call as the integer search.  HMME_VERIFY=1 additionally runs HM's own refinement for every 64x64 2Nx2N PU: the
+    quarter-pel MV and ruiCost from the table must be identical.  Smaller PUs price the MV against their own predictor."""
+    _build()
+    common = dict(frames=4, w=208, h=120, exe=EXE_HM, cfg=CFG, extra=("--SearchRange=24",))
+    r, p = _encode(tmp_path, 1, env_extra={"HMME_VERIFY": "1", "HMME_GPU_FRAC": "1"}, **common)
+    m = _TRACE.search(r.stderr)
+    assert m, r.stderr[-1500:]
+    calls, failed, edge, bi, verified, differ = (int(v) for v in m.groups())
+    assert failed == 0 and differ == 0 and calls > 0, m.group(0)
+    r1, p1 = _encode(tmp_path, 1, env_extra={"HMME_VERIFY": "1"}, **common)
+    assert verified > int(_TRACE.search(r1.stderr).group(5))          # the refinement checks came on top of the integer ones
+    bits, bits_cpu_frac = sum(b for _, b, _ in p[1:]), sum(b for _, b, _ in p1[1:])
+    assert abs(bits - bits_cpu_frac) < 0.05 * bits_cpu_frac + 300, (bits, bits_cpu_frac)
+    assert all(abs(a[2] - b[2]) < 0.5 for a, b in zip(p, p1))
+    print("GPU refinement tables:", p, "\nCPU xPatternSearchFracDIF:", p1, "\n", m.group(0))

@@ -13,7 +13,7 @@ int main() {
   struct Case { const char* name; int sr, bd; } cases[] = {{"8bit_sr64", 64, 8}, {"8bit_sr8", 8, 8}, {"8bit_sr128", 128, 8}, {"10bit_sr64", 64, 10}, {"10bit_sr128", 128, 10}};
   printf("{");
   for (const Case& c : cases) {
-    const int side = 64 + 2 * c.sr + 8, maxv = (1 << c.bd) - 1;
+    const int side = 64 + 2 * c.sr + 16, maxv = (1 << c.bd) - 1;
     std::vector<int16_t> cur(64 * 64), ref((size_t)side * side);
     srand(1);
     for (auto& v : cur) v = (int16_t)(rand() % (maxv + 1));
@@ -21,7 +21,7 @@ int main() {
     hmme_search_params p = {-c.sr, -c.sr, c.sr, c.sr, 5, -3, 1, c.bd};
     std::vector<int16_t> mv(2 * HMME_NUM_CTU_PARTS);
     std::vector<uint32_t> sad(HMME_NUM_CTU_PARTS);
-    const int16_t* r0 = ref.data() + (size_t)(c.sr + 4) * side + (c.sr + 4);
+    const int16_t* r0 = ref.data() + (size_t)(c.sr + 8) * side + (c.sr + 8);   // 8 samples of margin: window + refinement halo
     for (int i = 0; i < 5; ++i)
       if (hmme_search_ctu(ctx, cur.data(), 64, r0, side, &p, mv.data(), sad.data()) != HMME_OK) { fprintf(stderr, "%s\n", hmme_last_error(ctx)); return 1; }
     const int n = 200;
@@ -29,6 +29,23 @@ int main() {
     for (int i = 0; i < n; ++i) hmme_search_ctu(ctx, cur.data(), 64, r0, side, &p, mv.data(), sad.data());
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / n;
     printf("%s\"%s_ms_per_call\": %.4f", &c == cases ? "" : ", ", c.name, ms);
+    // the same call with the refinement of the winners riding along (hmme_search_refine_ctu): on unrelated content nearly every slot
+    // has its own MV (nothing shared between slots: the refinement's worst case), on a displaced copy of the reference one MV
+    std::vector<int16_t> qmv(2 * HMME_NUM_CTU_PARTS);
+    std::vector<uint32_t> cost(HMME_NUM_CTU_PARTS);
+    std::vector<int16_t> moved(64 * 64);
+    for (int y = 0; y < 64; ++y)
+      for (int x = 0; x < 64; ++x) moved[y * 64 + x] = r0[(size_t)(y + 3) * side + x - 5];
+    const int16_t* blocks[2] = {cur.data(), moved.data()};
+    const char* tags[2] = {"search_refine_unrelated", "search_refine_coherent"};
+    for (int k = 0; k < 2; ++k) {
+      for (int i = 0; i < 3; ++i)
+        if (hmme_search_refine_ctu(ctx, blocks[k], 64, r0, side, &p, 1, mv.data(), sad.data(), qmv.data(), cost.data()) != HMME_OK) { fprintf(stderr, "%s\n", hmme_last_error(ctx)); return 1; }
+      const auto t1 = std::chrono::steady_clock::now();
+      for (int i = 0; i < n; ++i) hmme_search_refine_ctu(ctx, blocks[k], 64, r0, side, &p, 1, mv.data(), sad.data(), qmv.data(), cost.data());
+      const double ms2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count() / n;
+      printf(", \"%s_%s_ms_per_call\": %.4f", c.name, tags[k], ms2);
+    }
   }
   printf("}\n");
   hmme_destroy(ctx);

@@ -44,11 +44,14 @@ def main():
     for name, exe, extra in (("CPU TZ search (FastSearch=1)", EXE, ["--OpenCL=0", "--FastSearch=1"]),
                              ("CPU full search (FastSearch=0)", EXE, ["--OpenCL=0", "--FastSearch=0"]),
                              ("hmme, reference call sites (ME_MODE_OCL_COMPAT)", EXE, ["--OpenCL=1", "--FastSearch=1", "--KernelOpenCL=embedded"]),
-                             ("hmme, tools/hm_patch (ME_MODE_HM, bi-pred tables, edge CTUs)", EXE_HM, ["--OpenCL=1", "--FastSearch=1", "--KernelOpenCL=embedded"])):
+                             ("hmme, tools/hm_patch (ME_MODE_HM, bi-pred tables, edge CTUs)", EXE_HM, ["--OpenCL=1", "--FastSearch=1", "--KernelOpenCL=embedded"]),
+                             ("hmme, tools/hm_patch + HMME_GPU_FRAC=1 (refinement tables too)", EXE_HM, ["--OpenCL=1", "--FastSearch=1", "--KernelOpenCL=embedded"])):
         t0 = time.time()
         env = dict(os.environ, HMME_TRACE="1")
         if args.verify and exe == EXE_HM:
             env["HMME_VERIFY"] = "1"
+        if "GPU_FRAC" in name:
+            env["HMME_GPU_FRAC"] = "1"
         r = subprocess.run([exe, "-c", CFG, "-i", src, "-wdt", str(w), "-hgt", str(h), "-fr", "30", "-f", str(args.frames),
                             f"--SearchRange={args.search_range}", "-b", os.path.join(tmp, "s.bin"), *extra],
                            capture_output=True, text=True, env=env, cwd=tmp)
