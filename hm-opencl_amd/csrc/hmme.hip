@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -431,6 +432,20 @@ int hmme_slot_rect(int slot, int* x, int* y, int* w, int* h) {
 namespace {
 int build_frac_cover(hmme_ctx* ctx);
 
+// host-side packing of the call block, one picture row at a time; separate reduction and narrowing loops so that the compiler
+// vectorises both (the reference copies the same window sample by sample, TEncOpenCL.cpp:275-277)
+inline void row_minmax(const int16_t* __restrict__ s, int n, int& lo, int& hi) {
+  int16_t l = (int16_t)(lo < -32768 ? -32768 : lo), h = (int16_t)(hi > 32767 ? 32767 : hi);
+  for (int x = 0; x < n; ++x) { l = s[x] < l ? s[x] : l; h = s[x] > h ? s[x] : h; }
+  lo = l; hi = h;
+}
+inline void row_pack8(const int16_t* __restrict__ s, int n, uint8_t* __restrict__ d) {
+  for (int x = 0; x < n; ++x) d[x] = (uint8_t)s[x];
+}
+inline void row_pack16(const int16_t* __restrict__ s, int n, int bias, uint16_t* __restrict__ d) {
+  for (int x = 0; x < n; ++x) d[x] = (uint16_t)(s[x] + bias);
+}
+
 // One (CTU, reference) call: search (out_mv / out_sad), refinement of the winners or of the caller's integer MVs
 // (refine_had >= 0: out_qmv / out_cost), or both.  With refinement the staged window carries a halo of kRefineHalo samples.
 int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref0, int ref_stride, const hmme_search_params* p,
@@ -453,11 +468,7 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
   // TComYuv::removeHighFreq TComYuv.cpp:409-440, unclipped).  They stay exact: the 16-bit kernel runs on samples
   // biased by 2^bitDepth (|a - b| is unchanged), so pick the kernel after looking at the data.
   int lo = 0, hi = 0;
-  for (int y = 0; y < 64; ++y)
-    for (int x = 0; x < 64; ++x) {
-      const int v = ctu[y * ctu_stride + x];
-      lo = v < lo ? v : lo; hi = v > hi ? v : hi;
-    }
+  for (int y = 0; y < 64; ++y) row_minmax(ctu + (long)y * ctu_stride, 64, lo, hi);
   const int wx = p->rb_x - p->lt_x + 1, wy = p->rb_y - p->lt_y + 1;
   const bool bipred_origin = lo < 0 || hi > maxv;
   if (lo < -maxv || hi > 2 * maxv)
@@ -482,19 +493,16 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
   const int rows = wy + 63 + 2 * halo, cols = wx + 63 + 2 * halo;
   const int16_t* src = ref0 + (long)(p->lt_y - halo) * ref_stride + (p->lt_x - halo);
   int vlo = 0, vhi = 0;
-  for (int y = 0; y < 64; ++y)
-    for (int x = 0; x < 64; ++x) {
-      const int v = ctu[y * ctu_stride + x] + bias;
-      if (wide) ((uint16_t*)h_ctu)[y * 64 + x] = (uint16_t)v; else h_ctu[y * 64 + x] = (uint8_t)v;
-    }
+  for (int y = 0; y < 64; ++y) {
+    if (wide) row_pack16(ctu + (long)y * ctu_stride, 64, bias, (uint16_t*)h_ctu + y * 64);
+    else row_pack8(ctu + (long)y * ctu_stride, 64, h_ctu + y * 64);
+  }
   for (int y = 0; y < rows; ++y) {
     uint8_t* row = h_win + (size_t)y * kWinPitch;
     const int16_t* srow = src + (long)y * ref_stride;
-    if (wide) {
-      for (int x = 0; x < cols; ++x) { const int v = srow[x]; vlo = v < vlo ? v : vlo; vhi = v > vhi ? v : vhi; ((uint16_t*)row)[x] = (uint16_t)(v + bias); }
-    } else {
-      for (int x = 0; x < cols; ++x) { const int v = srow[x]; vlo = v < vlo ? v : vlo; vhi = v > vhi ? v : vhi; row[x] = (uint8_t)v; }
-    }
+    row_minmax(srow, cols, vlo, vhi);
+    if (wide) row_pack16(srow, cols, bias, (uint16_t*)row);
+    else row_pack8(srow, cols, row);
     std::memset(row + cols * bps, 0, 16);   // the kernels stage whole dwords past the last sample
   }
   if (vlo < 0 || vhi > maxv) return fail(ctx, HMME_ERR_RANGE, "hmme_search_ctu: reference sample outside [0,%d] for bit depth %d", maxv, p->bit_depth);
@@ -682,7 +690,8 @@ static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_para
   *pdw = fp->search_range <= 64 ? kPdw16Small : kPdw16Large;
   *n_strips = wide ? strips_for(*pdw, 2 * fp->search_range + 1) : 1;
   *strip_rows = (2 * fp->search_range + 1 + *n_strips - 1) / *n_strips;
-  if (!wide && jobs < 384) {
+  static const int split_below = std::getenv("HMME_SPLIT_BELOW") ? std::atoi(std::getenv("HMME_SPLIT_BELOW")) : 384;   // A/B knob, DESIGN.md 8
+  if (!wide && jobs < split_below) {
     // fewer CTU searches than workgroup slots (256 CUs x 2): cut each one's task list so that ~768 workgroups exist,
     // but never below 4 tasks (one per wave) per workgroup
     const int nt = hmme::me_num_tasks(2 * fp->search_range + 1, 2 * fp->search_range + 1);
