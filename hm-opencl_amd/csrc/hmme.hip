@@ -49,6 +49,11 @@ struct hmme_ctx {
   std::string err;
   std::string info;
   hipStream_t stream = nullptr;   // private stream of the synchronous entry points
+  // frame-path scratch (job tables, merge table, cover table) is shared by every call of the context: a call on another stream
+  // than the previous one first waits (stream-side) for that one's last use
+  hipEvent_t scratch_done = nullptr;
+  hipStream_t scratch_stream = nullptr;
+  bool scratch_used = false;
   // per-CTU path: one device block and its pinned host mirror -- jobs, first-strip index, merge table preset, current
   // block, window -- so that a call is one upload, the kernels, one download (layout: kCall* offsets below)
   uint8_t* d_call = nullptr;
@@ -87,6 +92,9 @@ struct hmme_plane {
   uint8_t* d_data = nullptr;
   void* d_stage = nullptr;  // device staging for uploads
   size_t stage_bytes = 0;
+  hipEvent_t filled = nullptr;      // recorded after the last fill; readers on another stream wait for it
+  hipStream_t fill_stream = nullptr;
+  bool fill_pending = false;
   const uint8_t* origin() const { return d_data + (size_t)kMarginY * pitch + (size_t)kMarginX * bps; }
 };
 
@@ -116,6 +124,21 @@ int ensure(hmme_ctx* ctx, T** p, size_t* cap_bytes, size_t bytes) {
   *p = nullptr; *cap_bytes = 0;
   HIP_TRY(ctx, hipMalloc((void**)p, bytes));
   *cap_bytes = bytes;
+  return HMME_OK;
+}
+
+// cross-stream ordering (see hmme.h "Streams"): scratch of the context, contents of a plane
+int scratch_acquire(hmme_ctx* ctx, hipStream_t s) {
+  if (ctx->scratch_used && ctx->scratch_stream != s) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->scratch_done, 0));
+  return HMME_OK;
+}
+int scratch_release(hmme_ctx* ctx, hipStream_t s) {
+  HIP_TRY(ctx, hipEventRecord(ctx->scratch_done, s));
+  ctx->scratch_stream = s; ctx->scratch_used = true;
+  return HMME_OK;
+}
+int plane_wait(hmme_ctx* ctx, const hmme_plane* pl, hipStream_t s) {
+  if (pl->fill_pending && pl->fill_stream != s) HIP_TRY(ctx, hipStreamWaitEvent(s, pl->filled, 0));
   return HMME_OK;
 }
 
@@ -250,6 +273,8 @@ int plane_fill(hmme_plane* pl, const SrcT* d_src, int src_pitch_elems, hipStream
   hipLaunchKernelGGL((hmme::me_fill_plane_kernel<SrcT, DstT>), grid, dim3(256), 0, s, pl->d_data, pl->pitch, kMarginX, kMarginY,
                      pl->width, pl->height, d_src, src_pitch_elems, (1 << pl->bit_depth) - 1, ctx->d_flag);
   HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipEventRecord(pl->filled, s));
+  pl->fill_stream = s; pl->fill_pending = true;
   if (check) {
     int flag = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&flag, ctx->d_flag, sizeof flag, hipMemcpyDeviceToHost, s));
@@ -315,6 +340,7 @@ int hmme_create(int device, int sr_max, unsigned flags, hmme_ctx** out) {
     if (e_ != hipSuccess) { int rc = fail(nullptr, HMME_ERR_NOMEM, "hmme_create: %s -> %s", #call, hipGetErrorString(e_)); hmme_destroy(ctx); return rc; } \
   } while (0)
   CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  CREATE_TRY(hipEventCreateWithFlags(&ctx->scratch_done, hipEventDisableTiming));
   CREATE_TRY(hipMalloc(&ctx->d_call, kCallWin + win_bytes));
   CREATE_TRY(hipHostMalloc(&ctx->h_call, kCallWin + win_bytes, hipHostMallocMapped));
   CREATE_TRY(hipHostGetDevicePointer((void**)&ctx->h_call_dev, ctx->h_call, 0));
@@ -334,6 +360,7 @@ void hmme_destroy(hmme_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   if (ctx->stream) { hipStreamSynchronize(ctx->stream); hipStreamDestroy(ctx->stream); }
+  if (ctx->scratch_done) hipEventDestroy(ctx->scratch_done);
   hipFree(ctx->d_call);
   hipFree(ctx->d_jobs); hipFree(ctx->d_first_strip); hipFree(ctx->d_best);
   hipFree(ctx->d_pred); hipFree(ctx->d_mv); hipFree(ctx->d_sad); hipFree(ctx->d_flag);
@@ -635,7 +662,8 @@ int hmme_plane_create_ex(hmme_ctx* ctx, int width, int height, int bit_depth, hm
   pl->pitch = ((width + 2 * kMarginX) * pl->bps + 255) & ~255;
   pl->rows = height + 2 * kMarginY;
   hipError_t e = hipMalloc(&pl->d_data, (size_t)pl->pitch * (pl->rows + 1));
-  if (e != hipSuccess) { delete pl; return fail(ctx, HMME_ERR_NOMEM, "hipMalloc plane: %s", hipGetErrorString(e)); }
+  if (e == hipSuccess && (e = hipEventCreateWithFlags(&pl->filled, hipEventDisableTiming)) != hipSuccess) hipFree(pl->d_data);
+  if (e != hipSuccess) { delete pl; return fail(ctx, HMME_ERR_NOMEM, "plane allocation: %s", hipGetErrorString(e)); }
   *out = pl;
   return HMME_OK;
 }
@@ -644,6 +672,8 @@ int hmme_plane_create(hmme_ctx* ctx, int width, int height, hmme_plane** out) { 
 void hmme_plane_destroy(hmme_plane* pl) {
   if (!pl) return;
   hipSetDevice(pl->ctx->device);
+  if (pl->fill_pending) hipEventSynchronize(pl->filled);   // a fill still in flight must not outlive the buffer
+  if (pl->filled) hipEventDestroy(pl->filled);
   hipFree(pl->d_data);
   hipFree(pl->d_stage);
   delete pl;
@@ -756,10 +786,16 @@ int hmme_search_frame_multi_device(hmme_ctx* ctx, const hmme_plane* cur, const h
   if (count == 0) return HMME_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
-  int n_strips, pdw, strip_rows;
-  int rc = prep_jobs(ctx, cur, fp, d_pred_q, first, count, n_refs, s, &n_strips, &pdw, &strip_rows);
+  int rc = scratch_acquire(ctx, s);
+  if (rc == HMME_OK) rc = plane_wait(ctx, cur, s);
+  for (int r = 0; r < n_refs && rc == HMME_OK; ++r) rc = plane_wait(ctx, refs[r], s);
   if (rc) return rc;
-  return run_search(ctx, cur, set, refs[0]->pitch, fp, count * n_refs, n_strips, pdw, strip_rows, (int16_t*)d_out_mv, (uint32_t*)d_out_sad, s);
+  int n_strips, pdw, strip_rows;
+  rc = prep_jobs(ctx, cur, fp, d_pred_q, first, count, n_refs, s, &n_strips, &pdw, &strip_rows);
+  if (rc) return rc;
+  rc = run_search(ctx, cur, set, refs[0]->pitch, fp, count * n_refs, n_strips, pdw, strip_rows, (int16_t*)d_out_mv, (uint32_t*)d_out_sad, s);
+  if (rc) return rc;
+  return scratch_release(ctx, s);
 }
 
 int hmme_search_frame_device(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp,
@@ -861,6 +897,10 @@ int hmme_refine_frame_multi_device(hmme_ctx* ctx, const hmme_plane* cur, const h
   ctx->jobs_bytes = cap;
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
+  rc = scratch_acquire(ctx, s);
+  if (rc == HMME_OK) rc = plane_wait(ctx, cur, s);
+  for (int r = 0; r < n_refs && rc == HMME_OK; ++r) rc = plane_wait(ctx, refs[r], s);
+  if (rc) return rc;
   hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, dim3((jobs + 255) / 256), dim3(256), 0, s, (MeJob*)ctx->d_jobs, (const int16_t*)d_pred_q,
                      first, count, n_refs, cur->width, cur->height, fp->search_range);
   HIP_TRY(ctx, hipGetLastError());
@@ -872,7 +912,7 @@ int hmme_refine_frame_multi_device(hmme_ctx* ctx, const hmme_plane* cur, const h
                      cur->pitch, set, refs[0]->pitch, (const MeJob*)ctx->d_jobs, ctx->d_frac_cover, (const int16_t*)d_int_mv, ctx->lambda_q16,
                      fp->bit_depth, (int16_t*)d_out_qmv, (uint32_t*)d_out_cost);
   HIP_TRY(ctx, hipGetLastError());
-  return HMME_OK;
+  return scratch_release(ctx, s);
 }
 
 int hmme_refine_frame(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp, const int16_t* pred_q,
@@ -916,6 +956,10 @@ int hmme_time_search_kernel(hmme_ctx* ctx, const hmme_plane* cur, const hmme_pla
   if (!avg_ms || reps < 1) return fail(ctx, HMME_ERR_ARG, "hmme_time_search_kernel: bad reps/avg_ms");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
+  rc = scratch_acquire(ctx, s);
+  if (rc == HMME_OK) rc = plane_wait(ctx, cur, s);
+  if (rc == HMME_OK) rc = plane_wait(ctx, ref, s);
+  if (rc) return rc;
   // job table once (it is not part of the timed kernel), then `reps` launches of the search kernel(s) alone
   int n_strips, pdw, strip_rows;
   rc = prep_jobs(ctx, cur, fp, d_pred_q, first, count, 1, s, &n_strips, &pdw, &strip_rows);
@@ -935,7 +979,7 @@ int hmme_time_search_kernel(hmme_ctx* ctx, const hmme_plane* cur, const hmme_pla
   if (rc) return rc;
   if (e != hipSuccess) return fail(ctx, HMME_ERR_DEVICE, "timing the search kernel: %s", hipGetErrorString(e));
   *avg_ms = ms / reps;
-  return HMME_OK;
+  return scratch_release(ctx, s);
 }
 
 }  // extern "C"

@@ -33,13 +33,13 @@
  * window LT..LT+2*SR, all rows).
  *
  * Threading: a context is not thread-safe; use one per host thread / per GPU.
- * Streams: a context owns scratch (job tables, merge tables, staging) that every call reuses, so at most ONE
- * stream may have work of a given context in flight at a time: before a *_device call on stream B, work this
- * context put on stream A must have completed (or B must wait on an event recorded on A after it).  The
- * synchronous host-facing calls (hmme_search_ctu, hmme_search_frame*, hmme_refine_frame, hmme_plane_upload_*)
- * run on a private non-blocking stream of the context and return when done; they are NOT ordered after work the
- * caller queued on its own streams -- synchronise a hmme_plane_set_device_u8 (or any *_device call whose output
- * they read) before calling them.
+ * Streams: a context owns scratch (job tables, merge tables, staging) that every frame call reuses, and planes are filled
+ * asynchronously by hmme_plane_set_device_u8.  The library orders these itself: a *_device call issued on another stream than the
+ * context's previous frame call first waits -- on the device, with hipStreamWaitEvent, never blocking the host -- for that call's
+ * last use of the scratch, and every search / refinement waits for the last fill of each plane it reads if that fill ran on
+ * another stream.  So calls of one context may be spread over streams; they serialise where they share scratch.  Output buffers
+ * are the caller's: reading d_out_* on another stream than the one passed in needs the caller's own event.  The synchronous
+ * host-facing calls run on a private non-blocking stream of the context and return when done.
  * Every function returns HMME_OK (0) or a negative HMME_ERR_* code; nothing ever falls back
  * to a CPU implementation.
  */

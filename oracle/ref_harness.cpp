@@ -189,4 +189,23 @@ void ref_frac_refine(int16_t* org, int org_stride, int w, int h, int16_t* ref_at
   *half_x = half.getHor(); *half_y = half.getVer(); *qter_x = qter.getHor(); *qter_y = qter.getVer(); *cost = d;
 }
 
+// TComPicYuv::create + extendPicBorder (TComPicYuv.cpp:80-133, :214-262): a w x h luma picture goes in, the whole padded buffer
+// (margin maxCU + 16 on every side) comes out.  out must hold (*out_stride) * (h + 2 * margin) samples; returns the margin.
+int ref_extend_border(const int16_t* img, int img_stride, int w, int h, int max_cu, int16_t* out, int out_capacity, int* out_stride) {
+  initROM();
+  TComPicYuv pic;
+  pic.create(w, h, CHROMA_400, max_cu, max_cu, 4, true);
+  const int stride = pic.getStride(COMPONENT_Y), total_h = pic.getTotalHeight(COMPONENT_Y), margin = pic.getMarginX(COMPONENT_Y);
+  *out_stride = stride;
+  if (stride * total_h > out_capacity) { pic.destroy(); return -1; }
+  Pel* org = pic.getAddr(COMPONENT_Y);
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) org[y * stride + x] = img[y * img_stride + x];
+  pic.extendPicBorder();
+  const Pel* buf = pic.getBuf(COMPONENT_Y);
+  for (int i = 0; i < stride * total_h; ++i) out[i] = buf[i];
+  pic.destroy();
+  return margin;
+}
+
 }  // extern "C"

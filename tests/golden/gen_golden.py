@@ -13,6 +13,7 @@ Every .npz holds inputs and the reference's outputs -- data only.
   search_sr64.npz  G1  same at SR 64 (two cases)
   tz.npz           G5  xTZSearch for a set of PUs
   frac.npz             xPatternSearchFracDIF (half + quarter-pel refinement, HAD or SAD) for a set of PUs
+  border.npz           TComPicYuv::create + extendPicBorder: small pictures in, the whole padded luma buffer out
 """
 import ctypes as C
 import os
@@ -238,6 +239,23 @@ def gen_tz(table):
     print("tz:", len(rows))
 
 
+def gen_border():
+    """TComPicYuv::extendPicBorder (TComPicYuv.cpp:214-262) on pictures of awkward sizes: margin = maxCU + 16, stride = W + 2 * margin"""
+    rng = np.random.default_rng(31)
+    R.ref_extend_border.restype = C.c_int
+    d = {}
+    for i, (w, h, bd) in enumerate([(40, 24, 8), (8, 8, 8), (72, 8, 10), (8, 136, 8), (200, 136, 10)]):
+        img = rng.integers(0, 1 << bd, size=(h, w)).astype(np.int16)
+        out = np.zeros((w + 400) * (h + 400), np.int16)
+        st = C.c_int()
+        m = R.ref_extend_border(img.ctypes.data_as(C.POINTER(C.c_int16)), w, w, h, 64, out.ctypes.data_as(C.POINTER(C.c_int16)), out.size, C.byref(st))
+        assert m == 80 and st.value == w + 160
+        d[f"img{i}"] = img
+        d[f"out{i}"] = out[:st.value * (h + 2 * m)].reshape(h + 2 * m, st.value).copy()
+    np.savez_compressed(os.path.join(HERE, "border.npz"), n=np.array(5), margin=np.array(80), **d)
+    print("border: 5")
+
+
 def gen_frac(table):
     """xPatternSearchFracDIF: (PU, integer MV, predictor, lambda, HAD on/off, bit depth) -> (half, quarter, cost)"""
     rng = np.random.default_rng(23)
@@ -305,6 +323,7 @@ def main():
     gen_search(table, "search_sr64.npz", sr64)
     gen_tz(table)
     gen_frac(table)
+    gen_border()
 
 
 if __name__ == "__main__":

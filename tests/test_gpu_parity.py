@@ -913,3 +913,63 @@ def test_search_refine_ctu_vs_oracle(engine, oracle_lib, bd, sr, had):
         engine.search_refine_ctu(cur2, (o, o), ref_p, (o, o), p)
     mv2, sad2 = engine.search_ctu(cur2, (o, o), ref_p, (o, o), p)     # ... the search itself takes it
     assert mv2.shape == (593, 2)
+
+
+def test_device_border_extension_matches_reference_goldens(engine, oracle_lib):
+    """me_fill_plane_kernel (= TComPicYuv::extendPicBorder) against the reference's own padded buffers (tests/golden/border.npz): the
+    device plane is not readable through the C ABI, so the check goes through a search whose windows reach the outermost margin --
+    cur = the picture, ref = the same picture: every clipped window of every CTU must give the oracle's tables on the REFERENCE's
+    padded buffer, and SAD 0 at MV (0,0) for the 64x64 PU only if both planes were padded identically"""
+    d = np.load(os.path.join(GOLDEN, "border.npz"))
+    m = int(d["margin"])
+    for i in range(int(d["n"])):
+        img, padded = d[f"img{i}"], np.ascontiguousarray(d[f"out{i}"])
+        h, w = img.shape
+        bd = 10 if int(img.max()) > 255 else 8
+        engine.set_lambda(4.7)
+        with engine.plane(w, h, bd) as pc, engine.plane(w, h, bd) as pr:
+            pc.upload_pel(np.ascontiguousarray(img), (0, 0))      # un-padded picture in: the device extends the borders
+            pr.upload_pel(np.ascontiguousarray(img), (0, 0))
+            mv, sad = engine.search_frame(pc, pr, 64)
+        ox, oy, osad = oracle_lib.search_frame(padded, padded, (m, m), w, h, 64, None, engine.lambda_q16, 1, bd, n_threads=4)
+        assert np.array_equal(mv[:, :, 0], ox) and np.array_equal(mv[:, :, 1], oy) and np.array_equal(sad, osad), i
+        assert (mv[:, 592] == 0).all() and (sad[:, 592] == 0).all()
+
+
+def test_calls_of_one_context_spread_over_streams(engine, oracle_lib):
+    """hmme.h "Streams": plane fills, searches and refinements of ONE context issued on different streams without any caller-side
+    synchronisation between them -- the library's own events order the shared scratch and the plane contents.  Repeated with
+    alternating pictures so that a search overtaking a fill, or two launches sharing a job table, would show as wrong tables."""
+    import torch
+    from hmme import api, synth
+    w, h, sr = 256, 192, 20
+    m = synth.MARGIN
+    dev = torch.device("cuda", 0)
+    pics = [synth.make_pair(w, h, seed=70 + k, max_mv=9, region=64) for k in range(2)]
+    t_cur = [torch.from_numpy(np.ascontiguousarray(p[0][m:m + h, m:m + w].astype(np.uint8))).to(dev) for p in pics]
+    t_ref = [torch.from_numpy(np.ascontiguousarray(p[1][m:m + h, m:m + w].astype(np.uint8))).to(dev) for p in pics]
+    n_ctu = 4 * 3
+    engine.set_lambda(57.9)
+    want = [oracle_lib.search_frame(p[0], p[1], (m, m), w, h, sr, None, engine.lambda_q16, 1, 8, n_threads=4) for p in pics]
+    s_fill, s_search, s_refine = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    fp = api.FrameParams(sr, 1, 8, 0, n_ctu)
+    d_mv = [torch.zeros((n_ctu, 593, 2), dtype=torch.int16, device=dev) for _ in range(2)]
+    d_sad = [torch.zeros((n_ctu, 593), dtype=torch.int32, device=dev) for _ in range(2)]
+    d_q = torch.zeros((n_ctu, 593, 2), dtype=torch.int16, device=dev)
+    d_c = torch.zeros((n_ctu, 593), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    with engine.plane(w, h) as pc, engine.plane(w, h) as pr:
+        for it in range(12):
+            k = it & 1
+            pc.set_device_u8(t_cur[k].data_ptr(), t_cur[k].stride(0), s_fill.cuda_stream)
+            pr.set_device_u8(t_ref[k].data_ptr(), t_ref[k].stride(0), s_fill.cuda_stream)
+            engine.search_frame_device(pc, pr, fp, None, d_mv[k].data_ptr(), d_sad[k].data_ptr(), s_search.cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record(s_search)
+            s_refine.wait_event(ev)          # the caller's own buffer (d_mv) crosses streams: the caller's event
+            engine.refine_frame_multi_device(pc, [pr], fp, None, d_mv[k].data_ptr(), 1, d_q.data_ptr(), d_c.data_ptr(), s_refine.cuda_stream)
+            s_refine.synchronize()
+            # the next iteration refills the planes on s_fill while nothing else is pending: the refinement just finished reading them
+            got_mv, got_sad = d_mv[k].cpu().numpy(), d_sad[k].cpu().numpy().astype(np.uint32)
+            assert np.array_equal(got_mv[:, :, 0], want[k][0]) and np.array_equal(got_mv[:, :, 1], want[k][1]) and np.array_equal(got_sad, want[k][2]), it
+            assert np.abs(d_q.cpu().numpy().astype(np.int32) - 4 * got_mv.astype(np.int32)).max() <= 3

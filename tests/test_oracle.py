@@ -127,6 +127,25 @@ def test_extend_border(oracle_lib):
     assert np.array_equal(buf, np.pad(img, ((my, my), (mx, mx)), mode="edge"))
 
 
+def test_extend_border_matches_reference_goldens(oracle_lib):
+    # reference: TComPicYuv::create + extendPicBorder (TComPicYuv.cpp:80-133, :214-262) -- margin maxCU + 16 = 80, stride W + 160;
+    # the oracle's restatement and synth.pad_plane (what every frame test feeds the oracle with) must both reproduce the buffer
+    from hmme import synth
+    d = g("border.npz")
+    L = oracle_lib.oracle()
+    m = int(d["margin"])
+    assert m == synth.MARGIN
+    for i in range(int(d["n"])):
+        img, want = d[f"img{i}"], d[f"out{i}"]
+        h, w = img.shape
+        assert want.shape == (h + 2 * m, w + 2 * m)
+        buf = np.zeros_like(want)
+        buf[m:m + h, m:m + w] = img
+        L.hmo_extend_border(oracle_lib._addr(buf, m * buf.shape[1] + m), buf.shape[1], w, h, m, m)
+        assert np.array_equal(buf, want), i
+        assert np.array_equal(synth.pad_plane(img), want), i
+
+
 def test_search_frame_matches_per_ctu(oracle_lib):
     from hmme import synth
     w, h, sr = 160, 136, 8   # partial CTUs on both edges
