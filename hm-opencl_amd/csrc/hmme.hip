@@ -199,6 +199,13 @@ int launch_search8_split(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const
 
 size_t lds_bytes16(int pdw, int strip_rows) { return (size_t)(2 * 594 + 64 * 8 * 4 + 4 + (strip_rows + 63) * pdw) * 4; }
 
+// most candidate rows of one strip whose window rows (+ 63) fit the LDS budget
+int rows_max16(int pdw) {
+  int r = 1;
+  while (lds_bytes16(pdw, r + 1) <= kLdsBudget16) ++r;
+  return r;
+}
+
 // strips of candidate rows so that one strip's window rows fit the LDS budget
 int strips_for(int pdw, int wy_max) {
   int n = 1;
@@ -718,8 +725,13 @@ static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_para
   const bool wide = fp->bit_depth > 8;
   const int jobs = count * n_refs;
   *pdw = fp->search_range <= 64 ? kPdw16Small : kPdw16Large;
-  *n_strips = wide ? strips_for(*pdw, 2 * fp->search_range + 1) : 1;
-  *strip_rows = (2 * fp->search_range + 1 + *n_strips - 1) / *n_strips;
+  *n_strips = 1;
+  *strip_rows = 2 * fp->search_range + 1;
+  if (wide) {   // strips of the balanced height for the full window (me_strip_rows16); clipped windows choose their own within n_strips
+    const int w = 2 * fp->search_range + 1, rmax = rows_max16(*pdw);
+    *strip_rows = rmax;
+    *n_strips = (w + hmme::me_strip_rows16(w, rmax) - 1) / hmme::me_strip_rows16(w, rmax);
+  }
   static const int split_below = std::getenv("HMME_SPLIT_BELOW") ? std::atoi(std::getenv("HMME_SPLIT_BELOW")) : 384;   // A/B knob, DESIGN.md 8
   if (!wide && jobs < split_below) {
     // fewer CTU searches than workgroup slots (256 CUs x 2): cut each one's task list so that ~768 workgroups exist,
@@ -754,7 +766,7 @@ static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_para
                        n_refs, cur->width, cur->height, fp->search_range);
   else
     hipLaunchKernelGGL(hmme::me_prep_jobs16_kernel, grid, block, 0, s, (MeJob16*)ctx->d_jobs, ctx->d_first_strip,
-                       (const int16_t*)d_pred_q, first, count, n_refs, cur->width, cur->height, fp->search_range, *n_strips);
+                       (const int16_t*)d_pred_q, first, count, n_refs, cur->width, cur->height, fp->search_range, *n_strips, *strip_rows);
   HIP_TRY(ctx, hipGetLastError());
   return HMME_OK;
 }

@@ -28,10 +28,17 @@ constexpr int kWinRowsMax = 192;       // (2*64+1) + 63
 constexpr int kIdxBits = 10;           // key = cost << 10 | iter(2) | lane(6) | j(2)
 constexpr uint32_t kInvCost = 3146751u;  // > any valid cost (<= 1047552 + 65535); + max SAD stays < 2^22
 constexpr int kGroups = 10;
+// lane-iterations per task (<= 4: 2 iteration bits in the key).  A task ends with the flush of ten running-minimum registers into the
+// CTU's LDS table; whole-picture launches run 4 per task (measured on 2160p: 1 / 2 / 4 -> 3 252 / 3 256 / 3 284 GSAD/s,
+// profiles/r02f_*), split launches (one CTU dealt to many workgroups, where the number of tasks is the parallelism) keep 2
 #ifndef ME_ITER_PER_TASK
-#define ME_ITER_PER_TASK 2
+#define ME_ITER_PER_TASK 4
 #endif
-constexpr int kIterPerTask = ME_ITER_PER_TASK;   // <= 4 (2 iteration bits in the key)
+#ifndef ME_ITER_PER_TASK_SPLIT
+#define ME_ITER_PER_TASK_SPLIT 2
+#endif
+constexpr int kIterPerTask = ME_ITER_PER_TASK;
+constexpr int kIterPerTaskSplit = ME_ITER_PER_TASK_SPLIT;
 constexpr int kThreads = 256;
 
 // one CTU search: everything in integer pels except the quarter-pel predictor
@@ -173,20 +180,33 @@ struct MeJob16 {
   int32_t job;         // index into the result arrays
 };
 
-// number of tasks me_search_kernel makes out of a wx x wy window (same arithmetic on host and device)
+// number of tasks me_search_kernel makes out of a wx x wy window (same arithmetic on host and device; the default is the split
+// kernel's task size: host code and the prep kernels only count tasks for split launches)
 // "fold": with 33 quads per row (the 129-wide window) and an odd number of rows, the 32-quad part's last iteration has an
 // idle second row of lanes; its first lanes take the leftover quads of the LAST window row, so the narrow parts stop one
 // row earlier (129 rows: 2 iterations of 64 rows instead of 3)
 __host__ __device__ inline bool me_fold(int quads, int wy) { return (quads & 32) && (quads & 31) && (wy & 1); }
-__host__ __device__ inline int me_num_tasks(int wx, int wy) {
+__host__ __device__ inline int me_num_tasks(int wx, int wy, int iter_per_task = kIterPerTaskSplit) {
   const int quads = (wx + 3) >> 2;
   const int wy_low = me_fold(quads, wy) ? wy - 1 : wy;
   int n = 0;
   for (int k = 5; k >= 0; --k)
-    if (quads & (1 << k)) n += (((k == 5 ? wy : wy_low) + (64 >> k) - 1) / (64 >> k) + kIterPerTask - 1) / kIterPerTask;
+    if (quads & (1 << k)) n += (((k == 5 ? wy : wy_low) + (64 >> k) - 1) / (64 >> k) + iter_per_task - 1) / iter_per_task;
   return n;
 }
 static_assert(sizeof(MeJob16) == 24, "MeJob16 layout");
+
+// 16-bit kernel: height of the strips a wx-wide window is cut into, given the most rows LDS holds (rows_max).  The four waves of a
+// workgroup pull lane-iterations from a counter; a strip whose even-column pass has a multiple of 4 iterations ends with all four
+// waves busy (37 iterations = 10 + 9 + 9 + 9: a quarter of the last round idle).  Iterations of the even pass of a strip of h rows:
+// ceil(h * pairs / 64), pairs = lanes per window row (the odd pass has at most as many).  Picks the largest h <= rows_max with a
+// multiple of 4, unless that costs more than an eighth of the height.
+__host__ __device__ inline int me_strip_rows16(int wx, int rows_max) {
+  const int pairs = (((wx + 1) >> 1) + 1) >> 1;
+  for (int h = rows_max; h >= rows_max - rows_max / 8 && h >= 4; --h)
+    if ((((h * pairs + 63) >> 6) & 3) == 0) return h;
+  return rows_max;
+}
 
 
 // ---- the search kernel --------------------------------------------------------------------------
@@ -249,7 +269,8 @@ me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefS
   // -- 2. task list: the ceil(wx/4) candidate quads of a row are split into power-of-two parts
   //       (129 -> 32 + 1); part k lays a wave out as 2^k quads x (64 >> k) rows per iteration.
   const int quads = (wx + 3) >> 2;
-  const int n_tasks = min(me_num_tasks(wx, wy), t_end);
+  constexpr int kIt = SPLIT ? kIterPerTaskSplit : kIterPerTask;
+  const int n_tasks = min(me_num_tasks(wx, wy, kIt), t_end);
   const bool fold = me_fold(quads, wy);
   const int wy_low = fold ? wy - 1 : wy;
 
@@ -269,8 +290,8 @@ me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefS
       for (int kk = 5; kk >= 0; --kk) {
         if (!(quads & (1 << kk))) continue;
         const int iters = ((kk == 5 ? wy : wy_low) + (64 >> kk) - 1) / (64 >> kk);
-        const int nt = (iters + kIterPerTask - 1) / kIterPerTask;
-        if (rem < nt) { x0 = xq * 4; k = kk; it0 = rem * kIterPerTask; n_it = min(kIterPerTask, iters - it0); break; }
+        const int nt = (iters + kIt - 1) / kIt;
+        if (rem < nt) { x0 = xq * 4; k = kk; it0 = rem * kIt; n_it = min(kIt, iters - it0); break; }
         rem -= nt;
         xq += 1 << kk;
       }
@@ -600,7 +621,7 @@ __global__ void me_publish_kernel(volatile uint32_t* done_flag, uint32_t seq) {
 }
 
 __global__ void me_prep_jobs16_kernel(MeJob16* jobs, int* first_strip_of_job, const int16_t* __restrict__ pred_q,
-                                      int ctu_first, int ctu_count, int n_refs, int pic_w, int pic_h, int sr, int n_strips) {
+                                      int ctu_first, int ctu_count, int n_refs, int pic_w, int pic_h, int sr, int n_strips, int rows_max) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ctu_count * n_refs) return;
   const int r = i / ctu_count;
@@ -617,11 +638,15 @@ __global__ void me_prep_jobs16_kernel(MeJob16* jobs, int* first_strip_of_job, co
   j.pred_x = (int16_t)px; j.pred_y = (int16_t)py;
   const int wy = rby - lty + 1;
   first_strip_of_job[i] = i * n_strips;
-  for (int s = 0; s < n_strips; ++s) {          // equal strips; empty ones (clipped windows) have y0 == y1
+  // strips of the balanced height (me_strip_rows16) while they cover the window within n_strips, the last one takes the rest;
+  // otherwise equal strips.  Strips beyond the window (clipped windows) are empty: y0 == y1
+  int h = me_strip_rows16(rbx - ltx + 1, rows_max);
+  if ((wy + h - 1) / h > n_strips) h = (wy + n_strips - 1) / n_strips;
+  for (int s = 0; s < n_strips; ++s) {
     MeJob16 js;
     js.j = j;
-    js.y0 = (int16_t)((long)wy * s / n_strips);
-    js.y1 = (int16_t)((long)wy * (s + 1) / n_strips);
+    js.y0 = (int16_t)min(wy, s * h);
+    js.y1 = (int16_t)min(wy, (s + 1) * h);
     js.job = i;
     jobs[i * n_strips + s] = js;
   }
