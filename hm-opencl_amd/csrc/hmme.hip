@@ -730,7 +730,7 @@ static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_para
   if (wide) {   // strips of the balanced height for the full window (me_strip_rows16); clipped windows choose their own within n_strips
     const int w = 2 * fp->search_range + 1, rmax = rows_max16(*pdw);
     *strip_rows = rmax;
-    *n_strips = (w + hmme::me_strip_rows16(w, rmax) - 1) / hmme::me_strip_rows16(w, rmax);
+    *n_strips = std::max(strips_for(*pdw, w), (w + hmme::me_strip_rows16(w, rmax) - 1) / hmme::me_strip_rows16(w, rmax));
   }
   static const int split_below = std::getenv("HMME_SPLIT_BELOW") ? std::atoi(std::getenv("HMME_SPLIT_BELOW")) : 384;   // A/B knob, DESIGN.md 8
   if (!wide && jobs < split_below) {

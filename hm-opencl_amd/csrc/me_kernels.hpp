@@ -152,11 +152,14 @@ __device__ __forceinline__ uint32_t me_mv_cost(uint32_t lambda_q16, int x, int y
   return (lambda_q16 * (me_component_bits((x << 2) - pred_x) + me_component_bits((y << 2) - pred_y))) >> 16;
 }
 
-constexpr int kIdxBits16 = 8;              // key = cost << 8 | iter(1) | lane(6) | j(1): 24-bit cost field
+#ifndef ME_IDX16
+#define ME_IDX16 8
+#endif
+constexpr int kIdxBits16 = ME_IDX16;       // key = cost << 8 | iter(1) | lane(6) | j(1): 24-bit cost field  (9: two iteration bits, 23-bit cost)
 // > any valid cost: bi-pred origins <= 3 142 656 + 65 535; shift-free 10-bit sums (hmme_search_params::shift_free, what
 // cl/sad.cl computes) <= 4 190 208 + 65 535; shift-free 9-bit bi-pred origins <= 6 279 168 + 65 535.  kInvCost16 + the
 // largest sum an invalid lane can add (6 279 168) stays < 2^24
-constexpr uint32_t kInvCost16 = 8000000u;
+constexpr uint32_t kInvCost16 = ME_IDX16 == 8 ? 8000000u : 4000000u;
 #ifndef ME_ITER_PER_TASK16
 #define ME_ITER_PER_TASK16 2
 #endif
@@ -556,7 +559,7 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const Re
       const uint32_t key = (key_);                                                                                 \
       const uint32_t cost = key >> kIdxBits16;                                                                       \
       if (slot >= 0 && cost < kInvCost16) {                                                                          \
-        const int kq = (it0 + (int)((key >> 7) & 1)) * 64 + (int)((key >> 1) & 63);                                \
+        const int kq = (it0 + (int)((key >> 7) & ((1 << (kIdxBits16 - 7)) - 1))) * 64 + (int)((key >> 1) & 63);    \
         const int krow = kq / pairs;                                                                               \
         const int bx = par + 4 * (kq - krow * pairs) + 2 * (int)(key & 1);                                         \
         atomicMin(&best64[slot], ((unsigned long long)cost << 32) | ((unsigned long long)(jb.y0 + krow) << 16) |   \
@@ -640,8 +643,11 @@ __global__ void me_prep_jobs16_kernel(MeJob16* jobs, int* first_strip_of_job, co
   first_strip_of_job[i] = i * n_strips;
   // strips of the balanced height (me_strip_rows16) while they cover the window within n_strips, the last one takes the rest;
   // otherwise equal strips.  Strips beyond the window (clipped windows) are empty: y0 == y1
+  // ... and while the last strip is not a sliver: workgroups of very different length pack badly into the launch's rounds
+  // (129 rows as 62 + 62 + 5 measured 8 % slower than 43 + 43 + 43)
   int h = me_strip_rows16(rbx - ltx + 1, rows_max);
-  if ((wy + h - 1) / h > n_strips) h = (wy + n_strips - 1) / n_strips;
+  const int n_h = (wy + h - 1) / h, last = wy - (n_h - 1) * h;
+  if (n_h > n_strips || 2 * last < h) h = (wy + n_strips - 1) / n_strips;
   for (int s = 0; s < n_strips; ++s) {
     MeJob16 js;
     js.j = j;

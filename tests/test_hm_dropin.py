@@ -122,3 +122,24 @@ def test_patched_encoder_gpu_refinement_tables(tmp_path):
     assert abs(bits - bits_cpu_frac) < 0.05 * bits_cpu_frac + 300, (bits, bits_cpu_frac)
     assert all(abs(a[2] - b[2]) < 0.5 for a, b in zip(p, p1))
     print("GPU refinement tables:", p, "\nCPU xPatternSearchFracDIF:", p1, "\n", m.group(0))
+
+
+@pytest.mark.gpu
+def test_encoders_at_10_bit_internal_depth(tmp_path):
+    """InternalBitDepth 10 (8-bit input, 10-bit coding): the unmodified call sites cannot tell the class the bit depth -- it takes the
+    sample width from the reference window and, like cl/sad.cl, leaves the sums unshifted; no call may fail or serve stale tables.
+    The patched encoder passes the SPS bit depth (16-bit kernels, HM's >> 2): HM's own xPatternSearch must agree on every check."""
+    _build()
+    common = dict(frames=3, w=208, h=120, cfg=CFG, extra=("--SearchRange=16", "--InternalBitDepth=10"))
+    r, p = _encode(tmp_path, 1, exe=EXE, **common)
+    m = _TRACE.search(r.stderr)
+    assert m and int(m.group(1)) > 0 and int(m.group(2)) == 0, r.stderr[-1500:]
+    r2, p2 = _encode(tmp_path, 1, exe=EXE_HM, env_extra={"HMME_VERIFY": "1", "HMME_GPU_FRAC": "1"}, **common)
+    m2 = _TRACE.search(r2.stderr)
+    calls, failed, edge, bi, verified, differ = (int(v) for v in m2.groups())
+    assert failed == 0 and differ == 0 and verified > 4 * (calls - edge), m2.group(0)
+    r0, p0 = _encode(tmp_path, 0, exe=EXE_HM, **common)
+    assert len(p) == len(p2) == len(p0) == 3
+    for (_, b0, y0), (_, b1, y1), (_, b2, y2) in zip(p0[1:], p[1:], p2[1:]):
+        assert abs(y1 - y0) < 1.5 and abs(y2 - y0) < 1.0 and b2 < 1.3 * b0 + 1000
+    print("10-bit: TZ", p0, "\ncompat", p, "\nhm mode", p2, m2.group(0))
