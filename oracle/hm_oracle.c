@@ -770,3 +770,62 @@ void hmo_frac_refine(const hmo_pel* org, int org_stride, int w, int h, const hmo
   *qter_x = k_refine_q[bi][0]; *qter_y = k_refine_q[bi][1];
   *cost = best;
 }
+
+/* ---- whole-picture refinement: hmo_frac_refine for every slot of every CTU in [ctu_first, ctu_first + ctu_count), threaded over
+ *      CTUs.  int_mv: [ctu_count][593][2] integer MVs (as hmo_search_frame / the engine produce them); pred_q: [n_ctu][2] by CTU
+ *      raster address or NULL.  out_qmv: [ctu_count][593][2] quarter-pel MVs (int << 2) + (half << 1) + quarter
+ *      (TEncSearch.cpp:3800-3803); out_cost: [ctu_count][593]. */
+typedef struct {
+  const hmo_pel *cur, *ref;
+  int cur_stride, ref_stride, pic_w, pic_h;
+  const int16_t* pred_q;
+  uint32_t lambda_q16;
+  int use_had, bit_depth, ctu_first, ctu_count, tid, n_threads;
+  const int16_t* int_mv;
+  int16_t* out_qmv;
+  uint32_t* out_cost;
+} refine_job;
+
+static void* refine_worker(void* arg) {
+  const refine_job* j = (const refine_job*)arg;
+  const int ctus_x = (j->pic_w + HMO_CTU - 1) / HMO_CTU;
+  for (int i = j->tid; i < j->ctu_count; i += j->n_threads) {
+    const int ctu = j->ctu_first + i, cx = (ctu % ctus_x) * HMO_CTU, cy = (ctu / ctus_x) * HMO_CTU;
+    const int px = j->pred_q ? j->pred_q[2 * ctu] : 0, py = j->pred_q ? j->pred_q[2 * ctu + 1] : 0;
+    for (int s = 0; s < HMO_NUM_CTU_PARTS; ++s) {
+      hmo_rect r;
+      hmo_slot_rect(s, &r);
+      const long o = (long)i * HMO_NUM_CTU_PARTS + s;
+      const int ix = j->int_mv[2 * o], iy = j->int_mv[2 * o + 1];
+      int hx, hy, qx, qy;
+      uint32_t cost;
+      hmo_frac_refine(j->cur + (long)(cy + r.y) * j->cur_stride + cx + r.x, j->cur_stride, r.w, r.h,
+                      j->ref + (long)(cy + r.y) * j->ref_stride + cx + r.x, j->ref_stride, ix, iy, px, py, j->lambda_q16, j->use_had,
+                      j->bit_depth, &hx, &hy, &qx, &qy, &cost);
+      j->out_qmv[2 * o] = (int16_t)(4 * ix + 2 * hx + qx);
+      j->out_qmv[2 * o + 1] = (int16_t)(4 * iy + 2 * hy + qy);
+      j->out_cost[o] = cost;
+    }
+  }
+  return NULL;
+}
+
+int hmo_refine_frame(const hmo_pel* cur, int cur_stride, const hmo_pel* ref, int ref_stride, int pic_w, int pic_h, const int16_t* pred_q,
+                     uint32_t lambda_q16, int use_had, int bit_depth, int ctu_first, int ctu_count, int n_threads, const int16_t* int_mv,
+                     int16_t* out_qmv, uint32_t* out_cost) {
+  const int ctus_x = (pic_w + HMO_CTU - 1) / HMO_CTU, ctus_y = (pic_h + HMO_CTU - 1) / HMO_CTU;
+  if (ctu_count < 0) ctu_count = ctus_x * ctus_y - ctu_first;
+  if (n_threads <= 0) n_threads = 1;
+  if (n_threads > 256) n_threads = 256;
+  refine_job jobs[256];
+  pthread_t th[256];
+  for (int t = 0; t < n_threads; ++t) {
+    refine_job j = {cur, ref, cur_stride, ref_stride, pic_w, pic_h, pred_q, lambda_q16, use_had, bit_depth, ctu_first, ctu_count, t, n_threads,
+                    int_mv, out_qmv, out_cost};
+    jobs[t] = j;
+  }
+  if (n_threads == 1) { refine_worker(&jobs[0]); return ctu_count; }
+  for (int t = 0; t < n_threads; ++t) pthread_create(&th[t], NULL, refine_worker, &jobs[t]);
+  for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
+  return ctu_count;
+}

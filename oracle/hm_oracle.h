@@ -117,6 +117,12 @@ void hmo_frac_refine(const hmo_pel* org, int org_stride, int w, int h, const hmo
                      int int_y, int pred_x, int pred_y, uint32_t lambda_q16, int use_had, int bit_depth, int* half_x,
                      int* half_y, int* qter_x, int* qter_y, uint32_t* cost);
 
+/* hmo_frac_refine for every slot of every CTU of a picture range, threaded over CTUs (the checker of hmme_refine_frame* at full
+ * picture sizes).  int_mv: [ctu_count][593][2]; out_qmv: [ctu_count][593][2] quarter-pel MVs; out_cost: [ctu_count][593] */
+int hmo_refine_frame(const hmo_pel* cur, int cur_stride, const hmo_pel* ref, int ref_stride, int pic_w, int pic_h, const int16_t* pred_q,
+                     uint32_t lambda_q16, int use_had, int bit_depth, int ctu_first, int ctu_count, int n_threads, const int16_t* int_mv,
+                     int16_t* out_qmv, uint32_t* out_cost);
+
 /* CPU baseline leg of bench.py: xTZSearch for the 64x64 PU (all_slots=0) or for all 593 PU
  * rectangles (all_slots=1) of every CTU in [ctu_first, ctu_first+ctu_count), threaded over CTUs.
  * probes = SAD evaluations; sad4x4 = the same work in 4x4-block-SAD equivalents (w*h/16 per probe,

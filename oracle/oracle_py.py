@@ -94,6 +94,9 @@ def oracle():
         L.hmo_frac_refine.argtypes = ([C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int16), C.c_int]
                                       + [C.c_int] * 4 + [C.c_uint32, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4
                                       + [C.POINTER(C.c_uint32)])
+        L.hmo_refine_frame.restype = C.c_int
+        L.hmo_refine_frame.argtypes = [C.POINTER(C.c_int16), C.c_int, C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hmo_had.restype = C.c_uint32
         L.hmo_had.argtypes = [C.POINTER(C.c_int16), C.c_int, C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int, C.c_int]
         L.hmo_tz_frame.restype = C.c_int
@@ -207,6 +210,26 @@ def search_frame(cur, ref_plane, origin, pic_w, pic_h, sr, pred_q, lambda_q16, f
                        pic_w, pic_h, sr, pq, int(lambda_q16), int(fen), int(bit_depth), ctu_first, n,
                        n_threads, ox.reshape(-1), oy.reshape(-1), osad.reshape(-1))
     return ox, oy, osad
+
+
+def refine_frame(cur, ref_plane, origin, pic_w, pic_h, int_mv, pred_q, lambda_q16, use_had, bit_depth, ctu_first=0, ctu_count=-1, n_threads=1):
+    """oracle xPatternSearchFracDIF for every slot of the CTUs [ctu_first, +ctu_count); int_mv: int16 [count, 593, 2]
+    -> (qmv int16 [count, 593, 2] quarter-pel, cost uint32 [count, 593])"""
+    L = oracle()
+    ctus = ((pic_w + 63) // 64) * ((pic_h + 63) // 64)
+    n = ctus - ctu_first if ctu_count < 0 else ctu_count
+    imv = np.ascontiguousarray(int_mv, dtype=np.int16)
+    assert imv.shape == (n, NUM_PARTS, 2)
+    qmv = np.zeros((n, NUM_PARTS, 2), np.int16)
+    cost = np.zeros((n, NUM_PARTS), np.uint32)
+    cs, rs = cur.shape[1], ref_plane.shape[1]
+    pq = None
+    if pred_q is not None:
+        pred_q = np.ascontiguousarray(pred_q, dtype=np.int16)
+        pq = pred_q.ctypes.data
+    L.hmo_refine_frame(_addr(cur, origin[1] * cs + origin[0]), cs, _addr(ref_plane, origin[1] * rs + origin[0]), rs, pic_w, pic_h, pq,
+                       int(lambda_q16), int(use_had), int(bit_depth), ctu_first, n, n_threads, imv.ctypes.data, qmv.ctypes.data, cost.ctypes.data)
+    return qmv, cost
 
 
 def tz_frame(cur, ref_plane, origin, pic_w, pic_h, sr, pred_q, lambda_q16, fen, bit_depth, ctu_first=0,

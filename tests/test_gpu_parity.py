@@ -180,6 +180,7 @@ def test_1080p_planted_motion_and_oracle_spot_check(engine, oracle_lib):
     pc, pr = engine.plane(w, h), engine.plane(w, h)
     pc.upload_pel(cur, (m, m)); pr.upload_pel(ref, (m, m))
     mv, sad = engine.search_frame(pc, pr, sr)
+    qmv, cost = engine.refine_frame(pc, pr, sr, mv)          # the step after the path, on the whole picture
     pc.close(); pr.close()
     ctus_x = 30
     assert mv.shape == (510, 593, 2)
@@ -199,12 +200,13 @@ def test_1080p_planted_motion_and_oracle_spot_check(engine, oracle_lib):
     # winning MV of the 64x64 PU): SAD(64x64 @ mv592) == sum of the four 32x32 SADs at that MV >= sum of
     # the 32x32 minima's SADs is NOT guaranteed with MV costs, so only check range sanity here
     assert sad.max() < 1044481
-    # (3) oracle spot check on 12 CTUs incl. partial bottom-row CTUs and picture corners
+    # (3) the whole picture against the oracle: 510 CTUs x 593 slots
     lq = oracle_lib.oracle().hmo_lambda_q16(57.9)
-    for ctu in (0, 29, 31, 200, 255, 340, 479, 480, 495, 509, 123, 77):
-        ox, oy, osad = oracle_lib.search_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, 8, ctu_first=ctu, ctu_count=1)
-        assert np.array_equal(mv[ctu, :, 0], ox[0]) and np.array_equal(mv[ctu, :, 1], oy[0]), ctu
-        assert np.array_equal(sad[ctu], osad[0]), ctu
+    ox, oy, osad = oracle_lib.search_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, 8, n_threads=16)
+    assert np.array_equal(mv[:, :, 0], ox) and np.array_equal(mv[:, :, 1], oy) and np.array_equal(sad, osad)
+    # (4) ... and xPatternSearchFracDIF (Hadamard) of all 510 x 593 winners against the oracle's
+    oq, oc = oracle_lib.refine_frame(cur, ref, (m, m), w, h, mv, None, lq, 1, 8, n_threads=16)
+    assert np.array_equal(qmv, oq) and np.array_equal(cost, oc)
 
 
 def test_cpp_host_module_tencopencl(oracle_lib):
@@ -347,9 +349,10 @@ def test_2160p_whole_frame_properties_and_spot_checks(engine, oracle_lib):
                 assert sad[ctu, 592] == 0 and tuple(mv[ctu, 592]) == (dx, dy), (cx, cy)
                 hits += 1
     assert hits > 300
-    for ctu in (0, 59, 61, 1017, 2039, 1980, 33 * 60 + 30, 777):          # corners, interior, partial bottom row
-        ox, oy, osad = oracle_lib.search_frame(cur, ref, (m, m), w, h, sr, pred, lq, 1, 8, ctu_first=ctu, ctu_count=1)
-        assert np.array_equal(mv[ctu, :, 0], ox[0]) and np.array_equal(mv[ctu, :, 1], oy[0]) and np.array_equal(sad[ctu], osad[0]), ctu
+    # the whole picture against the oracle: all 2 040 CTUs x 593 slots (16 host threads: a few seconds)
+    ox, oy, osad = oracle_lib.search_frame(cur, ref, (m, m), w, h, sr, pred, lq, 1, 8, n_threads=16)
+    bad = np.flatnonzero((mv[:, :, 0] != ox).any(axis=1) | (mv[:, :, 1] != oy).any(axis=1) | (sad != osad).any(axis=1))
+    assert bad.size == 0, f"CTUs that differ from the oracle: {bad[:20]}"
 
 
 def test_engine_lifecycle_and_two_contexts(oracle_lib):
@@ -761,6 +764,7 @@ def test_2160p_10bit_sr128_whole_frame_properties_and_spot_checks(engine, oracle
         pc.upload_pel(cur, (m, m)); pr.upload_pel(ref, (m, m))
         mv, sad = engine.search_frame(pc, pr, sr, pred)
         mv2, sad2 = engine.search_frame(pc, pr, sr, pred)
+        qmv, cost = engine.refine_frame(pc, pr, sr, mv, pred, use_hadamard=True)
     assert mv.shape == (n_ctu, 593, 2) and np.array_equal(mv, mv2) and np.array_equal(sad, sad2)
     hits = far = 0
     for cy in range(1, 32):
@@ -777,9 +781,14 @@ def test_2160p_10bit_sr128_whole_frame_properties_and_spot_checks(engine, oracle
                 hits += 1
                 far += max(abs(dx - px), abs(dy - py)) > 64                # beyond what SearchRange 64 could reach
     assert hits > 250 and far > 30
-    for ctu in (0, 59, 61, 1017, 2039, 1980, 33 * 60 + 30, 777):          # corners, interior, partial bottom row
-        ox, oy, osad = oracle_lib.search_frame(cur, ref, (m, m), w, h, sr, pred, lq, 1, bd, ctu_first=ctu, ctu_count=1)
-        assert np.array_equal(mv[ctu, :, 0], ox[0]) and np.array_equal(mv[ctu, :, 1], oy[0]) and np.array_equal(sad[ctu], osad[0]), ctu
+    # oracle equality on the first, the last (partial) and eight more CTU rows spread over the picture: 600 CTUs x 593 slots
+    for row in (0, 3, 7, 11, 16, 20, 24, 28, 31, 33):
+        ox, oy, osad = oracle_lib.search_frame(cur, ref, (m, m), w, h, sr, pred, lq, 1, bd, ctu_first=row * 60, ctu_count=60, n_threads=16)
+        sl = slice(row * 60, row * 60 + 60)
+        assert np.array_equal(mv[sl, :, 0], ox) and np.array_equal(mv[sl, :, 1], oy) and np.array_equal(sad[sl], osad), row
+        if row in (0, 16, 33):       # the refinement of those winners on u16 planes (first-pass shift 2, clip to 1023, distortion >> 2)
+            oq, oc = oracle_lib.refine_frame(cur, ref, (m, m), w, h, mv[sl], pred, lq, 1, bd, ctu_first=row * 60, ctu_count=60, n_threads=16)
+            assert np.array_equal(qmv[sl], oq) and np.array_equal(cost[sl], oc), row
 
 
 def test_shift_free_and_int16_argument_checks(engine, oracle_lib):
