@@ -130,7 +130,7 @@ def test_encoders_at_10_bit_internal_depth(tmp_path):
     sample width from the reference window and, like cl/sad.cl, leaves the sums unshifted; no call may fail or serve stale tables.
     The patched encoder passes the SPS bit depth (16-bit kernels, HM's >> 2): HM's own xPatternSearch must agree on every check."""
     _build()
-    common = dict(frames=3, w=208, h=120, cfg=CFG, extra=("--SearchRange=16", "--InternalBitDepth=10"))
+    common = dict(frames=3, w=208, h=120, cfg=CFG, extra=("--SearchRange=16", "--Profile=main10", "--InternalBitDepth=10"))
     r, p = _encode(tmp_path, 1, exe=EXE, **common)
     m = _TRACE.search(r.stderr)
     assert m and int(m.group(1)) > 0 and int(m.group(2)) == 0, r.stderr[-1500:]

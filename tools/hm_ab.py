@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--frames", type=int, default=5)
     ap.add_argument("--search-range", type=int, default=64)
     ap.add_argument("--gop", default="P", choices=sorted(CFGS), help="low-delay P (one reference) or B (two references, bi-prediction)")
+    ap.add_argument("--skip-full-search", action="store_true", help="leave out the CPU exhaustive search (minutes per picture at 1080p)")
+    ap.add_argument("--log", default=None, help="append progress lines to this file as configurations start and finish (long runs on the "
+                                                "GPU box must keep writing under gpurun_out/)")
     ap.add_argument("--verify", action="store_true", help="HMME_VERIFY=1 on the patched encoder (slower: runs HM's xPatternSearch beside the engine)")
     args = ap.parse_args()
     CFG = CFGS[args.gop]
@@ -46,6 +49,11 @@ def main():
                              ("hmme, reference call sites (ME_MODE_OCL_COMPAT)", EXE, ["--OpenCL=1", "--FastSearch=1", "--KernelOpenCL=embedded"]),
                              ("hmme, tools/hm_patch (ME_MODE_HM, bi-pred tables, edge CTUs)", EXE_HM, ["--OpenCL=1", "--FastSearch=1", "--KernelOpenCL=embedded"]),
                              ("hmme, tools/hm_patch + HMME_GPU_FRAC=1 (refinement tables too)", EXE_HM, ["--OpenCL=1", "--FastSearch=1", "--KernelOpenCL=embedded"])):
+        if args.skip_full_search and "FastSearch=0" in extra:
+            continue
+        if args.log:
+            with open(args.log, "a") as f:
+                f.write(f"{time.strftime('%H:%M:%S')} start: {name}\n")
         t0 = time.time()
         env = dict(os.environ, HMME_TRACE="1")
         if args.verify and exe == EXE_HM:
@@ -56,6 +64,9 @@ def main():
                             f"--SearchRange={args.search_range}", "-b", os.path.join(tmp, "s.bin"), *extra],
                            capture_output=True, text=True, env=env, cwd=tmp)
         dt = time.time() - t0
+        if args.log:
+            with open(args.log, "a") as f:
+                f.write(f"{time.strftime('%H:%M:%S')} done in {dt:.1f} s: {name}\n")
         if r.returncode != 0:
             rows.append({"config": name, "error": r.stderr[-300:]})
             continue
