@@ -49,7 +49,7 @@ def main():
                              ("hmme, reference call sites (ME_MODE_OCL_COMPAT)", EXE, ["--OpenCL=1", "--FastSearch=1", "--KernelOpenCL=embedded"]),
                              ("hmme, tools/hm_patch (ME_MODE_HM, bi-pred tables, edge CTUs)", EXE_HM, ["--OpenCL=1", "--FastSearch=1", "--KernelOpenCL=embedded"]),
                              ("hmme, tools/hm_patch + HMME_GPU_FRAC=1 (refinement tables too)", EXE_HM, ["--OpenCL=1", "--FastSearch=1", "--KernelOpenCL=embedded"])):
-        if args.skip_full_search and "FastSearch=0" in extra:
+        if args.skip_full_search and "--FastSearch=0" in extra:
             continue
         if args.log:
             with open(args.log, "a") as f:
