@@ -30,12 +30,13 @@ constexpr uint32_t kInvCost = 3146751u;  // > any valid cost (<= 1047552 + 65535
 constexpr int kGroups = 10;
 // lane-iterations per task (<= 4: 2 iteration bits in the key).  A task ends with the flush of ten running-minimum registers into the
 // CTU's LDS table; whole-picture launches run 4 per task (measured on 2160p: 1 / 2 / 4 -> 3 252 / 3 256 / 3 284 GSAD/s,
-// profiles/r02f_*), split launches (one CTU dealt to many workgroups, where the number of tasks is the parallelism) keep 2
+// profiles/r02f_*), split launches (one CTU dealt to many workgroups, where the number of tasks is the parallelism) 1: the per-CTU
+// call at SR 64 goes from 9 to 17 workgroups of one iteration per wave, 0.086 -> 0.065 ms (profiles/r02l_*)
 #ifndef ME_ITER_PER_TASK
 #define ME_ITER_PER_TASK 4
 #endif
 #ifndef ME_ITER_PER_TASK_SPLIT
-#define ME_ITER_PER_TASK_SPLIT 2
+#define ME_ITER_PER_TASK_SPLIT 1
 #endif
 constexpr int kIterPerTask = ME_ITER_PER_TASK;
 constexpr int kIterPerTaskSplit = ME_ITER_PER_TASK_SPLIT;
