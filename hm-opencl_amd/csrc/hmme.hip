@@ -35,9 +35,8 @@ static_assert(sizeof(MeJob16) * kCallMaxJobs <= kCallFirst && kCallFracJob + siz
 constexpr size_t kResMv = 0, kResSad = 4 * HMME_NUM_CTU_PARTS, kResDone = 8 * HMME_NUM_CTU_PARTS, kResQmv = kResDone + 64,
                  kResCost = kResQmv + 4 * HMME_NUM_CTU_PARTS, kResDone2 = kResCost + 4 * HMME_NUM_CTU_PARTS, kResBytes = kResDone2 + 64;
 constexpr size_t kLdsBudget16 = 78 * 1024;   // per workgroup of the 16-bit path -> 2 workgroups per CU
-// 16-bit window pitch in dwords for windows up to 129 / 257 candidates wide.  Even: rows stay 8-byte aligned for ds_read_b64.
-// 130 = 2 * 33 lanes-per-row + 64: with the kernel's linear lane packing every lane of a 129-wide even-column pass lands on
-// its own bank pair (measured +1.5 % over 98); the same trick for 257-wide windows (194) costs more strips than it saves
+// 16-bit window pitch in dwords for windows up to 129 / 257 candidates wide (row = (wx + 63 + 1) samples / 2, + 34 dwords the
+// last lane of a row reaches beyond its first candidate)
 constexpr int kPdw16Small = 130, kPdw16Large = 162;
 thread_local std::string g_create_error;   // hmme_last_error(NULL): per host thread, like the contexts themselves
 }  // namespace
@@ -730,7 +729,8 @@ static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_para
   if (wide) {   // strips of the balanced height for the full window (me_strip_rows16); clipped windows choose their own within n_strips
     const int w = 2 * fp->search_range + 1, rmax = rows_max16(*pdw);
     *strip_rows = rmax;
-    *n_strips = std::max(strips_for(*pdw, w), (w + hmme::me_strip_rows16(w, rmax) - 1) / hmme::me_strip_rows16(w, rmax));
+    const int h = hmme::me_strip_rows16(w, w, rmax, strips_for(*pdw, w) + 2);   // up to two strips more than LDS alone needs
+    *n_strips = (w + h - 1) / h;
   }
   static const int split_below = std::getenv("HMME_SPLIT_BELOW") ? std::atoi(std::getenv("HMME_SPLIT_BELOW")) : 384;   // A/B knob, DESIGN.md 8
   if (!wide && jobs < split_below) {

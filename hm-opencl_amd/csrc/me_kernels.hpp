@@ -153,28 +153,13 @@ __device__ __forceinline__ uint32_t me_mv_cost(uint32_t lambda_q16, int x, int y
   return (lambda_q16 * (me_component_bits((x << 2) - pred_x) + me_component_bits((y << 2) - pred_y))) >> 16;
 }
 
-#ifndef ME_IDX16
-#define ME_IDX16 8
-#endif
-constexpr int kIdxBits16 = ME_IDX16;       // key = cost << 8 | iter(1) | lane(6) | j(1): 24-bit cost field  (9: two iteration bits, 23-bit cost)
-// > any valid cost: bi-pred origins <= 3 142 656 + 65 535; shift-free 10-bit sums (hmme_search_params::shift_free, what
-// cl/sad.cl computes) <= 4 190 208 + 65 535; shift-free 9-bit bi-pred origins <= 6 279 168 + 65 535.  kInvCost16 + the
-// largest sum an invalid lane can add (6 279 168) stays < 2^24
-constexpr uint32_t kInvCost16 = ME_IDX16 == 8 ? 8000000u : 4000000u;
-#ifndef ME_ITER_PER_TASK16
-#define ME_ITER_PER_TASK16 2
-#endif
-constexpr int kIterPerTask16 = ME_ITER_PER_TASK16;   // <= 2 (one iteration bit in the key)
-// Workgroup shape of the 16-bit kernel.  The LDS window (78 KB) allows 2 workgroups per CU; at 4 waves each that is 2 waves per
-// SIMD with a 256-VGPR budget (the kernel uses 210 / 242).  ME_THREADS16=384 + ME_WAVES16=3 (6 waves share a window, 3 per SIMD,
-// 168 VGPRs) is an A/B knob: build with EXTRA="-DME_THREADS16=384 -DME_WAVES16=3 -DME_ITER_PER_TASK16=1".
-#ifndef ME_THREADS16
-#define ME_THREADS16 256
-#endif
-#ifndef ME_WAVES16
-#define ME_WAVES16 2
-#endif
-constexpr int kThreads16 = ME_THREADS16;
+// 16-bit kernel (three candidates per lane, one lane-iteration per task): key = cost << 8 | lane(6) | j(2).  The 24-bit cost field
+// holds HM's shifted sums with bi-prediction origins (<= 3 142 656 + 65 535) and the unshifted ones of
+// hmme_search_params::shift_free (what cl/sad.cl computes: 10-bit <= 4 190 208 + 65 535, 9-bit bi-prediction origins
+// <= 6 279 168 + 65 535); the invalid marker + the largest sum an invalid lane can add (6 279 168) stays < 2^24
+constexpr int kIdxBits16 = 8;
+constexpr uint32_t kInvCost16 = 8000000u;
+constexpr int kThreads16 = 256;
 
 // a CTU search cut into several workgroups: the 16-bit path cuts by candidate rows (LDS capacity), the 8-bit path
 // by task range (latency of the per-CTU drop-in call, small pictures)
@@ -200,18 +185,24 @@ __host__ __device__ inline int me_num_tasks(int wx, int wy, int iter_per_task = 
 }
 static_assert(sizeof(MeJob16) == 24, "MeJob16 layout");
 
-// 16-bit kernel: height of the strips a wx-wide window is cut into, given the most rows LDS holds (rows_max).  The four waves of a
-// workgroup pull lane-iterations from a counter; a strip whose even-column pass has a multiple of 4 iterations ends with all four
-// waves busy (37 iterations = 10 + 9 + 9 + 9: a quarter of the last round idle).  Iterations of the even pass of a strip of h rows:
-// ceil(h * pairs / 64), pairs = lanes per window row (the odd pass has at most as many).  Picks the largest h <= rows_max with a
-// multiple of 4, unless that costs more than an eighth of the height.
-__host__ __device__ inline int me_strip_rows16(int wx, int rows_max) {
-  const int pairs = (((wx + 1) >> 1) + 1) >> 1;
-  for (int h = rows_max; h >= rows_max - rows_max / 8 && h >= 4; --h)
-    if ((((h * pairs + 63) >> 6) & 3) == 0) return h;
-  return rows_max;
+// 16-bit kernel: height of the strips a wx x wy window is cut into, given the most rows LDS holds (rows_max) and the number of
+// strips the launch provides (max_strips).  The four waves of a workgroup pull lane-iterations from a counter and meet at a barrier
+// after each column-parity pass, so a pass of n iterations costs ceil(n / 4) rounds: 25 iterations cost 7 rounds, 24 cost 6.
+// Iterations of a pass over h rows: ceil(h * lanes_per_row / 64), lanes_per_row = ceil(candidates of one parity / 3) (three
+// candidates per lane; the even pass has at least as many as the odd one).  Picks the height whose split [h, h, ..., rest] costs the
+// fewest rounds, a strip counting half a round for its two window loads; ties go to the taller strip.
+__host__ __device__ inline int me_strip_rows16(int wx, int wy, int rows_max, int max_strips) {
+  const int lanes = (((wx + 1) >> 1) + 2) / 3;
+  int best_h = (wy + max_strips - 1) / max_strips, best_cost = 0x7fffffff;
+  for (int h = rows_max < wy ? rows_max : wy; h >= 1; --h) {
+    const int n = (wy + h - 1) / h;
+    if (n > max_strips) break;
+    const int rest = wy - (n - 1) * h;
+    const int cost = 2 * ((n - 1) * ((((h * lanes + 63) >> 6) + 3) >> 2) + ((((rest * lanes + 63) >> 6) + 3) >> 2)) + n;
+    if (cost < best_cost) { best_cost = cost; best_h = h; }
+  }
+  return best_h;
 }
-
 
 // ---- the search kernel --------------------------------------------------------------------------
 // windows wider or taller than 129 candidates (8-bit planes, search range 65..128) are cut into up to 2 x 2 tiles of at most
@@ -443,30 +434,32 @@ __global__ void me_fill_plane_kernel(uint8_t* __restrict__ dst, int dst_pitch, i
   if (bad) atomicOr(flag, 1);
 }
 
-// ---- 16-bit sample path (bit depth 9..12) -----------------------------------------------------------------
-// Same task / key / butterfly / merge machinery as me_search_kernel; differences (see tools/gen_me_tree.py,
-// class Tree16): v_sad_u16 leaves on u16 samples, two candidates per lane, exact 32-bit sums and
+// ---- 16-bit sample path (bit depth 9..12, bi-prediction origins of any depth) -----------------------------------------------
+// Same task / key / butterfly / merge machinery as me_search_kernel; differences (see tools/gen_me_tree.py, class Tree16):
+// v_sad_u16 leaves on u16 samples, three candidates per lane (x, x+2, x+4), exact 32-bit sums and
 //   key = ((sum << fen_shift) >> (bitDepth-8)) << kIdxBits16 + c     (reference TComRdCost.cpp:520-521),
-// lanes packed linearly over the window (candidate pair q = iteration*64 + lane), and the window is cut into
-// horizontal strips of candidate rows so that one strip's reference rows fit LDS (SR 128: 320 x 322 samples);
-// strips of a CTU are separate workgroups that merge through 64-bit atomicMin on a global table.
+// lanes packed linearly over the window (candidate triple q = iteration*64 + lane), one lane-iteration per task, and the window
+// is cut into horizontal strips of candidate rows so that one strip's reference rows fit LDS (SR 128: 320 x 322 samples); strips
+// of a CTU are separate workgroups that merge through 64-bit atomicMin on a global table.
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-// 16-bit kernel: key of each of the lane's two candidates from its exact sum, and their minimum; `asm volatile` for the same
-// reason as me_min4 (ordered against the masked merges)
-__device__ __forceinline__ uint32_t me_keymin2(uint32_t s0, uint32_t s1, uint32_t mask, uint32_t lsh, uint32_t c0, uint32_t c1) {
-  uint32_t r, t;
-  asm volatile("v_and_b32 %0, %4, %2\n\tv_and_b32 %1, %4, %3\n\t"
-               "v_lshl_add_u32 %0, %0, %5, %6\n\tv_lshl_add_u32 %1, %1, %5, %7\n\t"
-               "v_min_u32 %0, %0, %1"
-               : "=&v"(r), "=&v"(t) : "v"(s0), "v"(s1), "s"(mask), "s"(lsh), "v"(c0), "v"(c1));
-  return r;
-}
 typedef volatile __attribute__((address_space(3))) uint32_t lds_vu32_t;
 typedef volatile __attribute__((address_space(3))) u32x4_t lds_vu32x4_t;
 #define ME_SAD16(a, b, acc) __builtin_amdgcn_sad_u16((a), (b), (acc))
 
+// key of each of the lane's three candidates from its exact sum, and their minimum; `asm volatile` for the same reason as me_min4
+// (ordered against the masked merges)
+__device__ __forceinline__ uint32_t me_keymin3(uint32_t s0, uint32_t s1, uint32_t s2, uint32_t mask, uint32_t lsh, uint32_t c0, uint32_t c1,
+                                               uint32_t c2) {
+  uint32_t r, t, u;
+  asm volatile("v_and_b32 %0, %6, %3\n\tv_and_b32 %1, %6, %4\n\tv_and_b32 %2, %6, %5\n\t"
+               "v_lshl_add_u32 %0, %0, %7, %8\n\tv_lshl_add_u32 %1, %1, %7, %9\n\tv_lshl_add_u32 %2, %2, %7, %10\n\t"
+               "v_min3_u32 %0, %0, %1, %2"
+               : "=&v"(r), "=&v"(t), "=&v"(u) : "v"(s0), "v"(s1), "v"(s2), "s"(mask), "s"(lsh), "v"(c0), "v"(c1), "v"(c2));
+  return r;
+}
+
 template <int FEN, int PDW>
-__global__ void __launch_bounds__(kThreads16, ME_WAVES16)
+__global__ void __launch_bounds__(kThreads16, 2)
 me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet refs, int ref_pitch,
                    const MeJob16* __restrict__ jobs, uint32_t lambda_q16, int sh, unsigned long long* __restrict__ g_best) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -495,11 +488,10 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const Re
   const bool rb1 = lane & 2, rb0 = lane & 1;
   const lds_vu32x4_t* curv4 = (const lds_vu32x4_t*)curl;
   constexpr int ME16_PDW = PDW;
-  static_assert(PDW % 2 == 0, "window rows must stay 8-byte aligned (ds_read_b64)");
 
   // Two passes: the even window columns, then the odd ones, each over a window loaded with a shift of `par` samples.
-  // A lane owns the candidates (x, x + 2): both read dword-aligned u16 pairs, the second one dword further on, so no
-  // per-lane realignment (v_alignbit per dword and row) is left in the tree.
+  // A lane owns the candidates (x, x + 2, x + 4): all read dword-aligned u16 pairs, each one dword further on -- the six dwords
+  // three 64-bit reads of a window row deliver.  Lane bases are 3 dwords apart: 4-byte-aligned reads (ds_read2_b32).
 #pragma unroll 1
   for (int par = 0; par < 2; ++par) {
     if (par) __syncthreads();                                          // every wave is done with the previous window
@@ -519,35 +511,35 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const Re
     __syncthreads();
 
   const int n_par = (wx + 1 - par) >> 1;                               // candidates of this column parity per window row
-  const int pairs = (n_par + 1) >> 1;                                  // lanes per window row
+  const int pairs = (n_par + 2) / 3;                                   // lanes per window row
   const int n_iters = (ny * pairs + 63) >> 6;
-  const int n_tasks = (n_iters + kIterPerTask16 - 1) / kIterPerTask16;
+  const int n_tasks = n_iters;                                         // one lane-iteration per task: a pass is ~25 iterations for 4 waves
 
   while (true) {
     int t = 0;
     if (lane == 0) t = atomicAdd(task_ctr, 1);
     t = __builtin_amdgcn_readfirstlane(t);
     if (t >= n_tasks) break;
-    const int it0 = t * kIterPerTask16;
-    const int n_it = min(kIterPerTask16, n_iters - it0);
+    const int it0 = t;
+    constexpr int n_it = 1;
     uint32_t b0 = ME_MAXKEY, b1 = ME_MAXKEY, b2 = ME_MAXKEY, b3 = ME_MAXKEY, b4 = ME_MAXKEY, b5 = ME_MAXKEY,
              b6 = ME_MAXKEY, b7 = ME_MAXKEY, b8 = ME_MAXKEY, b9 = ME_MAXKEY;
     for (int it = 0; it < n_it; ++it) {
       const int q = (it0 + it) * 64 + lane;
       const int row = q / pairs, pr = q - row * pairs;
-      const int cx = par + 4 * pr, cy = jb.y0 + row;
+      const int cx = par + 6 * pr, cy = jb.y0 + row;
       const bool vy = row < ny;
       const int mvy = job.lt_y + cy, mvx = job.lt_x + cx;
       const uint32_t by = me_component_bits((mvy << 2) - job.pred_y);
-      const uint32_t tag = ((uint32_t)it << 7) | ((uint32_t)lane << 1);
-      uint32_t cc[2];
+      const uint32_t tag = (uint32_t)lane << 2;
+      uint32_t cc[3];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < 3; ++j) {
         const uint32_t cost = (lambda_q16 * (me_component_bits(((mvx + 2 * j) << 2) - job.pred_x) + by)) >> 16;
         cc[j] = (((vy && (cx + 2 * j) < wx) ? cost : kInvCost16) << kIdxBits16) | tag | (uint32_t)j;
       }
-      const uint32_t c0 = cc[0], c1 = cc[1];
-      const lds_vu64_t* lpq = (const lds_vu64_t*)(win + min(row, ny - 1) * PDW + 2 * pr);   // 8-byte aligned: PDW is even
+      const uint32_t c0 = cc[0], c1 = cc[1], c2 = cc[2];
+      const lds_char_t* lpd = (const lds_char_t*)(win + min(row, ny - 1) * PDW + 3 * pr);
       if constexpr (FEN) {
 #include "me_tree16_fen1.inc"
       } else {
@@ -558,11 +550,11 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const Re
     {                                                                                                              \
       const int slot = ME_SLOT_OF[g][lane];                                                                        \
       const uint32_t key = (key_);                                                                                 \
-      const uint32_t cost = key >> kIdxBits16;                                                                       \
-      if (slot >= 0 && cost < kInvCost16) {                                                                          \
-        const int kq = (it0 + (int)((key >> 7) & ((1 << (kIdxBits16 - 7)) - 1))) * 64 + (int)((key >> 1) & 63);    \
+      const uint32_t cost = key >> kIdxBits16;                                                                     \
+      if (slot >= 0 && cost < kInvCost16) {                                                                        \
+        const int kq = it0 * 64 + (int)((key >> 2) & 63);                                                          \
         const int krow = kq / pairs;                                                                               \
-        const int bx = par + 4 * (kq - krow * pairs) + 2 * (int)(key & 1);                                         \
+        const int bx = par + 6 * (kq - krow * pairs) + 2 * (int)(key & 3);                                         \
         atomicMin(&best64[slot], ((unsigned long long)cost << 32) | ((unsigned long long)(jb.y0 + krow) << 16) |   \
                                      (unsigned long long)bx);                                                      \
       }                                                                                                            \
@@ -642,13 +634,9 @@ __global__ void me_prep_jobs16_kernel(MeJob16* jobs, int* first_strip_of_job, co
   j.pred_x = (int16_t)px; j.pred_y = (int16_t)py;
   const int wy = rby - lty + 1;
   first_strip_of_job[i] = i * n_strips;
-  // strips of the balanced height (me_strip_rows16) while they cover the window within n_strips, the last one takes the rest;
-  // otherwise equal strips.  Strips beyond the window (clipped windows) are empty: y0 == y1
-  // ... and while the last strip is not a sliver: workgroups of very different length pack badly into the launch's rounds
-  // (129 rows as 62 + 62 + 5 measured 8 % slower than 43 + 43 + 43)
-  int h = me_strip_rows16(rbx - ltx + 1, rows_max);
-  const int n_h = (wy + h - 1) / h, last = wy - (n_h - 1) * h;
-  if (n_h > n_strips || 2 * last < h) h = (wy + n_strips - 1) / n_strips;
+  // strips of the height me_strip_rows16 picks for this window, the last one takes the rest; strips beyond the window (clipped
+  // windows need fewer) are empty: y0 == y1
+  const int h = me_strip_rows16(rbx - ltx + 1, wy, rows_max, n_strips);
   for (int s = 0; s < n_strips; ++s) {
     MeJob16 js;
     js.j = j;

@@ -118,13 +118,13 @@ def test_generated_tree_full_window_with_folded_last_row():
 INV16, IDX16 = 8000000, G.IDX_BITS16
 
 
-def model_search16(tree, cur, ref, origin, lt, rb, pred, lq, bit_depth, iters_per_task=2):
-    """python model of me_search16_kernel (16-bit samples; two passes, even and odd window columns, the LDS window
-    loaded with a shift of `par` samples; a lane owns candidates (x, x+2); linear lane packing)"""
+def model_search16(tree, cur, ref, origin, lt, rb, pred, lq, bit_depth):
+    """python model of me_search16_kernel (16-bit samples; two passes, even and odd window columns, the LDS window loaded with a
+    shift of `par` samples; a lane owns candidates (x, x+2, x+4); linear lane packing; one lane-iteration per task)"""
     sh = bit_depth - 8
     wx, wy = rb[0] - lt[0] + 1, rb[1] - lt[1] + 1
     ox, oy = origin[0] + lt[0], origin[1] + lt[1]
-    pitch = 2 * ((wx + 63 + 2 + 1) // 2) + 4
+    pitch = 2 * ((wx + 63 + 2 + 1) // 2) + 8
     slot_of = tree.slot_of_lane()
     best64 = np.full(593, (1 << 64) - 1, dtype=np.uint64)
     lanes = np.arange(64)
@@ -133,32 +133,31 @@ def model_search16(tree, cur, ref, origin, lt, rb, pred, lq, bit_depth, iters_pe
         w = ref[oy:oy + wy + 63, ox + par:ox + par + min(pitch, ref.shape[1] - ox - par)]
         win[:w.shape[0], :w.shape[1]] = w
         n_par = (wx + 1 - par) // 2            # candidates of this column parity per window row
-        P = (n_par + 1) // 2
+        P = (n_par + 2) // 3                   # lanes per window row
         iters = (wy * P + 63) // 64
-        for it0 in range(0, iters, iters_per_task):
+        for it0 in range(iters):
             best = np.full((G.N_GROUPS, 64), 0xFFFFFFFF, np.uint32)
-            for it in range(min(iters_per_task, iters - it0)):
-                q = (it0 + it) * 64 + lanes
-                cy, cx = q // P, par + 4 * (q % P)
-                c = np.zeros((2, 64), np.uint32)
-                for l in range(64):
-                    by = cbits(((lt[1] + int(cy[l])) << 2) - pred[1])
-                    for j in range(2):
-                        x = int(cx[l]) + 2 * j
-                        cost = ((lq * (cbits(((lt[0] + x) << 2) - pred[0]) + by)) & 0xFFFFFFFF) >> 16
-                        valid = cy[l] < wy and x < wx
-                        c[j, l] = ((cost if valid else INV16) << IDX16) | (it << 7) | (l << 1) | j
-                lane_off = np.minimum(cy, wy - 1) * pitch + (cx - par)
-                G.simulate16(tree, win, cur, lane_off, c, best, sh)
+            q = it0 * 64 + lanes
+            cy, cx = q // P, par + 6 * (q % P)
+            c = np.zeros((3, 64), np.uint32)
+            for l in range(64):
+                by = cbits(((lt[1] + int(cy[l])) << 2) - pred[1])
+                for j in range(3):
+                    x = int(cx[l]) + 2 * j
+                    cost = ((lq * (cbits(((lt[0] + x) << 2) - pred[0]) + by)) & 0xFFFFFFFF) >> 16
+                    valid = cy[l] < wy and x < wx
+                    c[j, l] = ((cost if valid else INV16) << IDX16) | (l << 2) | j
+            lane_off = np.minimum(cy, wy - 1) * pitch + (cx - par)
+            G.simulate16(tree, win, cur, lane_off, c, best, sh)
             for g in range(G.N_GROUPS):
                 for l in range(64):
                     s, key = slot_of[g, l], int(best[g, l])
                     cost = key >> IDX16
                     if s < 0 or cost >= INV16:
                         continue
-                    kit, kl, kj = (key >> 7) & 1, (key >> 1) & 63, key & 1
-                    q = (it0 + kit) * 64 + kl
-                    v = np.uint64((cost << 32) | ((q // P) << 16) | (par + 4 * (q % P) + 2 * kj))
+                    kl, kj = (key >> 2) & 63, key & 3
+                    q1 = it0 * 64 + kl
+                    v = np.uint64((cost << 32) | ((q1 // P) << 16) | (par + 6 * (q1 % P) + 2 * kj))
                     if v < best64[s]:
                         best64[s] = v
     out = np.zeros((593, 3), np.int64)

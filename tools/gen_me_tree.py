@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT_DIR = os.path.join(ROOT, "hm-opencl_amd", "csrc")
 
 IDX_BITS = 10          # key = cost << 10 | iter(2) | lane(6) | j(2)
-IDX_BITS16 = 8         # 16-bit path: cost << 8 | iter(1) | lane(6) | j(1)  (24-bit cost: shift-free 9-bit bi-pred origins reach 6.3 M)
+IDX_BITS16 = 8         # 16-bit path: cost << 8 | lane(6) | j(2), one lane-iteration per task  (24-bit cost: shift-free 9-bit bi-pred origins reach 6.3 M)
 MULT_A = 1 << IDX_BITS
 N_GROUPS = 10          # ceil(593 / 64)
 PDW = 49               # LDS window pitch in dwords (odd: conflict-free for every lane shape)
@@ -68,7 +68,7 @@ def slot_2Nx2N(s, cx, cy):
     return BASE_2Nx2N[s] + cy * n + cx
 
 
-LOAD_OPS = ("LDS", "CURLD", "BASE", "LDS16", "LDS16P", "CURLD16")
+LOAD_OPS = ("LDS", "CURLD", "BASE", "LDS16Q", "ROWBASE", "CURLD16")
 
 
 class Tree:
@@ -205,17 +205,20 @@ class Tree:
                 quads.append(self.level2(qx, qy, regions))
         self.level3(quads)
         self.flush()
-        # software prefetch: the loads of CU n+1 are issued at the top of CU n's arithmetic
+        self.ops = self._assemble()
+        assert sorted(s for s in self.emitted if s is not None) == list(range(593))
+        return self
+
+    def _assemble(self):
+        """software prefetch: the loads of CU n+1 are issued at the top of CU n's arithmetic"""
         ops = list(self.cu_loads[0])
         for o in self.ops:
             if o[0] == "LOADS_FOR":
                 if o[1] < len(self.cu_loads):
                     ops.extend(self.cu_loads[o[1]])
-            else:
+            elif o[0] != "MID":
                 ops.append(o)
-        self.ops = ops
-        assert sorted(s for s in self.emitted if s is not None) == list(range(593))
-        return self
+        return ops
 
     def level0(self, cx8, cy8, cx, cy):
         """8x8 CU at CU coords (cx8, cy8); (cx, cy) = position inside its 16x16 region"""
@@ -334,39 +337,48 @@ class Tree:
 
 
 class Tree16(Tree):
-    """Reduction tree of the 16-bit sample path (10-bit video; later bi-pred int16 origins).
+    """Reduction tree of the 16-bit sample path (bit depth 9..12, bi-prediction origins of any depth).
 
-    A lane owns TWO candidates of the same column parity (x, x+2) -- the kernel runs the even and the odd columns
-    as two passes over an LDS window loaded with a one-sample shift, so both candidates read dword-aligned
-    samples and nothing is realigned per lane -- and every value is a pair of exact
-    32-bit sums: HM applies `>> (bitDepth-8)` to the whole-PU sum *after* the FEN `<< 1`
-    (TComRdCost.cpp:520-521), which is a floor and therefore not linear -- no key linearity, no u16
-    packing; each slot's key is formed from its own exact sum:
-        key_j = ((S_j & MASK_f) << LSH_f) + C_j      (v_and_b32 + v_lshl_add_u32)
-    Leaves are v_sad_u16 (2 samples per op)."""
+    A lane owns NC = 3 candidates of one column parity, (x, x+2, x+4): the kernel runs the even and the odd window columns as two
+    passes over an LDS window loaded with a one-sample shift, so every candidate reads dword-aligned u16 pairs, each one dword
+    further on than the previous -- together the six dwords that three 64-bit reads of a window row deliver, nothing realigned
+    per lane.  Lane bases are 3 dwords apart: the reads are 4-byte-aligned 64-bit loads (ds_read2_b32) through one opaque base
+    per two window rows (its offsets reach 255 dwords).
+    Every value is a triple of exact 32-bit sums: HM applies `>> (bitDepth-8)` to the whole-PU sum *after* the FEN `<< 1`
+    (TComRdCost.cpp:520-521), a floor and therefore not linear -- no key linearity, no u16 packing; each slot's key is formed
+    from its own exact sum:   key_j = ((S_j & MASK_f) << LSH_f) + C_j      (v_and_b32 + v_lshl_add_u32)
+    Leaves are v_sad_u16 (2 samples per op).  Three 32-bit sums per value leave no room for a whole CU of loads in flight on top
+    of the CU being consumed, so the prefetch distance is half a CU (_assemble)."""
+
+    nc = 3
 
     def block16(self, cx8, cy8):
-        """-> [(E, A)] for the 4 blocks TL, TR, BL, BR of the CU; E/A are 2-candidate sum pairs"""
+        """-> [(E, A)] for the 4 blocks TL, TR, BL, BR of the CU; E/A are NC-candidate sum tuples"""
         out = []
         rows = {}
+        nc = self.nc
         for r in range(8):
             row = cy8 * 8 + r
+            base = f"lrow{row & ~1}_{cx8}"
+            if r % 2 == 0:   # one opaque base per two window rows: ds_read2_b32 offsets reach 255 dwords, a row is ME16_PDW <= 162
+                self.ops.append(("ROWBASE", base, row))
             d = []
-            for i in range(0, 6, 2):   # three aligned 64-bit reads (ds_read_b64): dwords 0..5, the last one unused
+            for i in range(0, 6, 2):
                 v0, v1 = self.new("d"), self.new("d")
-                self.ops.append(("LDS16P", v0, v1, row, 4 * cx8 + i))
+                self.ops.append(("LDS16Q", v0, v1, base, (row & 1), 4 * cx8 + i))
                 d += [v0, v1]
-            d = d[:5]
             w = self.new("w")
             self.ops.append(("CURLD16", w, row, cx8))
-            o = d[1:]   # second candidate = two samples to the right: the same row one dword on, no realignment
-            rows[r] = (d, o, w)
+            rows[r] = (d, w)
         for by in range(2):
+            if by == 1:
+                self.ops.append(("MID",))   # rows 4..7 are first read from here on (see _assemble)
             for bl in range(2):
                 def chain(r, acc):
-                    d, o, w = rows[by * 4 + r]
+                    d, w = rows[by * 4 + r]
                     v = self.new("s")
-                    self.ops.append(("SAD16x2", v, d[2 * bl], d[2 * bl + 1], o[2 * bl], o[2 * bl + 1], w, 2 * bl, acc,
+                    # candidate j reads the row j dwords on: samples (2*bl + j) * 2 .. + 3
+                    self.ops.append(("SAD16xN", v, [(d[2 * bl + j], d[2 * bl + j + 1]) for j in range(nc)], w, 2 * bl, acc,
                                      cy8 * 8 + by * 4 + r, cx8 * 8 + bl * 4))
                     return v
                 if self.fen:
@@ -390,12 +402,12 @@ class Tree16(Tree):
 
     def pkadd(self, a, b):
         v = self.new("p")
-        self.ops.append(("ADD2", v, a, b))
+        self.ops.append(("ADDN", v, a, b))
         return v
 
     def pksub(self, a, b):
         v = self.new("p")
-        self.ops.append(("SUB2", v, a, b))
+        self.ops.append(("SUBN", v, a, b))
         return v
 
     # "keys" stay exact sums tagged with their family until they are emitted
@@ -412,12 +424,31 @@ class Tree16(Tree):
 
     def emit(self, slot, k):
         r = self.new("r")
-        self.ops.append(("KEYMIN2", r, k[0], k[1]))
+        self.ops.append(("KEYMINN", r, k[0], k[1]))
         self._push(slot, r)
 
-    def build(self):
-        Tree.build(self)
-        return self
+    def _assemble(self):
+        """Half-CU prefetch: rows 4..7 of CU n are issued at the top of CU n's arithmetic (needed from its middle on), rows 0..3 of
+        CU n+1 at the middle of CU n: at most one CU's worth of loads (48 window + 32 current-block registers) is live at any time."""
+        def half(loads, h):
+            return [o for o in loads if (o[0] == "ROWBASE" and (o[2] & 7) // 4 == h) or (o[0] == "LDS16Q" and self._row_of(o) // 4 == h)
+                    or (o[0] == "CURLD16" and (o[2] & 7) // 4 == h)]
+        ops = list(half(self.cu_loads[0], 0))
+        cu = 0
+        for o in self.ops:
+            if o[0] == "LOADS_FOR":
+                cu = o[1] - 1                      # marker n+1 sits at the top of CU n
+                ops.extend(half(self.cu_loads[cu], 1))
+            elif o[0] == "MID":
+                if cu + 1 < len(self.cu_loads):
+                    ops.extend(half(self.cu_loads[cu + 1], 0))
+            else:
+                ops.append(o)
+        return ops
+
+    def _row_of(self, o):
+        """row (0..7 inside its CU) of an LDS16Q op: its base names the even row, op[4] the parity"""
+        return (int(o[3][4:].split("_")[0]) & 7) + o[4]
 
 
 # =====================================================================================================
@@ -431,17 +462,17 @@ HEADER = """// GENERATED by tools/gen_me_tree.py -- do not edit.  One lane-itera
 """
 
 
-HEADER16 = """// GENERATED by tools/gen_me_tree.py -- do not edit.  One lane-iteration of the 16-bit-sample
-// reduction tree (fen=%d): two candidates (x, x+2) per lane, exact 32-bit sums, v_sad_u16 leaves.
-// Expects in scope: lpq (per-lane volatile LDS pointer to 64-bit words at the first candidate, window row 0),
-// ME16_PDW (window pitch in dwords, even), curv4 (volatile LDS copy of the 64x64 current block, u32x4[64][8]),
-// c0, c1, mask_a/lsh_a/mask_e/lsh_e, b0..b9, rb1, rb0 and the me_merge* helpers.
+HEADER16 = """// GENERATED by tools/gen_me_tree.py -- do not edit.  One lane-iteration of the 16-bit-sample reduction tree
+// (fen=%d): three candidates (x, x+2, x+4) per lane, exact 32-bit sums, v_sad_u16 leaves.
+// Expects in scope: lpd (per-lane LDS byte pointer at the first candidate, window row 0; 4-byte aligned), ME16_PDW (window pitch in
+// dwords), curv4 (volatile LDS copy of the 64x64 current block, u32x4[64][8]), c0, c1, c2, mask_a/lsh_a/mask_e/lsh_e, b0..b9,
+// rb1, rb0, me_keymin3 and the me_merge* helpers.
 """
 
 
 MASKED_MERGE_LEVELS = (0, 1)   # the two levels done with hand-written bank-masked DPP pairs (me_merge0 / me_merge1)
 # instructions of the ops that the 8-bit kernel emits as `asm volatile` (their mutual order in the ISA is the order here)
-ORDERED_INSTRS = {"KEYS": 4, "LIN": 4, "SUB": 4, "MIN4": 2, "KEYMIN2": 5}
+ORDERED_INSTRS = {"KEYS": 4, "LIN": 4, "SUB": 4, "MIN4": 2, "KEYMINN": 7}
 
 
 def space_merges(ops, enable):
@@ -492,7 +523,7 @@ def space_merges(ops, enable):
         count[0] += ORDERED_INSTRS.get(op[0], 0)
         if op[0] in ("KEYS", "LIN", "SUB"):
             key_at[op[1]] = count[0]
-        if op[0] in ("MIN4", "KEYMIN2"):       # the ops whose result a level-0 merge reads
+        if op[0] in ("MIN4", "KEYMINN"):       # the ops whose result a level-0 merge reads
             where[op[1]] = count[0]
         out.append((op, False))
 
@@ -559,28 +590,27 @@ def emit_cpp(tree, path, header=None):
             o.append(f"const uint32_t {m} = me_merge{level}{nn}({a}, {b}{'' if level < 4 else f', rb{5 - level}'});")
         elif t == "ACC":
             o.append(f"b{op[1]} = min(b{op[1]}, {op[2]});")
-        elif t == "LDS16":
-            o.append(f"const uint32_t {op[1]} = lpv[{op[2]} * ME16_PDW + {op[3]}];")
-        elif t == "LDS16P":   # ME16_PDW and the dword index are even: an 8-byte-aligned ds_read_b64, conflict-free at a lane stride of 2 dwords
-            o.append(f"const uint64_t {op[1]}_q = lpq[({op[3]} * ME16_PDW + {op[4]}) >> 1]; "
+        elif t == "LDS16Q":   # 4-byte-aligned 64-bit read (ds_read2_b32)
+            o.append(f"const uint64_t {op[1]}_q = *(const lds_vu64a4_t*)({op[3]} + ({op[4]} * ME16_PDW + {op[5]}) * 4); "
                      f"const uint32_t {op[1]} = (uint32_t){op[1]}_q, {op[2]} = (uint32_t)({op[1]}_q >> 32);")
+        elif t == "ROWBASE":
+            o.append(f"const lds_char_t* {op[1]} = lpd + {op[2]} * ME16_PDW * 4; asm volatile(\"\" : \"+v\"({op[1]}));")
+        elif t == "SAD16xN":
+            _, v, dd, w, wi, acc, row, col = op
+            parts = []
+            for j, (d0, d1) in enumerate(dd):
+                a = f"{acc}_{j}" if acc else "0u"
+                parts.append(f"{v}_{j} = ME_SAD16({d1}, {w}[{wi + 1}], ME_SAD16({d0}, {w}[{wi}], {a}))")
+            o.append("const uint32_t " + ", ".join(parts) + ";")
+        elif t == "ADDN":
+            o.append("const uint32_t " + ", ".join(f"{op[1]}_{j} = {op[2]}_{j} + {op[3]}_{j}" for j in range(tree.nc)) + ";")
+        elif t == "SUBN":
+            o.append("const uint32_t " + ", ".join(f"{op[1]}_{j} = {op[2]}_{j} - {op[3]}_{j}" for j in range(tree.nc)) + ";")
+        elif t == "KEYMINN":
+            f_ = "e" if op[3] == "E" else "a"
+            o.append(f"const uint32_t {op[1]} = me_keymin3({op[2]}_0, {op[2]}_1, {op[2]}_2, mask_{f_}, lsh_{f_}, c0, c1, c2);")
         elif t == "CURLD16":
             o.append(f"const u32x4_t {op[1]} = curv4[{op[2] * 8 + op[3]}];")
-        elif t == "ALIGN16":
-            o.append(f"const uint32_t {op[1]} = __builtin_amdgcn_alignbit({op[2]}, {op[3]}, 16);")
-        elif t == "SAD16x2":
-            _, v, d0, d1, o0, o1, w, wi, acc, row, col = op
-            a0 = f"{acc}_0" if acc else "0u"
-            a1 = f"{acc}_1" if acc else "0u"
-            o.append(f"const uint32_t {v}_0 = ME_SAD16({d1}, {w}[{wi + 1}], ME_SAD16({d0}, {w}[{wi}], {a0})), "
-                     f"{v}_1 = ME_SAD16({o1}, {w}[{wi + 1}], ME_SAD16({o0}, {w}[{wi}], {a1}));")
-        elif t == "ADD2":
-            o.append(f"const uint32_t {op[1]}_0 = {op[2]}_0 + {op[3]}_0, {op[1]}_1 = {op[2]}_1 + {op[3]}_1;")
-        elif t == "SUB2":
-            o.append(f"const uint32_t {op[1]}_0 = {op[2]}_0 - {op[3]}_0, {op[1]}_1 = {op[2]}_1 - {op[3]}_1;")
-        elif t == "KEYMIN2":
-            f_ = "e" if op[3] == "E" else "a"
-            o.append(f"const uint32_t {op[1]} = me_keymin2({op[2]}_0, {op[2]}_1, mask_{f_}, lsh_{f_}, c0, c1);")
         else:
             raise ValueError(t)
     write_if_changed(path, "\n".join(o) + "\n")
@@ -631,8 +661,9 @@ def _perm_level(level):
 
 def simulate16(tree, window, cur, lane_off, c, best, sh):
     """interpret one lane-iteration of a Tree16.  window: (rows, pitch_samples) uint16 LDS image;
-    cur: (64,64) uint16; lane_off[l] = sample index of lane l's even candidate at window row 0;
-    c: (2, 64) uint32; sh = bit_depth - 8."""
+    cur: (64,64) uint16; lane_off[l] = sample index of lane l's first candidate at window row 0;
+    c: (3, 64) uint32 per-candidate constants; sh = bit_depth - 8."""
+    rowbase = {}
     flat = np.concatenate([window.reshape(-1), np.zeros(64, window.dtype)]).astype(np.int64)
     pitch = window.shape[1]
     mask = {"A": ~((1 << sh) - 1), "E": ~((1 << max(sh - 1, 0)) - 1) if tree.fen else ~((1 << sh) - 1)}
@@ -641,31 +672,26 @@ def simulate16(tree, window, cur, lane_off, c, best, sh):
     MAXK = np.full(64, 0xFFFFFFFF, np.uint32)
     for op in tree.ops:
         t = op[0]
-        if t == "LDS16":       # dword k of row = samples 2k, 2k+1 (relative to the lane's first candidate)
-            idx = lane_off + op[2] * pitch + 2 * op[3]
-            val[op[1]] = np.stack([flat[idx], flat[idx + 1]], axis=1)
-        elif t == "LDS16P":
-            for v, k in ((op[1], op[4]), (op[2], op[4] + 1)):
-                idx = lane_off + op[3] * pitch + 2 * k
+        if t == "ROWBASE":
+            rowbase[op[1]] = op[2]
+        elif t == "LDS16Q":    # dwords k, k+1 of a window row = samples 2k .. 2k+3 (relative to the lane's first candidate)
+            for v, k in ((op[1], op[5]), (op[2], op[5] + 1)):
+                idx = lane_off + (rowbase[op[3]] + op[4]) * pitch + 2 * k
                 val[v] = np.stack([flat[idx], flat[idx + 1]], axis=1)
         elif t == "CURLD16":
             val[op[1]] = cur[op[2], op[3] * 8:op[3] * 8 + 8].astype(np.int64).reshape(4, 2)
-        elif t == "ALIGN16":   # (hi, lo) >> 16 : samples (lo.hi, hi.lo)
-            val[op[1]] = np.stack([val[op[3]][:, 1], val[op[2]][:, 0]], axis=1)
-        elif t == "SAD16x2":
-            _, v, d0, d1, o0, o1, w, wi, acc, row, col = op
+        elif t == "SAD16xN":
+            _, v, dd, w, wi, acc, row, col = op
             cw = val[w]
-            e = np.abs(val[d0] - cw[wi][None, :]).sum(axis=1) + np.abs(val[d1] - cw[wi + 1][None, :]).sum(axis=1)
-            od = np.abs(val[o0] - cw[wi][None, :]).sum(axis=1) + np.abs(val[o1] - cw[wi + 1][None, :]).sum(axis=1)
-            res = np.stack([e, od], axis=1)
+            res = np.stack([np.abs(val[d0] - cw[wi][None, :]).sum(axis=1) + np.abs(val[d1] - cw[wi + 1][None, :]).sum(axis=1) for d0, d1 in dd], axis=1)
             if acc:
                 res = res + val[acc]
             val[v] = res
-        elif t == "ADD2":
+        elif t == "ADDN":
             val[op[1]] = val[op[2]] + val[op[3]]
-        elif t == "SUB2":
+        elif t == "SUBN":
             val[op[1]] = val[op[2]] - val[op[3]]
-        elif t == "KEYMIN2":
+        elif t == "KEYMINN":
             k = ((val[op[2]] & mask[op[3]]) << lsh[op[3]]) + c.T.astype(np.int64)
             val[op[1]] = k.min(axis=1).astype(np.uint32)
         elif t == "MERGE":
