@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--skip-full-search", action="store_true", help="leave out the CPU exhaustive search (minutes per picture at 1080p)")
     ap.add_argument("--log", default=None, help="append progress lines to this file as configurations start and finish (long runs on the "
                                                 "GPU box must keep writing under gpurun_out/)")
+    ap.add_argument("--hm-args", default="", help="extra TAppEncoder arguments for every configuration, e.g. '--Profile=main10 --InternalBitDepth=10'")
     ap.add_argument("--verify", action="store_true", help="HMME_VERIFY=1 on the patched encoder (slower: runs HM's xPatternSearch beside the engine)")
     args = ap.parse_args()
     CFG = CFGS[args.gop]
@@ -61,7 +62,7 @@ def main():
         if "GPU_FRAC" in name:
             env["HMME_GPU_FRAC"] = "1"
         r = subprocess.run([exe, "-c", CFG, "-i", src, "-wdt", str(w), "-hgt", str(h), "-fr", "30", "-f", str(args.frames),
-                            f"--SearchRange={args.search_range}", "-b", os.path.join(tmp, "s.bin"), *extra],
+                            f"--SearchRange={args.search_range}", "-b", os.path.join(tmp, "s.bin"), *extra, *args.hm_args.split()],
                            capture_output=True, text=True, env=env, cwd=tmp)
         dt = time.time() - t0
         if args.log:
@@ -78,7 +79,7 @@ def main():
         if m and int(m.group(1)):
             row.update(dict(zip(("engine_calls", "failed", "edge_ctu_calls", "bipred_calls", "verified", "verify_mismatches"), (int(v) for v in m.groups()))))
         rows.append(row)
-    print(json.dumps({"clip": f"{w}x{h} x {args.frames} synthetic", "gop": "low-delay " + args.gop, "search_range": args.search_range, "runs": rows}, indent=1))
+    print(json.dumps({"clip": f"{w}x{h} x {args.frames} synthetic", "gop": "low-delay " + args.gop, "search_range": args.search_range, "hm_args": args.hm_args, "runs": rows}, indent=1))
 
 
 if __name__ == "__main__":
