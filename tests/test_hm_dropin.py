@@ -143,3 +143,23 @@ def test_encoders_at_10_bit_internal_depth(tmp_path):
     for (_, b0, y0), (_, b1, y1), (_, b2, y2) in zip(p0[1:], p[1:], p2[1:]):
         assert abs(y1 - y0) < 1.5 and abs(y2 - y0) < 1.0 and b2 < 1.3 * b0 + 1000
     print("10-bit: TZ", p0, "\ncompat", p, "\nhm mode", p2, m2.group(0))
+
+
+def test_hm_patch_is_a_pure_insertion_and_applies(tmp_path):
+    """tools/hm_patch/TEncSearch_hm_mode.patch: no reference line removed (nothing of the reference is restated beyond one line of
+    context per hunk edge), and it applies cleanly to the reference file where that is present"""
+    import subprocess
+    patch = os.path.join(ROOT, "tools", "hm_patch", "TEncSearch_hm_mode.patch")
+    lines = open(patch).read().splitlines()
+    body = [ln for ln in lines if not ln.startswith(("---", "+++", "@@"))]
+    assert not [ln for ln in body if ln.startswith("-")], "the patch removes reference lines"
+    assert sum(1 for ln in body if ln.startswith("+")) > 100
+    assert sum(1 for ln in body if ln.startswith(" ")) <= 2 * sum(1 for ln in lines if ln.startswith("@@"))
+    ref = "/root/reference/source/Lib/TLibEncoder/TEncSearch.cpp"
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not present")
+    out = tmp_path / "TEncSearch.cpp"
+    r = subprocess.run(["patch", "-s", "-o", str(out), ref, patch], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    n_ref, n_new = len(open(ref).read().splitlines()), len(open(out).read().splitlines())
+    assert n_new - n_ref == sum(1 for ln in body if ln.startswith("+"))
