@@ -38,8 +38,12 @@ constexpr int kGroups = 10;
 #ifndef ME_ITER_PER_TASK_SPLIT
 #define ME_ITER_PER_TASK_SPLIT 1
 #endif
+#ifndef ME_GUIDED_TASKS
+#define ME_GUIDED_TASKS 1
+#endif
 constexpr int kIterPerTask = ME_ITER_PER_TASK;
 constexpr int kIterPerTaskSplit = ME_ITER_PER_TASK_SPLIT;
+static_assert(ME_ITER_PER_TASK <= 4 && (!ME_GUIDED_TASKS || ME_ITER_PER_TASK == 4), "2 iteration bits in the key; the guided schedule deals 4 / 2 / 1");
 constexpr int kThreads = 256;
 
 // one CTU search: everything in integer pels except the quarter-pel predictor
@@ -185,6 +189,35 @@ __host__ __device__ inline int me_num_tasks(int wx, int wy, int iter_per_task = 
 }
 static_assert(sizeof(MeJob16) == 24, "MeJob16 layout");
 
+// Task sizes of a whole-picture launch ("guided"): the lane-iterations of a part are dealt out 4 at a time while more than T4 (8)
+// remain, then 2 at a time while more than T2 (2) remain, the last ones singly.  Large tasks keep the number of flushes low, small last ones keep the four waves of a
+// workgroup level when the task counter runs dry (a wave that finishes a 4-iteration task early leaves its SIMD slot empty until the
+// whole workgroup is done).  n4 / n2 / n1 = number of tasks of each size for `iters` iterations.
+#ifndef ME_GUIDED_T4
+#define ME_GUIDED_T4 8
+#endif
+#ifndef ME_GUIDED_T2
+#define ME_GUIDED_T2 2
+#endif
+__host__ __device__ inline void me_guided(int iters, int& n4, int& n2, int& n1) {
+  n4 = iters > ME_GUIDED_T4 ? (iters - ME_GUIDED_T4 + 3) >> 2 : 0;
+  const int rem = iters - 4 * n4;                    // T4-3..T4, or iters itself when <= T4
+  n2 = rem > ME_GUIDED_T2 ? (rem - ME_GUIDED_T2 + 1) >> 1 : 0;
+  n1 = rem - 2 * n2;                                 // T2-1..T2 (0 only for iters == 0)
+}
+__host__ __device__ inline int me_num_tasks_guided(int wx, int wy) {
+  const int quads = (wx + 3) >> 2;
+  const int wy_low = me_fold(quads, wy) ? wy - 1 : wy;
+  int n = 0;
+  for (int k = 5; k >= 0; --k)
+    if (quads & (1 << k)) {
+      int n4, n2, n1;
+      me_guided(((k == 5 ? wy : wy_low) + (64 >> k) - 1) / (64 >> k), n4, n2, n1);
+      n += n4 + n2 + n1;
+    }
+  return n;
+}
+
 // 16-bit kernel: height of the strips a wx x wy window is cut into, given the most rows LDS holds (rows_max) and the number of
 // strips the launch provides (max_strips).  The four waves of a workgroup pull lane-iterations from a counter and meet at a barrier
 // after each column-parity pass, so a pass of n iterations costs ceil(n / 4) rounds: 25 iterations cost 7 rounds, 24 cost 6.
@@ -285,7 +318,8 @@ me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefS
   //       (129 -> 32 + 1); part k lays a wave out as 2^k quads x (64 >> k) rows per iteration.
   const int quads = (wx + 3) >> 2;
   constexpr int kIt = SPLIT ? kIterPerTaskSplit : kIterPerTask;
-  const int n_tasks = min(me_num_tasks(wx, wy, kIt), t_end);
+  constexpr bool kGuided = !SPLIT && ME_GUIDED_TASKS;
+  const int n_tasks = kGuided ? me_num_tasks_guided(wx, wy) : min(me_num_tasks(wx, wy, kIt), t_end);
   const bool fold = me_fold(quads, wy);
   const int wy_low = fold ? wy - 1 : wy;
 
@@ -305,8 +339,22 @@ me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefS
       for (int kk = 5; kk >= 0; --kk) {
         if (!(quads & (1 << kk))) continue;
         const int iters = ((kk == 5 ? wy : wy_low) + (64 >> kk) - 1) / (64 >> kk);
-        const int nt = (iters + kIt - 1) / kIt;
-        if (rem < nt) { x0 = xq * 4; k = kk; it0 = rem * kIt; n_it = min(kIt, iters - it0); break; }
+        int nt;
+        if constexpr (kGuided) {
+          int n4, n2, n1;
+          me_guided(iters, n4, n2, n1);
+          nt = n4 + n2 + n1;
+          if (rem < nt) {
+            x0 = xq * 4; k = kk;
+            if (rem < n4) { it0 = 4 * rem; n_it = 4; }
+            else if (rem < n4 + n2) { it0 = 4 * n4 + 2 * (rem - n4); n_it = 2; }
+            else { it0 = 4 * n4 + 2 * n2 + (rem - n4 - n2); n_it = 1; }
+            break;
+          }
+        } else {
+          nt = (iters + kIt - 1) / kIt;
+          if (rem < nt) { x0 = xq * 4; k = kk; it0 = rem * kIt; n_it = min(kIt, iters - it0); break; }
+        }
         rem -= nt;
         xq += 1 << kk;
       }
