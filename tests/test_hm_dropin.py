@@ -19,6 +19,8 @@ EXE = os.path.join(ROOT, "oracle", "_ref", "TAppEncoder_hmme")
 EXE_HM = os.path.join(ROOT, "oracle", "_ref", "TAppEncoder_hmme_hm")   # + tools/hm_patch (CPU-exact mode, bi-pred tables, edge CTUs)
 CFG = os.path.join(ROOT, "tests", "hm", "lowdelay_P_small.cfg")
 CFG_B = os.path.join(ROOT, "tests", "hm", "lowdelay_B_small.cfg")
+CFG_P4 = os.path.join(ROOT, "tests", "hm", "lowdelay_P4_small.cfg")      # four active references (refIdx 0..3)
+CFG_RA = os.path.join(ROOT, "tests", "hm", "randomaccess_small.cfg")     # hierarchical B, GOP 8, references on both sides
 
 
 def _encode(tmp_path, opencl, frames=3, w=192, h=128, extra=(), exe=None, cfg=None, env_extra=None):
@@ -78,27 +80,27 @@ _TRACE = re.compile(r"TEncOpenCL\(hmme\): (\d+) calcMotionVectors calls, (\d+) f
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg,bipred", [(CFG, False), (CFG_B, True)])
-def test_patched_encoder_hm_mode_equals_hm_cpu_search(tmp_path, cfg, bipred):
+@pytest.mark.parametrize("cfg,bipred,frames", [(CFG, False, 4), (CFG_B, True, 4), (CFG_P4, False, 6), (CFG_RA, True, 9)])
+def test_patched_encoder_hm_mode_equals_hm_cpu_search(tmp_path, cfg, bipred, frames):
     """tools/hm_patch applied (oracle/_ref/TAppEncoder_hmme_hm), 208x120 = 4 x 2 CTUs of which only 3 are whole.  HMME_VERIFY=1 makes
     the encoder run HM's OWN xPatternSearch beside every engine call: the 64x64 2Nx2N PU and three more slots per call must
     come out identical (MV and ruiCost) -- i.e. what --FastSearch=0 computes for those PUs on the same inputs -- for uni- and
     bi-prediction calls.  Edge CTUs are searched (not served from the previous CTU's tables), bi-prediction uses its own tables."""
     _build()
-    r, p = _encode(tmp_path, 1, frames=4, w=208, h=120, exe=EXE_HM, cfg=cfg, env_extra={"HMME_VERIFY": "1"}, extra=("--SearchRange=24",))
+    r, p = _encode(tmp_path, 1, frames=frames, w=208, h=120, exe=EXE_HM, cfg=cfg, env_extra={"HMME_VERIFY": "1"}, extra=("--SearchRange=24",))
     m = _TRACE.search(r.stderr)
     assert m, r.stderr[-1500:]
     calls, failed, edge, bi, verified, differ = (int(v) for v in m.groups())
     assert failed == 0 and differ == 0, m.group(0)
     assert calls > 0 and edge > 0 and verified >= 4 * (calls - edge - bi)
     assert (bi > 0) == bipred, m.group(0)
-    assert len(p) == 4
+    assert len(p) == frames
     # the same binary with HMME_HM_MODE=0 is the unmodified reference call sequence
-    r0, p0 = _encode(tmp_path, 1, frames=4, w=208, h=120, exe=EXE_HM, cfg=cfg, env_extra={"HMME_HM_MODE": "0"}, extra=("--SearchRange=24",))
-    rc, pc = _encode(tmp_path, 1, frames=4, w=208, h=120, exe=EXE, cfg=cfg, extra=("--SearchRange=24",))
+    r0, p0 = _encode(tmp_path, 1, frames=frames, w=208, h=120, exe=EXE_HM, cfg=cfg, env_extra={"HMME_HM_MODE": "0"}, extra=("--SearchRange=24",))
+    rc, pc = _encode(tmp_path, 1, frames=frames, w=208, h=120, exe=EXE, cfg=cfg, extra=("--SearchRange=24",))
     assert p0 == pc and int(_TRACE.search(r0.stderr).group(3)) == 0
     # against HM's own searches: exhaustive-search quality (bits within a few per cent of --FastSearch=0)
-    rf, pf = _encode(tmp_path, 0, frames=4, w=208, h=120, exe=EXE_HM, cfg=cfg, extra=("--SearchRange=24", "--FastSearch=0"))
+    rf, pf = _encode(tmp_path, 0, frames=frames, w=208, h=120, exe=EXE_HM, cfg=cfg, extra=("--SearchRange=24", "--FastSearch=0"))
     bits, bits_full = sum(b for _, b, _ in p[1:]), sum(b for _, b, _ in pf[1:])
     assert bits < 1.06 * bits_full + 500, (bits, bits_full)
     print("hm mode:", p, "\nFastSearch=0:", pf, "\n", m.group(0))

@@ -19,7 +19,8 @@ from hmme import synth, yuv  # noqa: E402
 
 EXE = os.path.join(ROOT, "oracle", "_ref", "TAppEncoder_hmme")
 EXE_HM = os.path.join(ROOT, "oracle", "_ref", "TAppEncoder_hmme_hm")   # with tools/hm_patch applied
-CFGS = {"P": os.path.join(ROOT, "tests", "hm", "lowdelay_P_small.cfg"), "B": os.path.join(ROOT, "tests", "hm", "lowdelay_B_small.cfg")}
+CFGS = {"P": os.path.join(ROOT, "tests", "hm", "lowdelay_P_small.cfg"), "B": os.path.join(ROOT, "tests", "hm", "lowdelay_B_small.cfg"),
+        "P4": os.path.join(ROOT, "tests", "hm", "lowdelay_P4_small.cfg"), "RA": os.path.join(ROOT, "tests", "hm", "randomaccess_small.cfg")}
 
 
 def main():
@@ -27,7 +28,7 @@ def main():
     ap.add_argument("--size", default="416x240")
     ap.add_argument("--frames", type=int, default=5)
     ap.add_argument("--search-range", type=int, default=64)
-    ap.add_argument("--gop", default="P", choices=sorted(CFGS), help="low-delay P (one reference) or B (two references, bi-prediction)")
+    ap.add_argument("--gop", default="P", choices=sorted(CFGS), help="low-delay P (one reference), B (two references, bi-prediction), P4 (four references) or RA (hierarchical B, GOP 8)")
     ap.add_argument("--skip-full-search", action="store_true", help="leave out the CPU exhaustive search (minutes per picture at 1080p)")
     ap.add_argument("--log", default=None, help="append progress lines to this file as configurations start and finish (long runs on the "
                                                 "GPU box must keep writing under gpurun_out/)")
@@ -79,7 +80,7 @@ def main():
         if m and int(m.group(1)):
             row.update(dict(zip(("engine_calls", "failed", "edge_ctu_calls", "bipred_calls", "verified", "verify_mismatches"), (int(v) for v in m.groups()))))
         rows.append(row)
-    print(json.dumps({"clip": f"{w}x{h} x {args.frames} synthetic", "gop": "low-delay " + args.gop, "search_range": args.search_range, "hm_args": args.hm_args, "runs": rows}, indent=1))
+    print(json.dumps({"clip": f"{w}x{h} x {args.frames} synthetic", "gop": {"P": "low-delay P", "B": "low-delay B", "P4": "low-delay P, 4 references", "RA": "random access, GOP 8"}[args.gop], "search_range": args.search_range, "hm_args": args.hm_args, "runs": rows}, indent=1))
 
 
 if __name__ == "__main__":
