@@ -242,8 +242,7 @@ __host__ __device__ inline int me_strip_rows16(int wx, int wy, int rows_max, int
 // round trip per 256 dwords -- 37 of them for a 129 x 129 window, ~4 % of a workgroup's lifetime, 63 per pass and strip (12 %) in
 // the 16-bit kernel.
 template <int PDW, int THREADS>
-__device__ __forceinline__ void me_stage_window(uint32_t* win, const uint32_t* __restrict__ src_al, int pitch_dw, int n, uint32_t mis, int tid,
-                                                int pre = 0) {
+__device__ __forceinline__ void me_stage_window(uint32_t* win, const uint32_t* __restrict__ src_al, int pitch_dw, int n, uint32_t mis, int tid) {
   constexpr int U = 8;
   for (int i0 = tid; i0 < n; i0 += THREADS * U) {
     uint32_t lo[U], hi[U];
@@ -257,7 +256,7 @@ __device__ __forceinline__ void me_stage_window(uint32_t* win, const uint32_t* _
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int i = i0 + u * THREADS;
-      if (i < n) win[i] = __builtin_amdgcn_alignbyte(hi[u], lo[u], mis) << pre;
+      if (i < n) win[i] = __builtin_amdgcn_alignbyte(hi[u], lo[u], mis);
     }
   }
 }
@@ -527,22 +526,6 @@ __device__ __forceinline__ uint32_t me_keymin3(uint32_t s0, uint32_t s1, uint32_
   return r;
 }
 
-// pre-scaled samples (sums carry 8 - shift zero bits at the bottom): the all-rows family's key is (sum & ~0xFF) + c
-__device__ __forceinline__ uint32_t me_keymin3_add(uint32_t s0, uint32_t s1, uint32_t s2, uint32_t mask, uint32_t c0, uint32_t c1, uint32_t c2) {
-  uint32_t r, t, u;
-  asm volatile("v_and_b32 %0, %6, %3\n\tv_and_b32 %1, %6, %4\n\tv_and_b32 %2, %6, %5\n\t"
-               "v_add_u32 %0, %0, %7\n\tv_add_u32 %1, %1, %8\n\tv_add_u32 %2, %2, %9\n\t"
-               "v_min3_u32 %0, %0, %1, %2"
-               : "=&v"(r), "=&v"(t), "=&v"(u) : "v"(s0), "v"(s1), "v"(s2), "s"(mask), "v"(c0), "v"(c1), "v"(c2));
-  return r;
-}
-#ifdef ME16_PRE_HACK
-#define ME16_KEYMIN_A(s0, s1, s2) me_keymin3_add(s0, s1, s2, mask_a, c0, c1, c2)
-#else
-#define ME16_KEYMIN_A(s0, s1, s2) me_keymin3(s0, s1, s2, mask_a, lsh_a, c0, c1, c2)
-#endif
-#define ME16_KEYMIN_E(s0, s1, s2) me_keymin3(s0, s1, s2, mask_e, lsh_e, c0, c1, c2)
-
 template <int FEN, int PDW>
 __global__ void __launch_bounds__(kThreads16, 2)
 me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet refs, int ref_pitch,
@@ -565,22 +548,11 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const Re
   for (int s = tid; s < kParts; s += kThreads16) best64[s] = ~0ull;
   for (int i = tid; i < 64 * 8; i += kThreads16) {
     const int r = i >> 3, q = i & 7;
-#ifdef ME16_PRE_HACK
-    curl[i] = *(const u32x4_t*)(cur_base + (long)(job.ctu_y + r) * cur_pitch + 2 * job.ctu_x + 16 * q) << (uint32_t)(8 - sh);
-#else
     curl[i] = *(const u32x4_t*)(cur_base + (long)(job.ctu_y + r) * cur_pitch + 2 * job.ctu_x + 16 * q);
-#endif
   }
   // key = ((sum & mask) << lsh) + c  ==  (((sum << fen_shift) >> sh) << kIdxBits16) + c
-#ifdef ME16_PRE_HACK
-  const int pre = 8 - sh;
-  const uint32_t mask_a = ~0xFFu, lsh_a = 0;
-  const uint32_t mask_e = FEN ? ~0x7Fu : mask_a, lsh_e = FEN ? 1 : 0;
-#else
-  const int pre = 0;
   const uint32_t mask_a = ~((1u << sh) - 1u), lsh_a = kIdxBits16 - sh;
   const uint32_t mask_e = FEN ? ~((1u << (sh > 0 ? sh - 1 : 0)) - 1u) : mask_a, lsh_e = FEN ? kIdxBits16 + 1 - sh : lsh_a;
-#endif
   const bool rb1 = lane & 2, rb0 = lane & 1;
   const lds_vu32x4_t* curv4 = (const lds_vu32x4_t*)curl;
   constexpr int ME16_PDW = PDW;
@@ -598,7 +570,7 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const Re
       const uint32_t* src_al = (const uint32_t*)(src - mis);
       const int pitch_dw = ref_pitch >> 2;
       const int n = (ny + 63) * PDW;
-      me_stage_window<PDW, kThreads16>(win, src_al, pitch_dw, n, mis, tid, pre);
+      me_stage_window<PDW, kThreads16>(win, src_al, pitch_dw, n, mis, tid);
     }
     __syncthreads();
 

@@ -466,7 +466,7 @@ HEADER16 = """// GENERATED by tools/gen_me_tree.py -- do not edit.  One lane-ite
 // (fen=%d): three candidates (x, x+2, x+4) per lane, exact 32-bit sums, v_sad_u16 leaves.
 // Expects in scope: lpd (per-lane LDS byte pointer at the first candidate, window row 0; 4-byte aligned), ME16_PDW (window pitch in
 // dwords), curv4 (volatile LDS copy of the 64x64 current block, u32x4[64][8]), c0, c1, c2, mask_a/lsh_a/mask_e/lsh_e, b0..b9,
-// rb1, rb0, the key macros ME16_KEYMIN_A / ME16_KEYMIN_E (all-rows / even-rows family) and the me_merge* helpers.
+// rb1, rb0, me_keymin3 and the me_merge* helpers.
 """
 
 
@@ -608,7 +608,7 @@ def emit_cpp(tree, path, header=None):
             o.append("const uint32_t " + ", ".join(f"{op[1]}_{j} = {op[2]}_{j} - {op[3]}_{j}" for j in range(tree.nc)) + ";")
         elif t == "KEYMINN":
             f_ = "e" if op[3] == "E" else "a"
-            o.append(f"const uint32_t {op[1]} = ME16_KEYMIN_{f_.upper()}({op[2]}_0, {op[2]}_1, {op[2]}_2);")
+            o.append(f"const uint32_t {op[1]} = me_keymin3({op[2]}_0, {op[2]}_1, {op[2]}_2, mask_{f_}, lsh_{f_}, c0, c1, c2);")
         elif t == "CURLD16":
             o.append(f"const u32x4_t {op[1]} = curv4[{op[2] * 8 + op[3]}];")
         else:
