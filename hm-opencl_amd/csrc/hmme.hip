@@ -510,9 +510,6 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
   const int bias = bipred_origin ? (1 << p->bit_depth) : 0;
   // xPatternSearchFracDIF on 2*org - pred_other (the bBi pass) stays with the caller: the refinement kernel works on samples
   if (refine && bipred_origin) return fail(ctx, HMME_ERR_UNSUPPORTED, "refinement of a bi-prediction origin (current-block samples outside [0, %d])", maxv);
-  // unshifted sums must fit the 24-bit cost field of the 16-bit kernel's keys (me_kernels.hpp kInvCost16)
-  if (p->shift_free && p->bit_depth > (bipred_origin ? 9 : 10))
-    return fail(ctx, HMME_ERR_UNSUPPORTED, "shift-free SADs at bit depth %d%s", p->bit_depth, bipred_origin ? " with a bi-prediction origin" : "");
   const int shift_bd = p->shift_free ? 8 : p->bit_depth;   // the kernels shift by (this - 8)
   const int sr_cap = ctx->sr_max;
   if (wx < 1 || wy < 1 || wx > 2 * sr_cap + 1 || wy > 2 * sr_cap + 1)
@@ -539,6 +536,16 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
     std::memset(row + cols * bps, 0, 16);   // the kernels stage whole dwords past the last sample
   }
   if (vlo < 0 || vhi > maxv) return fail(ctx, HMME_ERR_RANGE, "hmme_search_ctu: reference sample outside [0,%d] for bit depth %d", maxv, p->bit_depth);
+  // unshifted sums must fit the 24-bit cost field of the 16-bit kernel's keys (me_kernels.hpp kInvCost16).  The bound is taken
+  // from the samples of THIS call (both scans are made anyway): no |cur - ref| exceeds max(hi - vlo, vhi - lo), so any content whose
+  // 64x64 sum cannot reach the marker is searched, whatever the nominal bit depth says (10-bit bi-prediction origins nominally
+  // reach 4096 * 2046, real ones stay far below)
+  if (p->shift_free && wide) {
+    const long span = std::max<long>((long)hi - vlo, (long)vhi - lo);
+    if (4096 * span + 65535 >= (long)hmme::kInvCost16)
+      return fail(ctx, HMME_ERR_UNSUPPORTED, "shift-free SADs of this block could reach %ld (sample difference up to %ld at bit depth %d%s): beyond the cost field",
+                  4096 * span, span, p->bit_depth, bipred_origin ? ", bi-prediction origin" : "");
+  }
   MeJob job;
   job.ctu_x = 0; job.ctu_y = 0;
   job.lt_x = (int16_t)p->lt_x; job.lt_y = (int16_t)p->lt_y; job.rb_x = (int16_t)p->rb_x; job.rb_y = (int16_t)p->rb_y;

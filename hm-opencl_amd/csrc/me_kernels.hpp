@@ -160,7 +160,8 @@ __device__ __forceinline__ uint32_t me_mv_cost(uint32_t lambda_q16, int x, int y
 // 16-bit kernel (three candidates per lane, one lane-iteration per task): key = cost << 8 | lane(6) | j(2).  The 24-bit cost field
 // holds HM's shifted sums with bi-prediction origins (<= 3 142 656 + 65 535) and the unshifted ones of
 // hmme_search_params::shift_free (what cl/sad.cl computes: 10-bit <= 4 190 208 + 65 535, 9-bit bi-prediction origins
-// <= 6 279 168 + 65 535); the invalid marker + the largest sum an invalid lane can add (6 279 168) stays < 2^24
+// <= 6 279 168 + 65 535; wider content when the samples of the call bound the sum below the marker, hmme.hip ctu_call); the invalid
+// marker + the largest sum an invalid lane can add (< 8 000 000) stays < 2^24
 constexpr int kIdxBits16 = 8;
 constexpr uint32_t kInvCost16 = 8000000u;
 constexpr int kThreads16 = 256;

@@ -78,7 +78,9 @@ typedef struct hmme_search_params {
   int fen;             /* m_pcEncCfg->getUseFastEnc() (TEncSearch.cpp:3853-3859) */
   int bit_depth;       /* 8 (packed-byte path) or 9..12 (16-bit path): SAD >> (bitDepth-8), TComRdCost.cpp:520-521 */
   int shift_free;      /* 1: no >> (bitDepth-8) on the SAD -- what cl/sad.cl computes for any Pel width;
-                          bit_depth then only states the sample range.  Bit depth <= 10 (<= 9 with bi-prediction origins) */
+                          bit_depth then only states the sample range.  A call is refused (HMME_ERR_UNSUPPORTED) when the samples it
+                          was handed could produce a 64x64 sum + MV cost >= 8 000 000, i.e. when the largest |cur - ref| its two
+                          blocks admit exceeds 1 937: never at <= 10 bit, never at 9 bit with bi-prediction origins */
 } hmme_search_params;
 
 /* one whole-picture search: window derived per CTU from the predictor exactly like

@@ -817,11 +817,30 @@ def test_shift_free_and_int16_argument_checks(engine, oracle_lib):
         shifted = engine.search_ctu(cur, (0, 0), ref, (o, o), api.SearchParams(-sr, -sr, sr, sr - 1, 7, -9, 0, bd, 0))[1]
         if bd > 8:
             assert int(shifted[592]) < int(sad[592])
+    # beyond those widths the limit is the sample span of the call's own blocks (a 64x64 sum cannot exceed 4096 * span): 10-bit
+    # bi-prediction origins and 12-bit content of moderate contrast are searched, bit-exact; a span that could reach the marker is refused
+    for bd, lo_c, hi_c, lo_r, hi_r in ((10, -700, 1200, 40, 1000), (12, 1200, 2900, 1000, 2900), (11, -100, 1800, 0, 1830)):
+        sr = 5
+        side = 64 + 2 * sr + 8
+        ref = rng.integers(lo_r, hi_r + 1, size=(side, side)).astype(np.int16)
+        cur = rng.integers(lo_c, hi_c + 1, size=(64, 64)).astype(np.int16)
+        cur[:8, :8] = ref[sr + 4 + 2:sr + 4 + 10, sr + 4 - 3:sr + 4 + 5]    # a few slots with a clear winner
+        o = sr + 4
+        for fen in (0, 1):
+            mv, sad = engine.search_ctu(cur, (0, 0), ref, (o, o), api.SearchParams(-sr, -sr, sr, sr, -3, 5, fen, bd, 1))
+            op = oracle_lib.make_params((-sr, -sr), (sr, sr), (-3, 5), engine.lambda_q16, fen, 8)
+            ox, oy, osad = oracle_lib.search_ctu(cur, (0, 0), ref, (o, o), op)
+            assert np.array_equal(mv[:, 0], ox) and np.array_equal(mv[:, 1], oy) and np.array_equal(sad, osad), (bd, fen)
+            assert int(sad[592]) > (1 << 20)
     cur = np.zeros((64, 64), np.int16)
     ref = np.zeros((100, 100), np.int16)
+    engine.search_ctu(cur, (0, 0), ref, (18, 18), api.SearchParams(-8, -8, 8, 8, 0, 0, 0, 12, 1))       # span 0: nothing to refuse
+    ref[40, 40] = 1938
     with pytest.raises(api.HmmeError, match="shift-free"):
         engine.search_ctu(cur, (0, 0), ref, (18, 18), api.SearchParams(-8, -8, 8, 8, 0, 0, 0, 12, 1))
-    cur2 = cur.copy(); cur2[0, 0] = -5
+    ref[40, 40] = 1937
+    engine.search_ctu(cur, (0, 0), ref, (18, 18), api.SearchParams(-8, -8, 8, 8, 0, 0, 0, 12, 1))
+    cur2 = cur.copy(); cur2[0, 0] = -1023; ref[40, 40] = 1000
     with pytest.raises(api.HmmeError, match="shift-free"):
         engine.search_ctu(cur2, (0, 0), ref, (18, 18), api.SearchParams(-8, -8, 8, 8, 0, 0, 0, 10, 1))
     for bad in (api.SearchParams(-8, -8, 8, 8, 40000, 0, 1, 8), api.SearchParams(-8, -8, 8, 8, 0, -40000, 1, 8),
