@@ -34,7 +34,8 @@ static_assert(sizeof(MeJob16) * kCallMaxJobs <= kCallFirst && kCallFracJob + siz
 // pinned result block: 593 MVs, 593 SADs, completion word of the search; 593 quarter-pel MVs, 593 costs, completion word of the refinement
 constexpr size_t kResMv = 0, kResSad = 4 * HMME_NUM_CTU_PARTS, kResDone = 8 * HMME_NUM_CTU_PARTS, kResQmv = kResDone + 64,
                  kResCost = kResQmv + 4 * HMME_NUM_CTU_PARTS, kResDone2 = kResCost + 4 * HMME_NUM_CTU_PARTS, kResBytes = kResDone2 + 64;
-constexpr size_t kLdsBudget16 = 78 * 1024;   // per workgroup of the 16-bit path -> 2 workgroups per CU
+// per workgroup of the 16-bit path -> 2 workgroups per CU (HMME_LDS_BUDGET16: A/B knob in bytes)
+const size_t kLdsBudget16 = std::getenv("HMME_LDS_BUDGET16") ? (size_t)std::atol(std::getenv("HMME_LDS_BUDGET16")) : 78 * 1024;
 // 16-bit window pitch in dwords for windows up to 129 / 257 candidates wide (row = (wx + 63 + 1) samples / 2, + 34 dwords the
 // last lane of a row reaches beyond its first candidate)
 constexpr int kPdw16Small = 130, kPdw16Large = 162;
@@ -196,7 +197,10 @@ int launch_search8_split(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const
 
 // ---- 16-bit path -------------------------------------------------------------------------------------
 
-size_t lds_bytes16(int pdw, int strip_rows) { return (size_t)(2 * 594 + 64 * 8 * 4 + 4 + (strip_rows + 63) * pdw) * 4; }
+#ifndef ME16_LDS_PAD
+#define ME16_LDS_PAD 0
+#endif
+size_t lds_bytes16(int pdw, int strip_rows) { return (size_t)(2 * 594 + 4 + ME16_LDS_PAD + (strip_rows + 63) * pdw) * 4; }
 
 // most candidate rows of one strip whose window rows (+ 63) fit the LDS budget
 int rows_max16(int pdw) {
@@ -234,7 +238,8 @@ int launch_search16(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const RefS
   unsigned long long* best = nullptr;
   int rc = merge_table(ctx, n_jobs, preset_best, stream, &best);
   if (rc) return rc;
-  const size_t lds = lds_bytes16(pdw, strip_rows_max);
+  size_t lds = lds_bytes16(pdw, strip_rows_max);
+  if (const char* e = std::getenv("HMME_LDS_REQ16")) lds = std::max(lds, (size_t)std::atol(e));
   const int sh = bit_depth - 8, n_wg = n_jobs * n_strips;
   if (pdw == kPdw16Small)
     rc = fen ? launch16_t<1, kPdw16Small>(ctx, cur, cur_pitch, ref, ref_pitch, d_jobs, n_wg, lds, sh, best, stream)
@@ -500,7 +505,7 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
   // samples outside [0, maxv] are the bi-prediction origin 2*org - pred_other (reference TEncSearch.cpp:3702-3712,
   // TComYuv::removeHighFreq TComYuv.cpp:409-440, unclipped).  They stay exact: the 16-bit kernel runs on samples
   // biased by 2^bitDepth (|a - b| is unchanged), so pick the kernel after looking at the data.
-  int lo = 0, hi = 0;
+  int lo = 32767, hi = -32768;
   for (int y = 0; y < 64; ++y) row_minmax(ctu + (long)y * ctu_stride, 64, lo, hi);
   const int wx = p->rb_x - p->lt_x + 1, wy = p->rb_y - p->lt_y + 1;
   const bool bipred_origin = lo < 0 || hi > maxv;
@@ -522,7 +527,7 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
   uint8_t* h_win = ctx->h_call + kCallWin;
   const int rows = wy + 63 + 2 * halo, cols = wx + 63 + 2 * halo;
   const int16_t* src = ref0 + (long)(p->lt_y - halo) * ref_stride + (p->lt_x - halo);
-  int vlo = 0, vhi = 0;
+  int vlo = 32767, vhi = -32768;
   for (int y = 0; y < 64; ++y) {
     if (wide) row_pack16(ctu + (long)y * ctu_stride, 64, bias, (uint16_t*)h_ctu + y * 64);
     else row_pack8(ctu + (long)y * ctu_stride, 64, h_ctu + y * 64);
@@ -736,8 +741,12 @@ static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_para
   if (wide) {   // strips of the balanced height for the full window (me_strip_rows16); clipped windows choose their own within n_strips
     const int w = 2 * fp->search_range + 1, rmax = rows_max16(*pdw);
     *strip_rows = rmax;
-    const int h = hmme::me_strip_rows16(w, w, rmax, strips_for(*pdw, w) + 2);   // up to two strips more than LDS alone needs
+    const int h = hmme::me_strip_rows16(w, w, rmax, strips_for(*pdw, w) + 4);   // up to four strips more than LDS alone needs
     *n_strips = (w + h - 1) / h;
+    if (const char* e = std::getenv("HMME_STRIPS16")) {   // A/B knob: that many strips of equal height
+      const int n = std::atoi(e);
+      if (n >= strips_for(*pdw, w) && n <= w) { *n_strips = n; *strip_rows = (w + n - 1) / n; }
+    }
   }
   static const int split_below = std::getenv("HMME_SPLIT_BELOW") ? std::atoi(std::getenv("HMME_SPLIT_BELOW")) : 384;   // A/B knob, DESIGN.md 8
   if (!wide && jobs < split_below) {

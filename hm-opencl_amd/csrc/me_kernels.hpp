@@ -223,16 +223,18 @@ __host__ __device__ inline int me_num_tasks_guided(int wx, int wy) {
 // strips the launch provides (max_strips).  The four waves of a workgroup pull lane-iterations from a counter and meet at a barrier
 // after each column-parity pass, so a pass of n iterations costs ceil(n / 4) rounds: 25 iterations cost 7 rounds, 24 cost 6.
 // Iterations of a pass over h rows: ceil(h * lanes_per_row / 64), lanes_per_row = ceil(candidates of one parity / 3) (three
-// candidates per lane; the even pass has at least as many as the odd one).  Picks the height whose split [h, h, ..., rest] costs the
-// fewest rounds, a strip counting half a round for its two window loads; ties go to the taller strip.
+// candidates per lane; the even pass has at least as many as the odd one).
+// Strips are of EQUAL height ceil(wy / n): what a launch loses at its end is about half the lifetime of its longest workgroup, and
+// a tall strip next to a short one made every launch measured slower than the even split of the same iterations (129 rows on
+// 4 080 workgroups: 65 + 64 5.07 ms, 69 + 60 5.23, 81 + 48 6.10; 257 rows: 5 x 52 19.05 ms, 5 x 47 + 22 19.69).  The number of
+// strips is the one with the fewest rounds, a strip counting half a round for its two window loads; ties go to fewer strips.
 __host__ __device__ inline int me_strip_rows16(int wx, int wy, int rows_max, int max_strips) {
   const int lanes = (((wx + 1) >> 1) + 2) / 3;
   int best_h = (wy + max_strips - 1) / max_strips, best_cost = 0x7fffffff;
-  for (int h = rows_max < wy ? rows_max : wy; h >= 1; --h) {
-    const int n = (wy + h - 1) / h;
-    if (n > max_strips) break;
-    const int rest = wy - (n - 1) * h;
-    const int cost = 2 * ((n - 1) * ((((h * lanes + 63) >> 6) + 3) >> 2) + ((((rest * lanes + 63) >> 6) + 3) >> 2)) + n;
+  for (int n = (wy + rows_max - 1) / rows_max; n <= max_strips && n <= wy; ++n) {
+    const int h = (wy + n - 1) / n;
+    const int used = (wy + h - 1) / h, rest = wy - (used - 1) * h;
+    const int cost = 2 * ((used - 1) * ((((h * lanes + 63) >> 6) + 3) >> 2) + ((((rest * lanes + 63) >> 6) + 3) >> 2)) + used;
     if (cost < best_cost) { best_cost = cost; best_h = h; }
   }
   return best_h;
@@ -533,9 +535,8 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const Re
                    const MeJob16* __restrict__ jobs, uint32_t lambda_q16, int sh, unsigned long long* __restrict__ g_best) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   unsigned long long* best64 = (unsigned long long*)smem;              // [593] (+1 pad)
-  u32x4_t* curl = (u32x4_t*)(smem + 2 * 594);                          // [64][8]: 64x64 u16 current block
-  int* task_ctr = (int*)(smem + 2 * 594 + 64 * 8 * 4);
-  uint32_t* win = smem + 2 * 594 + 64 * 8 * 4 + 4;                     // [(ny + 63)][PDW]
+  int* task_ctr = (int*)(smem + 2 * 594);
+  uint32_t* win = smem + 2 * 594 + 4;                                  // [(ny + 63)][PDW]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -547,16 +548,31 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const Re
   const int ny = jb.y1 - jb.y0;                                        // candidate rows of this strip
 
   for (int s = tid; s < kParts; s += kThreads16) best64[s] = ~0ull;
-  for (int i = tid; i < 64 * 8; i += kThreads16) {
-    const int r = i >> 3, q = i & 7;
-    curl[i] = *(const u32x4_t*)(cur_base + (long)(job.ctu_y + r) * cur_pitch + 2 * job.ctu_x + 16 * q);
-  }
   // key = ((sum & mask) << lsh) + c  ==  (((sum << fen_shift) >> sh) << kIdxBits16) + c
   const uint32_t mask_a = ~((1u << sh) - 1u), lsh_a = kIdxBits16 - sh;
   const uint32_t mask_e = FEN ? ~((1u << (sh > 0 ? sh - 1 : 0)) - 1u) : mask_a, lsh_e = FEN ? kIdxBits16 + 1 - sh : lsh_a;
   const bool rb1 = lane & 2, rb0 = lane & 1;
-  const lds_vu32x4_t* curv4 = (const lds_vu32x4_t*)curl;
   constexpr int ME16_PDW = PDW;
+  // The current block comes through the scalar cache into SGPRs (v_sad_u16 takes one SGPR operand): no LDS slot and no VGPR for
+  // it -- as a wave-uniform ds_read_b128 each of its 512 reads per lane-iteration cost a full LDS slot, a third of the kernel's LDS
+  // time.  Scalar loads complete out of order: ME16_CUR_WAIT (placed by the generator half a CU after the loads, before the next
+  // batch is issued) waits for the whole batch and ties the loaded quads to the wait; the window dwords of the same batch are
+  // named as inputs so that the compiler's own LDS wait lands in front of it, not behind the next batch.
+  const uintptr_t cur_addr = (uintptr_t)(cur_base + (long)job.ctu_y * cur_pitch + 2 * job.ctu_x);
+  const uint64_t curc = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)cur_addr) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(cur_addr >> 32)) << 32;
+  const uint32_t cur_pitch_s = (uint32_t)__builtin_amdgcn_readfirstlane(cur_pitch);
+#define ME16_CUR(row, q)                                                                                                           \
+  ({                                                                                                                               \
+    u32x4_t w_;                                                                                                                    \
+    uint32_t o_;                                                                                                                   \
+    asm volatile("s_mul_i32 %1, %3, %4\n\ts_load_dwordx4 %0, %2, %1 offset:%5"                                                     \
+                 : "=s"(w_), "=&s"(o_) : "s"(curc), "s"(cur_pitch_s), "n"(row), "n"(16 * (q)));                                     \
+    w_;                                                                                                                            \
+  })
+#define ME16_CUR_WAIT(w0, w1, w2, w3, d0, d1, d2, d3, d4, d5, d6, d7, d8, d9, d10, d11)                                               \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3)                                                       \
+               : "v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(d4), "v"(d5), "v"(d6), "v"(d7), "v"(d8), "v"(d9), "v"(d10), "v"(d11))
 
   // Two passes: the even window columns, then the odd ones, each over a window loaded with a shift of `par` samples.
   // A lane owns the candidates (x, x + 2, x + 4): all read dword-aligned u16 pairs, each one dword further on -- the six dwords
@@ -629,6 +645,8 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const Re
 #undef ME_FLUSH16
   }
   }   // par
+#undef ME16_CUR
+#undef ME16_CUR_WAIT
   __syncthreads();
   for (int s = tid; s < kParts; s += kThreads16) atomicMin(&g_best[(long)jb.job * kParts + s], best64[s]);
 }
@@ -702,13 +720,18 @@ __global__ void me_prep_jobs16_kernel(MeJob16* jobs, int* first_strip_of_job, co
   // strips of the height me_strip_rows16 picks for this window, the last one takes the rest; strips beyond the window (clipped
   // windows need fewer) are empty: y0 == y1
   const int h = me_strip_rows16(rbx - ltx + 1, wy, rows_max, n_strips);
+  const int xcd_period = (n_strips & 1) ? 8 : (n_strips & 2) ? 4 : (n_strips & 4) ? 2 : 1;
   for (int s = 0; s < n_strips; ++s) {
     MeJob16 js;
     js.j = j;
     js.y0 = (int16_t)min(wy, s * h);
     js.y1 = (int16_t)min(wy, (s + 1) * h);
     js.job = i;
-    jobs[i * n_strips + s] = js;
+    // Workgroup g runs on XCD g % 8 and each XCD works through its eighth of the grid on its own: strips of unequal height must
+    // not land on a fixed XCD (with two strips per CTU every tall strip sat on an even XCD and the launch took as long as if all
+    // strips were tall).  The XCD of a job's first workgroup repeats every 8 / gcd(n_strips, 8) jobs: the strip order rotates by
+    // one each time it does, which deals every height to every XCD.
+    jobs[i * n_strips + (s + i / xcd_period) % n_strips] = js;
   }
 }
 

@@ -433,13 +433,19 @@ class Tree16(Tree):
         def half(loads, h):
             return [o for o in loads if (o[0] == "ROWBASE" and (o[2] & 7) // 4 == h) or (o[0] == "LDS16Q" and self._row_of(o) // 4 == h)
                     or (o[0] == "CURLD16" and (o[2] & 7) // 4 == h)]
+        def arrived(loads):
+            """the batch about to be consumed: its scalar loads (the current block) complete out of order, so the wave waits for
+            the whole batch BEFORE it issues the next one -- the batch has had half a CU of arithmetic to arrive"""
+            return ("CURWAIT", [o[1] for o in loads if o[0] == "CURLD16"], [o[1] for o in loads if o[0] == "LDS16Q"])
         ops = list(half(self.cu_loads[0], 0))
         cu = 0
         for o in self.ops:
             if o[0] == "LOADS_FOR":
                 cu = o[1] - 1                      # marker n+1 sits at the top of CU n
+                ops.append(arrived(half(self.cu_loads[cu], 0)))
                 ops.extend(half(self.cu_loads[cu], 1))
             elif o[0] == "MID":
+                ops.append(arrived(half(self.cu_loads[cu], 1)))
                 if cu + 1 < len(self.cu_loads):
                     ops.extend(half(self.cu_loads[cu + 1], 0))
             else:
@@ -465,8 +471,8 @@ HEADER = """// GENERATED by tools/gen_me_tree.py -- do not edit.  One lane-itera
 HEADER16 = """// GENERATED by tools/gen_me_tree.py -- do not edit.  One lane-iteration of the 16-bit-sample reduction tree
 // (fen=%d): three candidates (x, x+2, x+4) per lane, exact 32-bit sums, v_sad_u16 leaves.
 // Expects in scope: lpd (per-lane LDS byte pointer at the first candidate, window row 0; 4-byte aligned), ME16_PDW (window pitch in
-// dwords), curv4 (volatile LDS copy of the 64x64 current block, u32x4[64][8]), c0, c1, c2, mask_a/lsh_a/mask_e/lsh_e, b0..b9,
-// rb1, rb0, me_keymin3 and the me_merge* helpers.
+// dwords), ME16_CUR(row, q) (scalar load of 8 current-block samples) and ME16_CUR_WAIT (the batch has arrived), c0, c1, c2,
+// mask_a/lsh_a/mask_e/lsh_e, b0..b9, rb1, rb0, me_keymin3 and the me_merge* helpers.
 """
 
 
@@ -610,7 +616,9 @@ def emit_cpp(tree, path, header=None):
             f_ = "e" if op[3] == "E" else "a"
             o.append(f"const uint32_t {op[1]} = me_keymin3({op[2]}_0, {op[2]}_1, {op[2]}_2, mask_{f_}, lsh_{f_}, c0, c1, c2);")
         elif t == "CURLD16":
-            o.append(f"const u32x4_t {op[1]} = curv4[{op[2] * 8 + op[3]}];")
+            o.append(f"u32x4_t {op[1]} = ME16_CUR({op[2]}, {op[3]});")
+        elif t == "CURWAIT":
+            o.append(f"ME16_CUR_WAIT({', '.join(op[1])}, {', '.join(v + '_q' for v in op[2])});")
         else:
             raise ValueError(t)
     write_if_changed(path, "\n".join(o) + "\n")
@@ -678,6 +686,8 @@ def simulate16(tree, window, cur, lane_off, c, best, sh):
             for v, k in ((op[1], op[5]), (op[2], op[5] + 1)):
                 idx = lane_off + (rowbase[op[3]] + op[4]) * pitch + 2 * k
                 val[v] = np.stack([flat[idx], flat[idx + 1]], axis=1)
+        elif t == "CURWAIT":
+            pass
         elif t == "CURLD16":
             val[op[1]] = cur[op[2], op[3] * 8:op[3] * 8 + 8].astype(np.int64).reshape(4, 2)
         elif t == "SAD16xN":
