@@ -25,7 +25,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "hm-opencl_amd"))
 
-SIZES = {"2160p": (3840, 2160), "1080p": (1920, 1080)}
+SIZES = {"2160p": (3840, 2160), "1080p": (1920, 1080), "1440p": (2560, 1440), "1600p": (2560, 1600), "720p": (1280, 720), "1200p": (1920, 1200)}
 
 
 def algo_bytes_per_ctu(sr, bit_depth):

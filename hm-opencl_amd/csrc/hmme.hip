@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -65,6 +66,7 @@ struct hmme_ctx {
   // frame path scratch (grown on demand)
   void* d_jobs = nullptr;         // MeJob[] or MeJob16[]
   size_t jobs_bytes = 0;
+  int wg_slots = 512;     // search workgroups resident at once: 2 per CU (VGPRs of the search kernels, LDS of the 16-bit one)
   int* d_first_strip = nullptr;
   int first_strip_cap = 0;
   unsigned long long* d_best = nullptr;   // 16-bit path: [jobs][593] merge table
@@ -197,10 +199,7 @@ int launch_search8_split(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const
 
 // ---- 16-bit path -------------------------------------------------------------------------------------
 
-#ifndef ME16_LDS_PAD
-#define ME16_LDS_PAD 0
-#endif
-size_t lds_bytes16(int pdw, int strip_rows) { return (size_t)(2 * 594 + 4 + ME16_LDS_PAD + (strip_rows + 63) * pdw) * 4; }
+size_t lds_bytes16(int pdw, int strip_rows) { return (size_t)(2 * 594 + 4 + (strip_rows + 63) * pdw) * 4; }
 
 // most candidate rows of one strip whose window rows (+ 63) fit the LDS budget
 int rows_max16(int pdw) {
@@ -232,15 +231,14 @@ int launch16_t(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const RefSet& r
 
 // d_jobs: n_jobs * n_strips MeJob16; results merged in ctx->d_best then decoded into d_mv / d_sad
 int launch_search16(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const RefSet& ref, int ref_pitch, const MeJob16* d_jobs,
-                    const int* d_first_strip, int n_jobs, int n_strips, int pdw, int strip_rows_max, int fen, int bit_depth,
+                    const int* d_first_strip, int n_jobs, int n_wg, int pdw, int strip_rows_max, int fen, int bit_depth,
                     int16_t* d_mv, uint32_t* d_sad, hipStream_t stream, unsigned long long* preset_best = nullptr, bool finalize = true) {
   if (n_jobs <= 0) return HMME_OK;
   unsigned long long* best = nullptr;
   int rc = merge_table(ctx, n_jobs, preset_best, stream, &best);
   if (rc) return rc;
-  size_t lds = lds_bytes16(pdw, strip_rows_max);
-  if (const char* e = std::getenv("HMME_LDS_REQ16")) lds = std::max(lds, (size_t)std::atol(e));
-  const int sh = bit_depth - 8, n_wg = n_jobs * n_strips;
+  const size_t lds = lds_bytes16(pdw, strip_rows_max);
+  const int sh = bit_depth - 8;
   if (pdw == kPdw16Small)
     rc = fen ? launch16_t<1, kPdw16Small>(ctx, cur, cur_pitch, ref, ref_pitch, d_jobs, n_wg, lds, sh, best, stream)
              : launch16_t<0, kPdw16Small>(ctx, cur, cur_pitch, ref, ref_pitch, d_jobs, n_wg, lds, sh, best, stream);
@@ -344,6 +342,7 @@ int hmme_create(int device, int sr_max, unsigned flags, hmme_ctx** out) {
   snprintf(info, sizeof info, "%s (%s), %d CUs, %.0f GiB", prop.name, prop.gcnArchName, prop.multiProcessorCount,
            (double)prop.totalGlobalMem / (1 << 30));
   ctx->info = info;
+  ctx->wg_slots = 2 * prop.multiProcessorCount;
   const size_t win_bytes = (size_t)kWinRows * kWinPitch + 64;
 #define CREATE_TRY(call)                                                                                           \
   do {                                                                                                             \
@@ -729,73 +728,139 @@ int hmme_plane_set_device_u8(hmme_plane* pl, const void* d_src, int src_pitch, v
 }
 
 // ---- frame search --------------------------------------------------------------------------------------------
+// How the (CTU, reference) searches of one launch are dealt to workgroups.  The chip holds ctx->wg_slots search workgroups at a time
+// and a launch runs in rounds of that many: 2 040 CTU searches are 3.98 rounds of 512, but 570 (1920 x 1200) are 1.11 -- the second
+// round would keep 58 slots busy and cost as much as the first (measured before this plan existed: 2 340 GSAD/s against 3 339 at
+// 2160p).  So the jobs beyond the last full round ("tail", from job tail_first on) are dealt in finer pieces:
+//   8-bit:  jobs [0, tail_first) run whole (me_search_kernel<FEN, 0>), the tail runs through the split kernel, tail_parts task ranges
+//           per job merged through the 64-bit atomicMin table (a second launch on the same stream);
+//   16-bit: one launch; jobs [0, tail_first) are cut into n_strips strips, tail jobs into tail_parts (>= n_strips).
+// A launch of fewer jobs than slots is all tail (the small-picture split mode of round 1).  8-bit windows beyond 129 x 129 (four tiles
+// per job through the split kernel) are not re-planned.
+struct FramePlan {
+  int jobs = 0;
+  int n_strips = 1;        // 16-bit: strips of a head job; 8-bit: 4 when tiled, else 1
+  int pdw = 0, strip_rows = 0;
+  int tail_first = 0;      // == jobs: no tail
+  int tail_parts = 1;
+  bool tile8 = false;
+  int n_wg16 = 0;          // 16-bit: workgroups of the launch
+  size_t tail_jobs_off = 0;   // 8-bit: byte offset of the tail's MeJob16[] inside ctx->d_jobs
+};
+
+// pieces per tail job that finish `tail` jobs soonest: rounds of `slots` workgroups, each as long as its piece of a whole job
+// (cost[k], in any unit) -- ties go to fewer pieces
+static int plan_tail(int tail, int slots, int k_min, int k_max, const std::function<double(int)>& cost) {
+  int best_k = k_min;
+  double best = 1e30;
+  for (int k = k_min; k <= k_max; ++k) {
+    const double t = (double)(((long)tail * k + slots - 1) / slots) * cost(k);
+    if (t < best * 0.999) { best = t; best_k = k; }
+  }
+  return best_k;
+}
+
 // builds the device job table of a picture search against n_refs reference pictures on `s`; job index =
-// ref * count + ctu.  8-bit: MeJob[jobs]; 8-bit split / 16-bit: MeJob16[jobs * strips]
+// ref * count + ctu.  8-bit: MeJob[head jobs] (+ MeJob16[tail jobs * parts]); 8-bit tiled / 16-bit: MeJob16[workgroups]
 static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_params* fp, const void* d_pred_q, int first, int count,
-                     int n_refs, hipStream_t s, int* n_strips, int* pdw, int* strip_rows) {
+                     int n_refs, hipStream_t s, FramePlan* pl) {
   const bool wide = fp->bit_depth > 8;
-  const int jobs = count * n_refs;
-  *pdw = fp->search_range <= 64 ? kPdw16Small : kPdw16Large;
-  *n_strips = 1;
-  *strip_rows = 2 * fp->search_range + 1;
-  if (wide) {   // strips of the balanced height for the full window (me_strip_rows16); clipped windows choose their own within n_strips
-    const int w = 2 * fp->search_range + 1, rmax = rows_max16(*pdw);
-    *strip_rows = rmax;
-    const int h = hmme::me_strip_rows16(w, w, rmax, strips_for(*pdw, w) + 4);   // up to four strips more than LDS alone needs
-    *n_strips = (w + h - 1) / h;
+  const int jobs = count * n_refs, slots = ctx->wg_slots, w = 2 * fp->search_range + 1;
+  pl->jobs = jobs;
+  pl->pdw = fp->search_range <= 64 ? kPdw16Small : kPdw16Large;
+  pl->n_strips = 1;
+  pl->strip_rows = w;
+  pl->tile8 = !wide && fp->search_range > 64;   // window beyond 129 x 129: four tile searches per CTU, merged like split tasks
+  pl->tail_first = jobs; pl->tail_parts = 1;
+  static const int tail_knob = std::getenv("HMME_TAIL_PARTS") ? std::atoi(std::getenv("HMME_TAIL_PARTS")) : 0;   // A/B knob: 1 = no tail plan
+  const int tail = jobs % slots;
+  if (wide) {   // strips of equal height for the full window (me_strip_rows16); clipped windows choose their own within n_strips
+    const int rmax = rows_max16(pl->pdw), n_min = strips_for(pl->pdw, w);
+    pl->strip_rows = rmax;
+    const int h = hmme::me_strip_rows16(w, w, rmax, n_min + 4);   // up to four strips more than LDS alone needs
+    pl->n_strips = (w + h - 1) / h;
     if (const char* e = std::getenv("HMME_STRIPS16")) {   // A/B knob: that many strips of equal height
       const int n = std::atoi(e);
-      if (n >= strips_for(*pdw, w) && n <= w) { *n_strips = n; *strip_rows = (w + n - 1) / n; }
+      if (n >= n_min && n <= w) { pl->n_strips = n; pl->strip_rows = (w + n - 1) / n; }
     }
+    // the workgroups beyond the last full round: head jobs give (jobs - tail) * n_strips of them, which need not fill whole rounds
+    // either -- the tail is planned on what is left of the last head round
+    const int lanes = (((w + 1) >> 1) + 2) / 3;
+    auto strip_cost = [&](int k) {   // rounds of one strip of a job cut into k, plus half a round for its two window loads
+      const int hk = (w + k - 1) / k;
+      return 2.0 * ((((hk * lanes + 63) >> 6) + 3) >> 2) + 1.0;
+    };
+    if (tail && tail_knob != 1) {
+      const int k_max = std::min(w / 4, 64);
+      int k = tail_knob > 1 ? std::min(tail_knob, k_max) : plan_tail(tail, slots, pl->n_strips, k_max, strip_cost);
+      if (k < pl->n_strips) k = pl->n_strips;
+      if (k > pl->n_strips) { pl->tail_first = jobs - tail; pl->tail_parts = k; }
+    }
+    pl->n_wg16 = pl->tail_first * pl->n_strips + (jobs - pl->tail_first) * pl->tail_parts;
+  } else if (pl->tile8) {
+    pl->n_strips = 4;
+  } else if (tail && tail_knob != 1) {
+    // a piece of a job costs its share of the job's iterations plus what every workgroup pays: window load, flush, merge
+    const int nt = hmme::me_num_tasks(w, w);
+    const int k_max = std::max(1, (nt + 3) / 4);   // never below 4 tasks (one per wave) per workgroup
+    // in lane-iterations of the slowest wave (4 waves share a piece's tasks); a quarter iteration per workgroup for window load, flush
+    // and merge fits the sweeps of profiles/r02Q_tail_sweep.txt (1440p: 5 pieces beat 1 and 3; 1200p: 17 beat 8; 720p: 2..6 alike)
+    auto part_cost = [&](int k) { return (double)(((nt + k - 1) / k + 3) / 4) + 0.25; };
+    const int k = tail_knob > 1 ? std::min(tail_knob, k_max) : plan_tail(tail, slots, 1, k_max, part_cost);
+    if (k > 1) { pl->tail_first = jobs - tail; pl->tail_parts = k; }
   }
-  static const int split_below = std::getenv("HMME_SPLIT_BELOW") ? std::atoi(std::getenv("HMME_SPLIT_BELOW")) : 384;   // A/B knob, DESIGN.md 8
-  if (!wide && jobs < split_below) {
-    // fewer CTU searches than workgroup slots (256 CUs x 2): cut each one's task list so that ~768 workgroups exist,
-    // but never below 4 tasks (one per wave) per workgroup
-    const int nt = hmme::me_num_tasks(2 * fp->search_range + 1, 2 * fp->search_range + 1);
-    int f = (768 + jobs - 1) / jobs;
-    if (f > (nt + 3) / 4) f = (nt + 3) / 4;
-    *n_strips = f < 1 ? 1 : f;
+  const int head = pl->tail_first, n_tail = jobs - head;
+  size_t need;
+  if (wide) need = sizeof(MeJob16) * (size_t)pl->n_wg16;
+  else if (pl->tile8) need = sizeof(MeJob16) * (size_t)jobs * 4;
+  else {
+    pl->tail_jobs_off = (sizeof(MeJob) * (size_t)head + 255) & ~(size_t)255;
+    need = pl->tail_jobs_off + sizeof(MeJob16) * (size_t)n_tail * pl->tail_parts;
   }
-  const bool tile8 = !wide && fp->search_range > 64;   // window beyond 129 x 129: four tile searches per CTU, merged like split tasks
-  if (tile8) *n_strips = 4;
-  const bool split8 = !wide && *n_strips > 1;
   size_t cap = ctx->jobs_bytes;
-  int rc = ensure(ctx, (uint8_t**)&ctx->d_jobs, &cap, (wide || split8) ? sizeof(MeJob16) * (size_t)jobs * *n_strips : sizeof(MeJob) * (size_t)jobs);
+  int rc = ensure(ctx, (uint8_t**)&ctx->d_jobs, &cap, need);
   ctx->jobs_bytes = cap;
   if (rc) return rc;
-  if (wide || split8) {
+  if (wide || pl->tile8 || n_tail) {
     size_t fcap = (size_t)ctx->first_strip_cap * sizeof(int);
     rc = ensure(ctx, &ctx->d_first_strip, &fcap, sizeof(int) * (size_t)jobs);
     ctx->first_strip_cap = (int)(fcap / sizeof(int));
     if (rc) return rc;
   }
-  const dim3 grid((jobs + 255) / 256), block(256);
-  if (tile8)
-    hipLaunchKernelGGL(hmme::me_prep_jobs_tile_kernel, grid, block, 0, s, (MeJob16*)ctx->d_jobs, ctx->d_first_strip,
+  const dim3 block(256);
+  auto grid = [](int n) { return dim3((n + 255) / 256); };
+  if (pl->tile8)
+    hipLaunchKernelGGL(hmme::me_prep_jobs_tile_kernel, grid(jobs), block, 0, s, (MeJob16*)ctx->d_jobs, ctx->d_first_strip,
                        (const int16_t*)d_pred_q, first, count, n_refs, cur->width, cur->height, fp->search_range);
-  else if (split8)
-    hipLaunchKernelGGL(hmme::me_prep_jobs_split_kernel, grid, block, 0, s, (MeJob16*)ctx->d_jobs, ctx->d_first_strip,
-                       (const int16_t*)d_pred_q, first, count, n_refs, cur->width, cur->height, fp->search_range, *n_strips);
-  else if (!wide)
-    hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, grid, block, 0, s, (MeJob*)ctx->d_jobs, (const int16_t*)d_pred_q, first, count,
-                       n_refs, cur->width, cur->height, fp->search_range);
-  else
-    hipLaunchKernelGGL(hmme::me_prep_jobs16_kernel, grid, block, 0, s, (MeJob16*)ctx->d_jobs, ctx->d_first_strip,
-                       (const int16_t*)d_pred_q, first, count, n_refs, cur->width, cur->height, fp->search_range, *n_strips, *strip_rows);
+  else if (wide)
+    hipLaunchKernelGGL(hmme::me_prep_jobs16_kernel, grid(jobs), block, 0, s, (MeJob16*)ctx->d_jobs, ctx->d_first_strip,
+                       (const int16_t*)d_pred_q, first, count, n_refs, cur->width, cur->height, fp->search_range, pl->n_strips, pl->strip_rows,
+                       pl->tail_first, pl->tail_parts);
+  else {
+    if (head)
+      hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, grid(head), block, 0, s, (MeJob*)ctx->d_jobs, (const int16_t*)d_pred_q, first, count,
+                         n_refs, cur->width, cur->height, fp->search_range, 0, head);
+    if (n_tail)
+      hipLaunchKernelGGL(hmme::me_prep_jobs_split_kernel, grid(n_tail), block, 0, s, (MeJob16*)((uint8_t*)ctx->d_jobs + pl->tail_jobs_off), ctx->d_first_strip,
+                         (const int16_t*)d_pred_q, first, count, n_refs, cur->width, cur->height, fp->search_range, pl->tail_parts, head, n_tail);
+  }
   HIP_TRY(ctx, hipGetLastError());
   return HMME_OK;
 }
 
-static int run_search(hmme_ctx* ctx, const hmme_plane* cur, const RefSet& refs, int ref_pitch, const hmme_frame_params* fp, int jobs,
-                      int n_strips, int pdw, int strip_rows, int16_t* d_mv, uint32_t* d_sad, hipStream_t s) {
-  if (fp->bit_depth == 8 && n_strips > 1)
-    return launch_search8_split(ctx, cur->origin(), cur->pitch, refs, ref_pitch, (const MeJob16*)ctx->d_jobs, ctx->d_first_strip, jobs,
-                                n_strips, fp->fen, d_mv, d_sad, s);
-  if (fp->bit_depth == 8)
-    return launch_search8(ctx, cur->origin(), cur->pitch, refs, ref_pitch, (const MeJob*)ctx->d_jobs, jobs, fp->fen, d_mv, d_sad, s);
-  return launch_search16(ctx, cur->origin(), cur->pitch, refs, ref_pitch, (const MeJob16*)ctx->d_jobs, ctx->d_first_strip, jobs, n_strips,
-                         pdw, strip_rows, fp->fen, fp->bit_depth, d_mv, d_sad, s);
+static int run_search(hmme_ctx* ctx, const hmme_plane* cur, const RefSet& refs, int ref_pitch, const hmme_frame_params* fp, const FramePlan& pl,
+                      int16_t* d_mv, uint32_t* d_sad, hipStream_t s) {
+  if (fp->bit_depth > 8)
+    return launch_search16(ctx, cur->origin(), cur->pitch, refs, ref_pitch, (const MeJob16*)ctx->d_jobs, ctx->d_first_strip, pl.jobs, pl.n_wg16,
+                           pl.pdw, pl.strip_rows, fp->fen, fp->bit_depth, d_mv, d_sad, s);
+  if (pl.tile8)
+    return launch_search8_split(ctx, cur->origin(), cur->pitch, refs, ref_pitch, (const MeJob16*)ctx->d_jobs, ctx->d_first_strip, pl.jobs, 4,
+                                fp->fen, d_mv, d_sad, s);
+  const int head = pl.tail_first, n_tail = pl.jobs - head;
+  int rc = launch_search8(ctx, cur->origin(), cur->pitch, refs, ref_pitch, (const MeJob*)ctx->d_jobs, head, fp->fen, d_mv, d_sad, s);
+  if (rc || !n_tail) return rc;
+  return launch_search8_split(ctx, cur->origin(), cur->pitch, refs, ref_pitch, (const MeJob16*)((const uint8_t*)ctx->d_jobs + pl.tail_jobs_off), ctx->d_first_strip,
+                              n_tail, pl.tail_parts, fp->fen, d_mv + (size_t)head * 2 * HMME_NUM_CTU_PARTS, d_sad + (size_t)head * HMME_NUM_CTU_PARTS, s);
 }
 
 int hmme_search_frame_multi_device(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* const* refs, int n_refs,
@@ -818,10 +883,10 @@ int hmme_search_frame_multi_device(hmme_ctx* ctx, const hmme_plane* cur, const h
   if (rc == HMME_OK) rc = plane_wait(ctx, cur, s);
   for (int r = 0; r < n_refs && rc == HMME_OK; ++r) rc = plane_wait(ctx, refs[r], s);
   if (rc) return rc;
-  int n_strips, pdw, strip_rows;
-  rc = prep_jobs(ctx, cur, fp, d_pred_q, first, count, n_refs, s, &n_strips, &pdw, &strip_rows);
+  FramePlan plan;
+  rc = prep_jobs(ctx, cur, fp, d_pred_q, first, count, n_refs, s, &plan);
   if (rc) return rc;
-  rc = run_search(ctx, cur, set, refs[0]->pitch, fp, count * n_refs, n_strips, pdw, strip_rows, (int16_t*)d_out_mv, (uint32_t*)d_out_sad, s);
+  rc = run_search(ctx, cur, set, refs[0]->pitch, fp, plan, (int16_t*)d_out_mv, (uint32_t*)d_out_sad, s);
   if (rc) return rc;
   return scratch_release(ctx, s);
 }
@@ -930,7 +995,7 @@ int hmme_refine_frame_multi_device(hmme_ctx* ctx, const hmme_plane* cur, const h
   for (int r = 0; r < n_refs && rc == HMME_OK; ++r) rc = plane_wait(ctx, refs[r], s);
   if (rc) return rc;
   hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, dim3((jobs + 255) / 256), dim3(256), 0, s, (MeJob*)ctx->d_jobs, (const int16_t*)d_pred_q,
-                     first, count, n_refs, cur->width, cur->height, fp->search_range);
+                     first, count, n_refs, cur->width, cur->height, fp->search_range, 0, jobs);
   HIP_TRY(ctx, hipGetLastError());
   const int had = use_hadamard ? 1 : 0, wide = cur->bps == 2 ? 1 : 0;
   using frac_fn = void (*)(const uint8_t*, int, const RefSet, int, const MeJob*, const uint16_t*, const int16_t*, uint32_t, int, int16_t*,
@@ -989,8 +1054,8 @@ int hmme_time_search_kernel(hmme_ctx* ctx, const hmme_plane* cur, const hmme_pla
   if (rc == HMME_OK) rc = plane_wait(ctx, ref, s);
   if (rc) return rc;
   // job table once (it is not part of the timed kernel), then `reps` launches of the search kernel(s) alone
-  int n_strips, pdw, strip_rows;
-  rc = prep_jobs(ctx, cur, fp, d_pred_q, first, count, 1, s, &n_strips, &pdw, &strip_rows);
+  FramePlan plan;
+  rc = prep_jobs(ctx, cur, fp, d_pred_q, first, count, 1, s, &plan);
   if (rc) return rc;
   const RefSet set = one_ref(ref->origin());
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -999,7 +1064,7 @@ int hmme_time_search_kernel(hmme_ctx* ctx, const hmme_plane* cur, const hmme_pla
   float ms = 0.f;
   hipError_t e = hipEventRecord(e0, s);
   for (int i = 0; i < reps && rc == HMME_OK && e == hipSuccess; ++i)
-    rc = run_search(ctx, cur, set, ref->pitch, fp, count, n_strips, pdw, strip_rows, (int16_t*)d_out_mv, (uint32_t*)d_out_sad, s);
+    rc = run_search(ctx, cur, set, ref->pitch, fp, plan, (int16_t*)d_out_mv, (uint32_t*)d_out_sad, s);
   if (rc == HMME_OK && e == hipSuccess) e = hipEventRecord(e1, s);
   if (rc == HMME_OK && e == hipSuccess) e = hipEventSynchronize(e1);
   if (rc == HMME_OK && e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);

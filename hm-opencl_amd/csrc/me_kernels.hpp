@@ -278,7 +278,6 @@ me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefS
                  uint32_t* __restrict__ out_sad, unsigned long long* __restrict__ g_best) {
   __shared__ uint32_t win[kWinRowsMax * kPDW];
   __shared__ unsigned long long best64[kParts];
-  __shared__ uint2 curl[64 * 8];   // the 64x64 current block; read wave-uniformly by the leaves
   __shared__ int task_ctr;
 
   const int tid = threadIdx.x;
@@ -300,12 +299,12 @@ me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefS
   for (int s = tid; s < kParts; s += kThreads) best64[s] = ~0ull;
   if (tid == 0) task_ctr = t_first;
 
-  // -- 0. current block -> LDS (one 16-byte load per thread)
-  {
-    const int r = tid >> 2, q = tid & 3;
-    const uint4 v = *(const uint4*)(cur_base + (long)(job.ctu_y + r) * cur_pitch + job.ctu_x + 16 * q);
-    *(uint4*)&curl[r * 8 + 2 * q] = v;
-  }
+  // -- 0. the current block is read through the scalar cache straight into SGPRs (v_qsad_pk_u16_u8 takes its 4 current-block bytes
+  //       from one): no LDS copy, no wave-uniform ds_read_b64 (each cost a full LDS slot), 35 VGPRs fewer
+  const uintptr_t cur_addr = (uintptr_t)(cur_base + (long)job.ctu_y * cur_pitch + job.ctu_x);
+  const uint64_t curc = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)cur_addr) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(cur_addr >> 32)) << 32;
+  const uint32_t cur_pitch_s = (uint32_t)__builtin_amdgcn_readfirstlane(cur_pitch);
   // -- 1. stage the reference window: LDS row r, byte b  <->  ref(ctu_x + lt_x + b, ctu_y + lt_y + r)
   {
     const uint8_t* src = ref_base + (long)(job.ctu_y + job.lt_y) * ref_pitch + (job.ctu_x + job.lt_x);
@@ -390,7 +389,20 @@ me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefS
       const uint32_t nc0 = 0u - c0, nc1 = 0u - c1, nc2 = 0u - c2, nc3 = 0u - c3;
       // lanes outside the window still run (wave-uniform code) on clamped, in-bounds addresses
       const lds_char_t* lpc = (const lds_char_t*)(win + min(cy, wy - 1) * kPDW + (min(cx, wx - 1) >> 2));
-      const lds_vu64_t* curv = (const lds_vu64_t*)curl;
+      // scalar loads complete out of order: ME8_CUR_WAIT (placed by the generator one CU after the loads, before the next CU's are
+      // issued) waits for the batch; the window dwords of the same batch are named first so that the compiler's LDS wait lands there
+#define ME8_CUR(row, q)                                                                                                            \
+  ({                                                                                                                               \
+    uint64_t w_;                                                                                                                   \
+    uint32_t o_;                                                                                                                   \
+    asm volatile("s_mul_i32 %1, %3, %4\n\ts_load_dwordx2 %0, %2, %1 offset:%5"                                                     \
+                 : "=s"(w_), "=&s"(o_) : "s"(curc), "s"(cur_pitch_s), "n"(row), "n"(8 * (q)));                                      \
+    w_;                                                                                                                            \
+  })
+#define ME8_CUR_WAIT(w0, w1, w2, w3, w4, w5, w6, w7, d0, d1, d2, d3, d4, d5, d6, d7, d8, d9, d10, d11, d12, d13, d14, d15)           \
+  asm volatile("" : : "v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(d4), "v"(d5), "v"(d6), "v"(d7), "v"(d8), "v"(d9), "v"(d10), "v"(d11),  \
+               "v"(d12), "v"(d13), "v"(d14), "v"(d15));                                                                             \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3), "+s"(w4), "+s"(w5), "+s"(w6), "+s"(w7))
       if constexpr (FEN) {
 #include "me_tree_fen1.inc"
       } else {
@@ -462,10 +474,12 @@ __host__ __device__ inline void set_search_range(int pred_x, int pred_y, int sr,
 
 // one job per CTU of the picture from the per-CTU predictors
 // job i = reference (i / ctu_count), CTU ctu_first + (i % ctu_count); pred_q is [n_refs][n_ctu][2]
+// jobs [job0, job0 + n_jobs) of the ctu_count * n_refs (CTU, reference) searches of a launch; jobs[] is indexed from job0
 __global__ void me_prep_jobs_kernel(MeJob* jobs, const int16_t* __restrict__ pred_q, int ctu_first, int ctu_count,
-                                    int n_refs, int pic_w, int pic_h, int sr) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ctu_count * n_refs) return;
+                                    int n_refs, int pic_w, int pic_h, int sr, int job0, int n_jobs) {
+  const int li = blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= n_jobs) return;
+  const int i = job0 + li;
   const int r = i / ctu_count;
   const int ctus_x = (pic_w + 63) >> 6, n_ctu = ctus_x * ((pic_h + 63) >> 6);
   const int ctu = ctu_first + (i - r * ctu_count);
@@ -478,7 +492,7 @@ __global__ void me_prep_jobs_kernel(MeJob* jobs, const int16_t* __restrict__ pre
   j.ctu_x = (int16_t)(cu_x | r); j.ctu_y = (int16_t)cu_y;
   j.lt_x = (int16_t)ltx; j.lt_y = (int16_t)lty; j.rb_x = (int16_t)rbx; j.rb_y = (int16_t)rby;
   j.pred_x = (int16_t)px; j.pred_y = (int16_t)py;
-  jobs[i] = j;
+  jobs[li] = j;
 }
 
 // picture area (int16 Pel, u16 or u8; pitch in elements) -> padded u8 / u16 plane, borders edge-replicated like
@@ -528,6 +542,9 @@ __device__ __forceinline__ uint32_t me_keymin3(uint32_t s0, uint32_t s1, uint32_
                : "=&v"(r), "=&v"(t), "=&v"(u) : "v"(s0), "v"(s1), "v"(s2), "s"(mask), "s"(lsh), "v"(c0), "v"(c1), "v"(c2));
   return r;
 }
+
+#define ME16_KEYMIN_A(s0, s1, s2) me_keymin3(s0, s1, s2, mask_a, lsh_a, c0, c1, c2)
+#define ME16_KEYMIN_E(s0, s1, s2) me_keymin3(s0, s1, s2, mask_e, lsh_e, c0, c1, c2)
 
 template <int FEN, int PDW>
 __global__ void __launch_bounds__(kThreads16, 2)
@@ -699,8 +716,11 @@ __global__ void me_publish_kernel(volatile uint32_t* done_flag, uint32_t seq) {
   __threadfence_system();
 }
 
+// jobs [0, tail_first) are cut into n_strips strips, jobs from tail_first on into tail_strips (the last, partial round of
+// workgroups of a launch is dealt in finer pieces, hmme.hip plan_tail)
 __global__ void me_prep_jobs16_kernel(MeJob16* jobs, int* first_strip_of_job, const int16_t* __restrict__ pred_q,
-                                      int ctu_first, int ctu_count, int n_refs, int pic_w, int pic_h, int sr, int n_strips, int rows_max) {
+                                      int ctu_first, int ctu_count, int n_refs, int pic_w, int pic_h, int sr, int n_strips_head, int rows_max,
+                                      int tail_first, int tail_strips) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ctu_count * n_refs) return;
   const int r = i / ctu_count;
@@ -716,10 +736,14 @@ __global__ void me_prep_jobs16_kernel(MeJob16* jobs, int* first_strip_of_job, co
   j.lt_x = (int16_t)ltx; j.lt_y = (int16_t)lty; j.rb_x = (int16_t)rbx; j.rb_y = (int16_t)rby;
   j.pred_x = (int16_t)px; j.pred_y = (int16_t)py;
   const int wy = rby - lty + 1;
-  first_strip_of_job[i] = i * n_strips;
+  const int n_strips = i < tail_first ? n_strips_head : tail_strips;
+  const int base = i < tail_first ? i * n_strips_head : tail_first * n_strips_head + (i - tail_first) * tail_strips;
+  first_strip_of_job[i] = base;
   // strips of the height me_strip_rows16 picks for this window, the last one takes the rest; strips beyond the window (clipped
   // windows need fewer) are empty: y0 == y1
-  const int h = me_strip_rows16(rbx - ltx + 1, wy, rows_max, n_strips);
+  // head jobs: the planner's choice within n_strips; tail jobs: exactly tail_strips equal pieces (the host chose that number for
+  // the sake of the launch's last round, not for this window)
+  const int h = i < tail_first ? me_strip_rows16(rbx - ltx + 1, wy, rows_max, n_strips) : max(1, (wy + n_strips - 1) / n_strips);
   const int xcd_period = (n_strips & 1) ? 8 : (n_strips & 2) ? 4 : (n_strips & 4) ? 2 : 1;
   for (int s = 0; s < n_strips; ++s) {
     MeJob16 js;
@@ -731,15 +755,17 @@ __global__ void me_prep_jobs16_kernel(MeJob16* jobs, int* first_strip_of_job, co
     // not land on a fixed XCD (with two strips per CTU every tall strip sat on an even XCD and the launch took as long as if all
     // strips were tall).  The XCD of a job's first workgroup repeats every 8 / gcd(n_strips, 8) jobs: the strip order rotates by
     // one each time it does, which deals every height to every XCD.
-    jobs[i * n_strips + (s + i / xcd_period) % n_strips] = js;
+    jobs[base + (s + i / xcd_period) % n_strips] = js;
   }
 }
 
 // 8-bit split mode: each CTU's tasks are dealt to n_split workgroups (4 tasks = one per wave is the useful minimum)
 __global__ void me_prep_jobs_split_kernel(MeJob16* jobs, int* first_strip_of_job, const int16_t* __restrict__ pred_q,
-                                      int ctu_first, int ctu_count, int n_refs, int pic_w, int pic_h, int sr, int n_split) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ctu_count * n_refs) return;
+                                      int ctu_first, int ctu_count, int n_refs, int pic_w, int pic_h, int sr, int n_split,
+                                      int job0, int n_jobs) {
+  const int li = blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= n_jobs) return;
+  const int i = job0 + li;              // which (CTU, reference); jobs[], first_strip_of_job[] and MeJob16::job count from job0
   const int r = i / ctu_count;
   const int ctus_x = (pic_w + 63) >> 6, n_ctu = ctus_x * ((pic_h + 63) >> 6);
   const int ctu = ctu_first + (i - r * ctu_count);
@@ -753,14 +779,14 @@ __global__ void me_prep_jobs_split_kernel(MeJob16* jobs, int* first_strip_of_job
   j.lt_x = (int16_t)ltx; j.lt_y = (int16_t)lty; j.rb_x = (int16_t)rbx; j.rb_y = (int16_t)rby;
   j.pred_x = (int16_t)px; j.pred_y = (int16_t)py;
   const int nt = me_num_tasks(rbx - ltx + 1, rby - lty + 1);
-  first_strip_of_job[i] = i * n_split;
+  first_strip_of_job[li] = li * n_split;
   for (int s = 0; s < n_split; ++s) {
     MeJob16 js;
     js.j = j;
     js.y0 = (int16_t)((long)nt * s / n_split);
     js.y1 = (int16_t)((long)nt * (s + 1) / n_split);
-    js.job = i;
-    jobs[i * n_split + s] = js;
+    js.job = li;
+    jobs[li * n_split + s] = js;
   }
 }
 

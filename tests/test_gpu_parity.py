@@ -1001,3 +1001,37 @@ def test_calls_of_one_context_spread_over_streams(engine, oracle_lib):
             got_mv, got_sad = d_mv[k].cpu().numpy(), d_sad[k].cpu().numpy().astype(np.uint32)
             assert np.array_equal(got_mv[:, :, 0], want[k][0]) and np.array_equal(got_mv[:, :, 1], want[k][1]) and np.array_equal(got_sad, want[k][2]), it
             assert np.abs(d_q.cpu().numpy().astype(np.int32) - 4 * got_mv.astype(np.int32)).max() <= 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bd,sr,refs", [(8, 64, 1), (8, 16, 2), (10, 32, 1), (10, 64, 1)])
+def test_tail_plan_pictures_whose_searches_do_not_fill_whole_rounds(engine, oracle_lib, bd, sr, refs):
+    """1920x1200 is 570 CTU searches: one full round of 512 workgroups and a tail of 58, which the frame plan (hmme.hip FramePlan)
+    deals in finer pieces -- 8-bit: a second launch through the split kernel with its own job numbering and output offset; 16-bit:
+    more strips for the tail jobs inside the same launch; two references: 1 140 jobs, the tail crosses the reference boundary.
+    Head and tail tables against the oracle on the CTU rows either side of job 512, the first row and the last"""
+    from hmme import api, synth
+    w, h = 1920, 1200
+    cur, ref, _ = synth.make_pair(w, h, seed=1200 + bd + sr, bit_depth=bd, max_mv=min(sr, 24), region=128, noise_sigma=1.0)
+    m = synth.MARGIN
+    ref2 = np.pad(np.roll(ref[m:m + h, m:m + w], (3, -5), axis=(0, 1)), m, mode="edge")   # a second reference, borders extended like the first
+    ctus_x, ctus_y = 30, 19
+    n_ctu = ctus_x * ctus_y
+    pred = synth.random_predictors(n_ctu * refs, seed=77, max_pel=12).reshape(refs, n_ctu, 2)
+    engine.set_lambda(91.3)
+    lq = engine.lambda_q16
+    with engine.plane(w, h, bd) as pc, engine.plane(w, h, bd) as pr, engine.plane(w, h, bd) as pr2:
+        pc.upload_pel(cur, (m, m)); pr.upload_pel(ref, (m, m)); pr2.upload_pel(ref2, (m, m))
+        if refs == 1:
+            mv, sad = engine.search_frame(pc, pr, sr, pred[0])
+            mv, sad = mv[None], sad[None]
+        else:
+            mv, sad = engine.search_frame_multi(pc, [pr, pr2], sr, pred)
+    assert mv.shape == (refs, n_ctu, 593, 2)
+    planes = [ref, ref2]
+    for r in range(refs):
+        for row in (0, 16, 17, 18):
+            ox, oy, osad = oracle_lib.search_frame(cur, planes[r], (m, m), w, h, sr, pred[r], lq, 1, bd, ctu_first=row * ctus_x, ctu_count=ctus_x,
+                                                   n_threads=16)
+            sl = slice(row * ctus_x, (row + 1) * ctus_x)
+            assert np.array_equal(mv[r, sl, :, 0], ox) and np.array_equal(mv[r, sl, :, 1], oy) and np.array_equal(sad[r, sl], osad), (r, row)

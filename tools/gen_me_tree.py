@@ -105,7 +105,7 @@ class Tree:
         return self.loaded[key]
 
     def curld(self, row, cx8):
-        """the 8 current-block bytes of `row` that belong to 8x8 CU column cx8 (wave-uniform LDS read)"""
+        """the 8 current-block bytes of `row` that belong to 8x8 CU column cx8 (scalar load into an SGPR pair)"""
         key = ("cur", row, cx8)
         if key not in self.loaded:
             v = self.new("w")
@@ -211,9 +211,13 @@ class Tree:
 
     def _assemble(self):
         """software prefetch: the loads of CU n+1 are issued at the top of CU n's arithmetic"""
+        def arrived(loads):
+            """the loads of the CU about to be consumed (issued one CU earlier); see Tree16._assemble"""
+            return ("CURWAIT8", [o[1] for o in loads if o[0] == "CURLD"], [o[1] for o in loads if o[0] == "LDS"])
         ops = list(self.cu_loads[0])
         for o in self.ops:
             if o[0] == "LOADS_FOR":
+                ops.append(arrived(self.cu_loads[o[1] - 1]))       # marker n+1 sits at the top of CU n
                 if o[1] < len(self.cu_loads):
                     ops.extend(self.cu_loads[o[1]])
             elif o[0] != "MID":
@@ -462,8 +466,8 @@ class Tree16(Tree):
 # =====================================================================================================
 HEADER = """// GENERATED by tools/gen_me_tree.py -- do not edit.  One lane-iteration of the full-search
 // reduction tree (fen=%d): 256 4x4 leaves -> 593 PU keys -> wave butterfly -> best[0..9].
-// Expects in scope: lpc (per-lane LDS byte pointer at the candidate's window row), curv (volatile
-// LDS copy of the 64x64 current block as uint64[64][8]; volatile = loads stay where the generator put them), c0..c3, nc0..nc3, b0..b9 (running minima), lane role
+// Expects in scope: lpc (per-lane LDS byte pointer at the candidate's window row), ME8_CUR(row, q) (scalar load of 8 current-block
+// bytes) and ME8_CUR_WAIT (the CU's loads have arrived), c0..c3, nc0..nc3, b0..b9 (running minima), lane role
 // masks rb3, rb2, rb1, rb0, and the ME_* helpers of me_kernel.hip.
 """
 
@@ -472,7 +476,7 @@ HEADER16 = """// GENERATED by tools/gen_me_tree.py -- do not edit.  One lane-ite
 // (fen=%d): three candidates (x, x+2, x+4) per lane, exact 32-bit sums, v_sad_u16 leaves.
 // Expects in scope: lpd (per-lane LDS byte pointer at the first candidate, window row 0; 4-byte aligned), ME16_PDW (window pitch in
 // dwords), ME16_CUR(row, q) (scalar load of 8 current-block samples) and ME16_CUR_WAIT (the batch has arrived), c0, c1, c2,
-// mask_a/lsh_a/mask_e/lsh_e, b0..b9, rb1, rb0, me_keymin3 and the me_merge* helpers.
+// b0..b9, rb1, rb0, the key macros ME16_KEYMIN_A / ME16_KEYMIN_E (all-rows / even-rows family) and the me_merge* helpers.
 """
 
 
@@ -570,7 +574,9 @@ def emit_cpp(tree, path, header=None):
             o.append(f"const uint64_t {v} = *(const lds_vu64a4_t*)({b} + {off * 4});")
         elif t == "CURLD":
             _, v, row, cx8 = op
-            o.append(f"const uint64_t {v} = curv[{row * 8 + cx8}];")
+            o.append(f"uint64_t {v} = ME8_CUR({row}, {cx8});")
+        elif t == "CURWAIT8":
+            o.append(f"ME8_CUR_WAIT({', '.join(op[1])}, {', '.join(op[2])});")
         elif t == "QSAD":
             _, v, pair, cw, half, row, bx, acc = op
             o.append(f"const uint64_t {v} = ME_QSAD({pair}, (uint32_t)({cw}{' >> 32' if half else ''}), {acc if acc else '0ull'});")
@@ -614,7 +620,7 @@ def emit_cpp(tree, path, header=None):
             o.append("const uint32_t " + ", ".join(f"{op[1]}_{j} = {op[2]}_{j} - {op[3]}_{j}" for j in range(tree.nc)) + ";")
         elif t == "KEYMINN":
             f_ = "e" if op[3] == "E" else "a"
-            o.append(f"const uint32_t {op[1]} = me_keymin3({op[2]}_0, {op[2]}_1, {op[2]}_2, mask_{f_}, lsh_{f_}, c0, c1, c2);")
+            o.append(f"const uint32_t {op[1]} = ME16_KEYMIN_{f_.upper()}({op[2]}_0, {op[2]}_1, {op[2]}_2);")
         elif t == "CURLD16":
             o.append(f"u32x4_t {op[1]} = ME16_CUR({op[2]}, {op[3]});")
         elif t == "CURWAIT":
@@ -737,7 +743,7 @@ def simulate(tree, window, cur, lane_off, c, best):
         t = op[0]
         if t == "LDS":
             val[op[1]] = np.concatenate([bytes_at(op[2], op[3]), bytes_at(op[2], op[3] + 1)], axis=1)   # (64, 8) bytes
-        elif t in ("CURLD", "BASE"):
+        elif t in ("CURLD", "BASE", "CURWAIT8"):
             pass
         elif t == "QSAD":
             _, v, pair, cw, half, row, bx, acc = op
