@@ -240,6 +240,21 @@ __host__ __device__ inline int me_strip_rows16(int wx, int wy, int rows_max, int
   return best_h;
 }
 
+// Pulls the 64 rows of a workgroup's current block (LINES 64-byte lines each) into the scalar cache while the window is being staged:
+// the first lane-iteration would otherwise meet every line cold, one CU at a time -- visible where a workgroup runs only a few
+// iterations (the per-CTU call: 64 workgroups per search).  One wave issues the loads; nothing reads the results.
+template <int LINES>
+__device__ __forceinline__ void me_prefetch_cur(uint64_t curc, uint32_t pitch) {
+#pragma unroll
+  for (int r = 0; r < 64; ++r)
+#pragma unroll
+    for (int l = 0; l < LINES; ++l) {
+      uint32_t d, o;
+      asm volatile("s_mul_i32 %1, %3, %4\n\ts_load_dword %0, %2, %1 offset:%5" : "=s"(d), "=&s"(o) : "s"(curc), "s"(pitch), "n"(r), "n"(64 * l));
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)");
+}
+
 // Window staging shared by the search kernels: LDS dword i = window row i / PDW, dword i % PDW, realigned by `mis` bytes.  Eight
 // loads are in flight per thread before the first one is waited for: the straightforward loop (load, wait, store) cost one memory
 // round trip per 256 dwords -- 37 of them for a 129 x 129 window, ~4 % of a workgroup's lifetime, 63 per pass and strip (12 %) in
@@ -305,6 +320,7 @@ me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefS
   const uint64_t curc = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)cur_addr) |
                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(cur_addr >> 32)) << 32;
   const uint32_t cur_pitch_s = (uint32_t)__builtin_amdgcn_readfirstlane(cur_pitch);
+  if (tid < 64) me_prefetch_cur<1>(curc, cur_pitch_s);
   // -- 1. stage the reference window: LDS row r, byte b  <->  ref(ctu_x + lt_x + b, ctu_y + lt_y + r)
   {
     const uint8_t* src = ref_base + (long)(job.ctu_y + job.lt_y) * ref_pitch + (job.ctu_x + job.lt_x);
@@ -579,6 +595,7 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const Re
   const uint64_t curc = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)cur_addr) |
                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(cur_addr >> 32)) << 32;
   const uint32_t cur_pitch_s = (uint32_t)__builtin_amdgcn_readfirstlane(cur_pitch);
+  if (tid < 64) me_prefetch_cur<2>(curc, cur_pitch_s);
 #define ME16_CUR(row, q)                                                                                                           \
   ({                                                                                                                               \
     u32x4_t w_;                                                                                                                    \
