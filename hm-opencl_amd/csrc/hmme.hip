@@ -857,10 +857,12 @@ static int run_search(hmme_ctx* ctx, const hmme_plane* cur, const RefSet& refs, 
     return launch_search8_split(ctx, cur->origin(), cur->pitch, refs, ref_pitch, (const MeJob16*)ctx->d_jobs, ctx->d_first_strip, pl.jobs, 4,
                                 fp->fen, d_mv, d_sad, s);
   const int head = pl.tail_first, n_tail = pl.jobs - head;
-  int rc = launch_search8(ctx, cur->origin(), cur->pitch, refs, ref_pitch, (const MeJob*)ctx->d_jobs, head, fp->fen, d_mv, d_sad, s);
+  unsigned long long* best = nullptr;
+  int rc = n_tail ? merge_table(ctx, n_tail, nullptr, s, &best) : HMME_OK;   // the tail's merge table is preset before the head runs, not between the two
+  if (rc == HMME_OK) rc = launch_search8(ctx, cur->origin(), cur->pitch, refs, ref_pitch, (const MeJob*)ctx->d_jobs, head, fp->fen, d_mv, d_sad, s);
   if (rc || !n_tail) return rc;
   return launch_search8_split(ctx, cur->origin(), cur->pitch, refs, ref_pitch, (const MeJob16*)((const uint8_t*)ctx->d_jobs + pl.tail_jobs_off), ctx->d_first_strip,
-                              n_tail, pl.tail_parts, fp->fen, d_mv + (size_t)head * 2 * HMME_NUM_CTU_PARTS, d_sad + (size_t)head * HMME_NUM_CTU_PARTS, s);
+                              n_tail, pl.tail_parts, fp->fen, d_mv + (size_t)head * 2 * HMME_NUM_CTU_PARTS, d_sad + (size_t)head * HMME_NUM_CTU_PARTS, s, best);
 }
 
 int hmme_search_frame_multi_device(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* const* refs, int n_refs,

@@ -1004,7 +1004,7 @@ def test_calls_of_one_context_spread_over_streams(engine, oracle_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("bd,sr,refs", [(8, 64, 1), (8, 16, 2), (10, 32, 1), (10, 64, 1)])
+@pytest.mark.parametrize("bd,sr,refs", [(8, 64, 1), (8, 16, 2), (10, 32, 1), (10, 64, 1), (10, 128, 1), (10, 24, 2)])
 def test_tail_plan_pictures_whose_searches_do_not_fill_whole_rounds(engine, oracle_lib, bd, sr, refs):
     """1920x1200 is 570 CTU searches: one full round of 512 workgroups and a tail of 58, which the frame plan (hmme.hip FramePlan)
     deals in finer pieces -- 8-bit: a second launch through the split kernel with its own job numbering and output offset; 16-bit:
