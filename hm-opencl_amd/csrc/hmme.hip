@@ -39,7 +39,15 @@ constexpr size_t kResMv = 0, kResSad = 4 * HMME_NUM_CTU_PARTS, kResDone = 8 * HM
 const size_t kLdsBudget16 = std::getenv("HMME_LDS_BUDGET16") ? (size_t)std::atol(std::getenv("HMME_LDS_BUDGET16")) : 78 * 1024;
 // 16-bit window pitch in dwords for windows up to 129 / 257 candidates wide (row = (wx + 63 + 1) samples / 2, + 34 dwords the
 // last lane of a row reaches beyond its first candidate)
-constexpr int kPdw16Small = 130, kPdw16Large = 162;
+// LDS window pitch of the 16-bit kernel in dwords, for windows up to 129 / 257 candidates wide.  A lane reads dwords
+// 3 * (lane in row) + 0..33 of its row, so 97 / 160 would do; the pitch decides which banks the rows of one wave-wide read share
+// (64 lanes cover 1.5 .. 3 window rows).  Measured (profiles/r02Y_pdw_sweep.txt, GSAD/s at 2160p 10-bit): SR 128 -- 160: 1 782,
+// 161: 1 812, 162: 1 780, 163: 1 777, 164..170: 1 698..1 724; SR 64 -- 130: 1 687, 98: 1 693, 97..106 otherwise: 1 630..1 651.
+#ifndef ME16_PDW_SMALL
+#define ME16_PDW_SMALL 130
+#define ME16_PDW_LARGE 161
+#endif
+constexpr int kPdw16Small = ME16_PDW_SMALL, kPdw16Large = ME16_PDW_LARGE;
 thread_local std::string g_create_error;   // hmme_last_error(NULL): per host thread, like the contexts themselves
 }  // namespace
 
