@@ -1035,3 +1035,38 @@ def test_tail_plan_pictures_whose_searches_do_not_fill_whole_rounds(engine, orac
                                                    n_threads=16)
             sl = slice(row * ctus_x, (row + 1) * ctus_x)
             assert np.array_equal(mv[r, sl, :, 0], ox) and np.array_equal(mv[r, sl, :, 1], oy) and np.array_equal(sad[r, sl], osad), (r, row)
+
+
+def test_fuzz_pictures_with_a_tail_vs_oracle(engine, oracle_lib):
+    """random pictures of 300..1 300 CTUs (more than one round of 512 workgroups, or nearly one): head and tail of the frame plan,
+    8- and 10/12-bit, one or two references, small search ranges so that the oracle checks EVERY CTU in seconds"""
+    from hmme import api, synth
+    n_cases = int(os.environ.get("HMME_FUZZ_BIG", "3"))
+    base = int(os.environ.get("HMME_FUZZ_SEED", "1000"))
+    for case in range(n_cases):
+        rng = np.random.default_rng(base + 7919 * case)
+        while True:
+            w, h = 8 * int(rng.integers(100, 400)), 8 * int(rng.integers(60, 220))
+            n = api.load().hmme_num_ctus(w, h)
+            if 300 <= n <= 1300:
+                break
+        bd = int(rng.choice([8, 8, 10, 12]))
+        sr = int(rng.choice([3, 8, 12, 16]))
+        refs = int(rng.choice([1, 1, 2]))
+        fen = int(rng.integers(0, 2))
+        cur, ref, _ = synth.make_pair(w, h, seed=base + case, bit_depth=bd, max_mv=min(sr, 10), region=64, noise_sigma=1.0)
+        m = synth.MARGIN
+        ref2 = np.pad(np.roll(ref[m:m + h, m:m + w], (-2, 4), axis=(0, 1)), m, mode="edge")
+        pred = synth.random_predictors(n * refs, seed=base + case, max_pel=int(rng.choice([0, 6, 60]))).reshape(refs, n, 2)
+        engine.set_lambda(float(rng.choice([3.3, 57.9, 400.0])))
+        with engine.plane(w, h, bd) as pc, engine.plane(w, h, bd) as pr, engine.plane(w, h, bd) as pr2:
+            pc.upload_pel(cur, (m, m)); pr.upload_pel(ref, (m, m)); pr2.upload_pel(ref2, (m, m))
+            if refs == 1:
+                mv, sad = engine.search_frame(pc, pr, sr, pred[0], fen=fen)
+                mv, sad = mv[None], sad[None]
+            else:
+                mv, sad = engine.search_frame_multi(pc, [pr, pr2], sr, pred, fen=fen)
+        tag = dict(case=case, w=w, h=h, n=n, bd=bd, sr=sr, refs=refs, fen=fen)
+        for r in range(refs):
+            ox, oy, osad = oracle_lib.search_frame(cur, (ref, ref2)[r], (m, m), w, h, sr, pred[r], engine.lambda_q16, fen, bd, n_threads=16)
+            assert np.array_equal(mv[r, :, :, 0], ox) and np.array_equal(mv[r, :, :, 1], oy) and np.array_equal(sad[r], osad), (tag, r)
