@@ -171,7 +171,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--size", default="2160p", choices=sorted(SIZES))
+    ap.add_argument("--size", default="2160p", help="one of %s, or WIDTHxHEIGHT (multiples of 8)" % ", ".join(sorted(SIZES)))
     ap.add_argument("--search-range", type=int, default=64)
     ap.add_argument("--bit-depth", type=int, default=8, help="8 = headline config; 10 + --search-range 128 = BASELINE config 5")
     ap.add_argument("--refs", type=int, default=1, help="reference pictures searched per step in one launch (lowdelay_P uses 4)")
@@ -207,7 +207,15 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    w, h = SIZES[args.size]
+    if args.size in SIZES:
+        w, h = SIZES[args.size]
+    else:
+        try:
+            w, h = (int(v) for v in args.size.lower().split("x"))
+        except ValueError:
+            ap.error("--size: %s, or WIDTHxHEIGHT" % ", ".join(sorted(SIZES)))
+        if w < 64 or h < 64 or w % 8 or h % 8:
+            ap.error("--size: width and height must be multiples of 8, at least 64")
     sr = args.search_range
     bd = args.bit_depth
     eng = api.Engine(local_rank, 128)
