@@ -49,16 +49,11 @@ def work_4x4_sads(api, w, h, sr):
     return total
 
 
-def kernel_source_hash():
-    """sha256 over the sources libhmme.so is built from: ties a committed counter summary to the binary that was profiled"""
-    import hashlib
-    csrc = os.path.join(ROOT, "hm-opencl_amd", "csrc")
-    h = hashlib.sha256()
-    for name in ("hmme.hip", "me_kernels.hpp", "me_slotmap.inc", "me_tree_fen0.inc", "me_tree_fen1.inc", "me_tree16_fen0.inc",
-                 "me_tree16_fen1.inc"):
-        with open(os.path.join(csrc, name), "rb") as f:
-            h.update(f.read())
-    return h.hexdigest()[:16]
+def library_build_id():
+    """hmme_build_id() of the library that is actually LOADED (HMME_LIB variants included): a hash over the kernel sources and the
+    flags that shape them, compiled into libhmme.so -- ties a committed counter summary to the binary that was profiled"""
+    from hmme import api
+    return api.build_id()
 
 
 def profile_label(size, sr, bd):
@@ -73,7 +68,7 @@ def pmc_profile(size, sr, bd):
         d = json.load(open(os.path.join(ROOT, "profiles", f"latest_pmc_{profile_label(size, sr, bd)}.json")))
     except (OSError, ValueError):
         return {}
-    if d.get("kernel_source_hash") != kernel_source_hash():
+    if d.get("library_build_id") != library_build_id():
         return {"stale": True}
     return d
 
@@ -175,6 +170,8 @@ def main():
     ap.add_argument("--search-range", type=int, default=64)
     ap.add_argument("--bit-depth", type=int, default=8, help="8 = headline config; 10 + --search-range 128 = BASELINE config 5")
     ap.add_argument("--refs", type=int, default=1, help="reference pictures searched per step in one launch (lowdelay_P uses 4)")
+    ap.add_argument("--pairs", type=int, default=1, help="DIFFERENT (current, reference) picture pairs searched per step in one launch "
+                    "(hmme_search_pairs_device: what an open-loop pass over a sequence of small pictures does); excludes --refs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-gpu: rehearse the N > 1 code path on a one-GPU box (not a measurement)")
@@ -226,11 +223,18 @@ def main():
     pc, pr = eng.plane(w, h, bd), eng.plane(w, h, bd)
     pc.upload_pel(cur, (synth.MARGIN, synth.MARGIN))
     pr.upload_pel(ref, (synth.MARGIN, synth.MARGIN))
-    n_refs = max(1, args.refs)
+    n_pairs = max(1, args.pairs)
+    if n_pairs > 1 and args.refs > 1:
+        raise SystemExit("bench.py: --pairs and --refs exclude each other")
+    n_refs = max(1, args.refs) if n_pairs == 1 else n_pairs      # searches per CTU position and launch
     ref_planes = [pr] + [eng.plane(w, h, bd) for _ in range(n_refs - 1)]
+    cur_planes = [pc] * n_refs
     for i, pl in enumerate(ref_planes[1:]):
-        _, r2, _ = synth.make_pair(w, h, seed=5000 + 17 * i + rank, bit_depth=bd)
+        c2, r2, _ = synth.make_pair(w, h, seed=5000 + 17 * i + rank, bit_depth=bd)
         pl.upload_pel(r2, (synth.MARGIN, synth.MARGIN))
+        if n_pairs > 1:      # a current picture of its own
+            cur_planes[i + 1] = eng.plane(w, h, bd)
+            cur_planes[i + 1].upload_pel(c2, (synth.MARGIN, synth.MARGIN))
     n_ctu = api.load().hmme_num_ctus(w, h)
     fp = api.FrameParams(sr, 1, bd, 0, n_ctu)
     # one picture pair per rank and step.  Results of step k land in buffer k % 2 ([2, n_refs, n_ctu, 593] int32: TComMv
@@ -245,14 +249,14 @@ def main():
         ev = events[k - n_untimed] if k >= n_untimed else None
         if ev:
             ev[0].record()
-        eng.search_frame_multi_device(pc, ref_planes, fp, None, buf[0].data_ptr(), buf[1].data_ptr(), stream)
+        eng.search_pairs_device(cur_planes, ref_planes, fp, None, buf[0].data_ptr(), buf[1].data_ptr(), stream)
         if ev:
             ev[1].record()
 
     # untimed set-up: the power management takes ~10 launches (tens of ms) to bring an idle GPU to its sustained clock; without
     # this the first timed steps of a short run (small K and W) are measured at a lower clock than the rest (5 steps: +6 %)
     for _ in range(24):
-        eng.search_frame_multi_device(pc, ref_planes, fp, None, pipe.bufs[0][0].data_ptr(), pipe.bufs[0][1].data_ptr(), stream)
+        eng.search_pairs_device(cur_planes, ref_planes, fp, None, pipe.bufs[0][0].data_ptr(), pipe.bufs[0][1].data_ptr(), stream)
     torch.cuda.synchronize()
     n_untimed = args.warmup
     for _ in range(args.warmup):
@@ -293,12 +297,13 @@ def main():
             "vs_baseline": None, "dtype": "u8" if bd == 8 else "u16", "data": "synthetic",
             "ctus_per_s": round(n_ctu * n_refs * world * args.steps / elapsed, 1),
             "config": {"workload": f"{w}x{h} {bd}-bit luma, lowdelay_P_main{'' if bd == 8 else '10'} (FEN=1), SearchRange={sr}, CTU=64, exhaustive "
-                                   f"integer search of all 593 PU shapes, {n_refs} reference picture{'s' if n_refs > 1 else ''} per launch, {n_ctu} CTUs per frame",
-                       "frames_per_step": world, "parallelism": f"frame-shard x{world}", "lambda": LAMBDA,
+                                   f"integer search of all 593 PU shapes, " + (f"{n_pairs} picture pairs" if n_pairs > 1 else f"{n_refs} reference picture{'s' if n_refs > 1 else ''}") + f" per launch, {n_ctu} CTUs per frame",
+                       "frames_per_step": world * n_pairs, "parallelism": f"frame-shard x{world}", "lambda": LAMBDA,
                        "collective": f"all_gather_into_tensor ({args.backend}), world {world}" if use_dist else "none (one rank)",
                        "sads_4x4_per_frame": sads},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": int(traffic) if traffic is not None else None,
+                         "traffic_same_run": False if traffic is not None else None,   # counters: separate rocprofv3 --pmc passes of this command
                          "kernel": "me_search_kernel<1, 0>" if bd == 8 else "me_search16_kernel<1,*> (+ merge-table preset and finalize)",
                          "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": algo_bytes,
@@ -306,7 +311,7 @@ def main():
                                  "see valu_roofline and DESIGN.md 5 for the instruction-issue roofline"},
         }
         if prof.get("stale"):
-            out["roofline"]["traffic_note"] = "profiles/latest_pmc_* was taken from other kernel sources than this build: counters withheld"
+            out["roofline"]["traffic_note"] = "profiles/latest_pmc_* was taken on a library with another build id than the one loaded: counters withheld"
         if kprof.get("valu_busy_frac") is not None:   # what actually binds: integer VALU issue
             # abs-diff operations the kernel performs: every candidate touches each of the CTU's 4096 samples once (FEN halves
             # nothing in the kernel: the even-row sums are the first half of the full sums)
@@ -315,7 +320,7 @@ def main():
             # wave-instructions per ns and CU, 1024 abs-diffs each -> 144e12 abs-diff/s on 256 CUs; v_sad_u16 1.917 per ns and CU,
             # 128 abs-diffs each -> 62.8e12
             ceiling = 144.2e12 if bd == 8 else 62.8e12
-            out["valu_roofline"] = {"bound": "valu-issue", "valu_busy_frac": round(kprof["valu_busy_frac"], 4),
+            out["valu_roofline"] = {"bound": "valu-issue", "same_run": False, "valu_busy_frac": round(kprof["valu_busy_frac"], 4),
                                     "valu_wave_instructions_per_launch": int(kprof["valu_wave_instructions_per_launch"]),
                                     "effective_clock_ghz": round(kprof.get("effective_clock_ghz", 0.0), 3),
                                     "abs_diff_per_s": round(absdiff, 0),
@@ -325,8 +330,8 @@ def main():
                                     "note": "sad_only_ceiling = the measured issue rate of the leaf instruction alone (v_qsad_pk_u16_u8 / v_sad_u16 "
                                             "micro-benchmarks under profiles/), i.e. a kernel whose reduction tree and arg-min cost nothing; it is "
                                             "0.46 (u8) of SURVEY 8d's paper figure 314.6e12 (v_sad_u8 at 2 cycles per wave-instruction)",
-                                    "source": "profiles/latest_pmc_%s.json (rocprofv3 --pmc passes of this command, same kernel sources: %s)"
-                                              % (profile_label(args.size, sr, bd), kernel_source_hash())}
+                                    "source": "profiles/latest_pmc_%s.json (rocprofv3 --pmc passes of this command on the library with the "
+                                              "same build id: %s)" % (profile_label(args.size, sr, bd), library_build_id())}
         # the step after the path, reported beside the headline, never part of `value`
         d_q = torch.zeros((n_refs, n_ctu, api.NUM_PARTS, 2), dtype=torch.int16, device=dev)
         d_c = torch.zeros((n_refs, n_ctu, api.NUM_PARTS), dtype=torch.int32, device=dev)
@@ -336,7 +341,7 @@ def main():
         for i in range(4):
             if i == 1:
                 ev[0].record()
-            eng.refine_frame_multi_device(pc, ref_planes, fp, None, d_mv16.data_ptr(), 1, d_q.data_ptr(), d_c.data_ptr(), stream)
+            eng.refine_pairs_device(cur_planes, ref_planes, fp, None, d_mv16.data_ptr(), 1, d_q.data_ptr(), d_c.data_ptr(), stream)
         ev[1].record()
         torch.cuda.synchronize()
         r_ms = ev[0].elapsed_time(ev[1]) / 3
@@ -354,8 +359,7 @@ def main():
             out["verified"] = verify_against_oracle(res, cur, ref, w, h, sr, lq, bd)
             out["cpu_baseline"] = cpu_baseline(cur, ref, w, h, sr, lq, bd)
         print(json.dumps(out), flush=True)
-    pc.close()
-    for pl in ref_planes:
+    for pl in set(cur_planes) | set(ref_planes):
         pl.close()
     eng.close()
     if use_dist:

@@ -36,7 +36,11 @@ static_assert(sizeof(MeJob16) * kCallMaxJobs <= kCallFirst && kCallFracJob + siz
 constexpr size_t kResMv = 0, kResSad = 4 * HMME_NUM_CTU_PARTS, kResDone = 8 * HMME_NUM_CTU_PARTS, kResQmv = kResDone + 64,
                  kResCost = kResQmv + 4 * HMME_NUM_CTU_PARTS, kResDone2 = kResCost + 4 * HMME_NUM_CTU_PARTS, kResBytes = kResDone2 + 64;
 // per workgroup of the 16-bit path -> 2 workgroups per CU (HMME_LDS_BUDGET16: A/B knob in bytes)
-const size_t kLdsBudget16 = std::getenv("HMME_LDS_BUDGET16") ? (size_t)std::atol(std::getenv("HMME_LDS_BUDGET16")) : 78 * 1024;
+// A value that cannot hold a one-row strip at the larger pitch (or exceeds the 160 KB of a CU) is ignored with a message: strips_for()
+// would otherwise never terminate / every launch would fail.
+constexpr size_t kLdsBudget16Default = 78 * 1024;
+size_t lds_budget16_from_env();
+const size_t kLdsBudget16 = lds_budget16_from_env();
 // 16-bit window pitch in dwords for windows up to 129 / 257 candidates wide (row = (wx + 63 + 1) samples / 2, + 34 dwords the
 // last lane of a row reaches beyond its first candidate)
 // LDS window pitch of the 16-bit kernel in dwords, for windows up to 129 / 257 candidates wide.  A lane reads dwords
@@ -49,6 +53,18 @@ const size_t kLdsBudget16 = std::getenv("HMME_LDS_BUDGET16") ? (size_t)std::atol
 #endif
 constexpr int kPdw16Small = ME16_PDW_SMALL, kPdw16Large = ME16_PDW_LARGE;
 thread_local std::string g_create_error;   // hmme_last_error(NULL): per host thread, like the contexts themselves
+constexpr size_t lds_bytes16_c(int pdw, int strip_rows) { return (size_t)(2 * 594 + 4 + (strip_rows + 63) * pdw) * 4; }
+size_t lds_budget16_from_env() {
+  const char* e = std::getenv("HMME_LDS_BUDGET16");
+  if (!e) return kLdsBudget16Default;
+  const long v = std::atol(e);
+  if (v < (long)lds_bytes16_c(kPdw16Large, 1) || v > 160 * 1024) {
+    fprintf(stderr, "hmme: HMME_LDS_BUDGET16=%s outside [%zu, %d] bytes: using the default %zu\n", e, lds_bytes16_c(kPdw16Large, 1), 160 * 1024,
+            kLdsBudget16Default);
+    return kLdsBudget16Default;
+  }
+  return (size_t)v;
+}
 }  // namespace
 
 struct hmme_ctx {
@@ -105,6 +121,11 @@ struct hmme_plane {
   hipEvent_t filled = nullptr;      // recorded after the last fill; readers on another stream wait for it
   hipStream_t fill_stream = nullptr;
   bool fill_pending = false;
+  // recorded after the last search / refinement that reads the plane; a refill on another stream waits for it (write after read).
+  // mutable: reading a plane does not change what it holds
+  mutable hipEvent_t read_done = nullptr;
+  mutable hipStream_t read_stream = nullptr;
+  mutable bool read_pending = false;
   const uint8_t* origin() const { return d_data + (size_t)kMarginY * pitch + (size_t)kMarginX * bps; }
 };
 
@@ -151,6 +172,20 @@ int plane_wait(hmme_ctx* ctx, const hmme_plane* pl, hipStream_t s) {
   if (pl->fill_pending && pl->fill_stream != s) HIP_TRY(ctx, hipStreamWaitEvent(s, pl->filled, 0));
   return HMME_OK;
 }
+// a search / refinement on `s` has been enqueued that reads `pl`.  One event holds the LAST read only, so a read on a new stream
+// first makes that stream wait for the previous reader: the event then covers both.
+int plane_read_mark(hmme_ctx* ctx, const hmme_plane* pl, hipStream_t s) {
+  if (pl->read_pending && pl->read_stream != s) HIP_TRY(ctx, hipStreamWaitEvent(s, pl->read_done, 0));
+  HIP_TRY(ctx, hipEventRecord(pl->read_done, s));
+  pl->read_stream = s; pl->read_pending = true;
+  return HMME_OK;
+}
+// before `s` overwrites the plane (or its staging buffer): the last fill and the last reader, if they ran on other streams
+int plane_write_wait(hmme_ctx* ctx, const hmme_plane* pl, hipStream_t s) {
+  if (pl->fill_pending && pl->fill_stream != s) HIP_TRY(ctx, hipStreamWaitEvent(s, pl->filled, 0));
+  if (pl->read_pending && pl->read_stream != s) HIP_TRY(ctx, hipStreamWaitEvent(s, pl->read_done, 0));
+  return HMME_OK;
+}
 
 // ---- 8-bit path --------------------------------------------------------------------------------------
 RefSet one_ref(const uint8_t* base) {
@@ -159,7 +194,7 @@ RefSet one_ref(const uint8_t* base) {
   return r;
 }
 
-int launch_search8(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const RefSet& ref, int ref_pitch, const MeJob* d_jobs,
+int launch_search8(hmme_ctx* ctx, const RefSet& cur, int cur_pitch, const RefSet& ref, int ref_pitch, const MeJob* d_jobs,
                    int n_jobs, int fen, int16_t* d_mv, uint32_t* d_sad, hipStream_t stream) {
   if (n_jobs <= 0) return HMME_OK;
   if (fen)
@@ -188,7 +223,7 @@ int merge_table(hmme_ctx* ctx, int n_jobs, unsigned long long* preset, hipStream
   return HMME_OK;
 }
 
-int launch_search8_split(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const RefSet& ref, int ref_pitch, const MeJob16* d_jobs,
+int launch_search8_split(hmme_ctx* ctx, const RefSet& cur, int cur_pitch, const RefSet& ref, int ref_pitch, const MeJob16* d_jobs,
                          const int* d_first_strip, int n_jobs, int n_split, int fen, int16_t* d_mv, uint32_t* d_sad,
                          hipStream_t stream, unsigned long long* preset_best = nullptr, bool finalize = true) {
   if (n_jobs <= 0) return HMME_OK;
@@ -207,7 +242,7 @@ int launch_search8_split(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const
 
 // ---- 16-bit path -------------------------------------------------------------------------------------
 
-size_t lds_bytes16(int pdw, int strip_rows) { return (size_t)(2 * 594 + 4 + (strip_rows + 63) * pdw) * 4; }
+size_t lds_bytes16(int pdw, int strip_rows) { return lds_bytes16_c(pdw, strip_rows); }
 
 // most candidate rows of one strip whose window rows (+ 63) fit the LDS budget
 int rows_max16(int pdw) {
@@ -219,12 +254,12 @@ int rows_max16(int pdw) {
 // strips of candidate rows so that one strip's window rows fit the LDS budget
 int strips_for(int pdw, int wy_max) {
   int n = 1;
-  while (lds_bytes16(pdw, (wy_max + n - 1) / n) > kLdsBudget16) ++n;
+  while (n < wy_max && lds_bytes16(pdw, (wy_max + n - 1) / n) > kLdsBudget16) ++n;   // bounded: one-row strips always fit (budget is validated)
   return n;
 }
 
 template <int FEN, int PDW>
-int launch16_t(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const RefSet& ref, int ref_pitch, const MeJob16* d_jobs, int n_wg,
+int launch16_t(hmme_ctx* ctx, const RefSet& cur, int cur_pitch, const RefSet& ref, int ref_pitch, const MeJob16* d_jobs, int n_wg,
                size_t lds, int sh, unsigned long long* d_best, hipStream_t stream) {
   bool& attr_set = ctx->lds_optin[FEN * 2 + (PDW == kPdw16Large ? 1 : 0)];   // > 64 KiB of dynamic LDS: opt in once per
   if (!attr_set) {                                                            // kernel and device (= per context)
@@ -238,7 +273,7 @@ int launch16_t(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const RefSet& r
 }
 
 // d_jobs: n_jobs * n_strips MeJob16; results merged in ctx->d_best then decoded into d_mv / d_sad
-int launch_search16(hmme_ctx* ctx, const uint8_t* cur, int cur_pitch, const RefSet& ref, int ref_pitch, const MeJob16* d_jobs,
+int launch_search16(hmme_ctx* ctx, const RefSet& cur, int cur_pitch, const RefSet& ref, int ref_pitch, const MeJob16* d_jobs,
                     const int* d_first_strip, int n_jobs, int n_wg, int pdw, int strip_rows_max, int fen, int bit_depth,
                     int16_t* d_mv, uint32_t* d_sad, hipStream_t stream, unsigned long long* preset_best = nullptr, bool finalize = true) {
   if (n_jobs <= 0) return HMME_OK;
@@ -286,6 +321,8 @@ int check_frame_args(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref
 template <typename SrcT, typename DstT>
 int plane_fill(hmme_plane* pl, const SrcT* d_src, int src_pitch_elems, hipStream_t s, bool check) {
   hmme_ctx* ctx = pl->ctx;
+  int wrc = plane_write_wait(ctx, pl, s);   // the previous fill and the last reader, if on other streams
+  if (wrc) return wrc;
   dim3 grid((pl->pitch / 4 + 255) / 256, pl->rows);
   hipLaunchKernelGGL((hmme::me_fill_plane_kernel<SrcT, DstT>), grid, dim3(256), 0, s, pl->d_data, pl->pitch, kMarginX, kMarginY,
                      pl->width, pl->height, d_src, src_pitch_elems, (1 << pl->bit_depth) - 1, ctx->d_flag);
@@ -304,22 +341,29 @@ int plane_fill(hmme_plane* pl, const SrcT* d_src, int src_pitch_elems, hipStream
   return HMME_OK;
 }
 
+// s == nullptr: the synchronous upload (private stream, range check, returns when the plane is filled); otherwise asynchronous on
+// `s` -- the copy runs at PCIe rate only from page-locked memory (hmme_host_register) and a range violation is latched for
+// hmme_upload_status
 template <typename T>
-int plane_upload(hmme_plane* pl, const T* origin, int stride) {
+int plane_upload(hmme_plane* pl, const T* origin, int stride, hipStream_t s, bool sync) {
   if (!pl) return HMME_ERR_ARG;
   hmme_ctx* ctx = pl->ctx;
   if (!origin || stride < pl->width) return fail(ctx, HMME_ERR_ARG, "plane upload: bad origin/stride");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (sync) s = ctx->stream;
   const size_t bytes = sizeof(T) * (size_t)pl->width * pl->height;
   if (pl->stage_bytes < bytes) {
+    if (pl->fill_pending) HIP_TRY(ctx, hipEventSynchronize(pl->filled));   // a fill may still be reading the old staging buffer
     hipFree(pl->d_stage); pl->d_stage = nullptr; pl->stage_bytes = 0;
     HIP_TRY(ctx, hipMalloc(&pl->d_stage, bytes));
     pl->stage_bytes = bytes;
   }
+  int rc = plane_write_wait(ctx, pl, s);   // the staging buffer is read by the previous fill
+  if (rc) return rc;
   HIP_TRY(ctx, hipMemcpy2DAsync(pl->d_stage, sizeof(T) * pl->width, origin, sizeof(T) * (size_t)stride, sizeof(T) * pl->width,
-                                pl->height, hipMemcpyHostToDevice, ctx->stream));
-  if (pl->bps == 1) return plane_fill<T, uint8_t>(pl, (const T*)pl->d_stage, pl->width, ctx->stream, true);
-  return plane_fill<T, uint16_t>(pl, (const T*)pl->d_stage, pl->width, ctx->stream, true);
+                                pl->height, hipMemcpyHostToDevice, s));
+  if (pl->bps == 1) return plane_fill<T, uint8_t>(pl, (const T*)pl->d_stage, pl->width, s, sync);
+  return plane_fill<T, uint16_t>(pl, (const T*)pl->d_stage, pl->width, s, sync);
 }
 
 }  // namespace
@@ -617,9 +661,9 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
   const uint32_t seq = ++ctx->call_seq ? ctx->call_seq : ++ctx->call_seq;   // never 0, the words' initial value
   if (do_search) {
   if (!wide)
-    rc = launch_search8_split(ctx, ctx->d_call + kCallCtu, 64, one_ref(ref_base), kWinPitch, d_js, d_first, 1, n_wg, p->fen, d_mv1, d_sad1, s, d_best1, false);
+    rc = launch_search8_split(ctx, one_ref(ctx->d_call + kCallCtu), 64, one_ref(ref_base), kWinPitch, d_js, d_first, 1, n_wg, p->fen, d_mv1, d_sad1, s, d_best1, false);
   else
-    rc = launch_search16(ctx, ctx->d_call + kCallCtu, 128, one_ref(ref_base), kWinPitch, d_js, d_first, 1, n_wg, pdw, smax, p->fen, shift_bd,
+    rc = launch_search16(ctx, one_ref(ctx->d_call + kCallCtu), 128, one_ref(ref_base), kWinPitch, d_js, d_first, 1, n_wg, pdw, smax, p->fen, shift_bd,
                          d_mv1, d_sad1, s, d_best1, false);
   if (rc) return rc;
   hipLaunchKernelGGL(hmme::me_finalize1_kernel, dim3(1), dim3(640), 0, s, d_best1, d_js, ctx->lambda_q16, d_mv1, d_sad1,
@@ -631,10 +675,10 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
     // its input the integer tables the finalize kernel just wrote (or the caller's), its output in the same pinned block
     rc = build_frac_cover(ctx);
     if (rc) return rc;
-    using frac_fn = void (*)(const uint8_t*, int, const RefSet, int, const MeJob*, const uint16_t*, const int16_t*, uint32_t, int, int16_t*, uint32_t*);
+    using frac_fn = void (*)(const RefSet, int, const RefSet, int, const MeJob*, const uint16_t*, const int16_t*, uint32_t, int, int16_t*, uint32_t*);
     static const frac_fn fns[2][2] = {{hmme::me_frac_kernel<0, 1>, hmme::me_frac_kernel<1, 1>}, {hmme::me_frac_kernel<0, 2>, hmme::me_frac_kernel<1, 2>}};
     const int16_t* d_imv = do_search ? d_mv1 : (const int16_t*)(ctx->d_call + kCallImv);
-    hipLaunchKernelGGL(fns[wide ? 1 : 0][refine_had ? 1 : 0], dim3(1), dim3(hmme::frac_threads(bps)), hmme::frac_lds_bytes(bps), s, ctx->d_call + kCallCtu,
+    hipLaunchKernelGGL(fns[wide ? 1 : 0][refine_had ? 1 : 0], dim3(1), dim3(hmme::frac_threads(bps)), hmme::frac_lds_bytes(bps), s, one_ref(ctx->d_call + kCallCtu),
                        64 * bps, one_ref(ref_base), kWinPitch, (const MeJob*)(ctx->d_call + kCallFracJob), ctx->d_frac_cover, d_imv, ctx->lambda_q16,
                        p->bit_depth, (int16_t*)(ctx->d_res + kResQmv), (uint32_t*)(ctx->d_res + kResCost));
     HIP_TRY(ctx, hipGetLastError());
@@ -688,6 +732,7 @@ int hmme_plane_create_ex(hmme_ctx* ctx, int width, int height, int bit_depth, hm
   pl->rows = height + 2 * kMarginY;
   hipError_t e = hipMalloc(&pl->d_data, (size_t)pl->pitch * (pl->rows + 1));
   if (e == hipSuccess && (e = hipEventCreateWithFlags(&pl->filled, hipEventDisableTiming)) != hipSuccess) hipFree(pl->d_data);
+  if (e == hipSuccess && (e = hipEventCreateWithFlags(&pl->read_done, hipEventDisableTiming)) != hipSuccess) { hipEventDestroy(pl->filled); hipFree(pl->d_data); }
   if (e != hipSuccess) { delete pl; return fail(ctx, HMME_ERR_NOMEM, "plane allocation: %s", hipGetErrorString(e)); }
   *out = pl;
   return HMME_OK;
@@ -697,8 +742,10 @@ int hmme_plane_create(hmme_ctx* ctx, int width, int height, hmme_plane** out) { 
 void hmme_plane_destroy(hmme_plane* pl) {
   if (!pl) return;
   hipSetDevice(pl->ctx->device);
-  if (pl->fill_pending) hipEventSynchronize(pl->filled);   // a fill still in flight must not outlive the buffer
+  if (pl->fill_pending) hipEventSynchronize(pl->filled);   // a fill or a search still in flight must not outlive the buffer
+  if (pl->read_pending) hipEventSynchronize(pl->read_done);
   if (pl->filled) hipEventDestroy(pl->filled);
+  if (pl->read_done) hipEventDestroy(pl->read_done);
   hipFree(pl->d_data);
   hipFree(pl->d_stage);
   delete pl;
@@ -708,8 +755,38 @@ int hmme_plane_width(const hmme_plane* pl) { return pl ? pl->width : 0; }
 int hmme_plane_height(const hmme_plane* pl) { return pl ? pl->height : 0; }
 int hmme_plane_bit_depth(const hmme_plane* pl) { return pl ? pl->bit_depth : 0; }
 
-int hmme_plane_upload_pel(hmme_plane* pl, const int16_t* origin, int stride) { return plane_upload<int16_t>(pl, origin, stride); }
-int hmme_plane_upload_u8(hmme_plane* pl, const uint8_t* origin, int stride) { return plane_upload<uint8_t>(pl, origin, stride); }
+int hmme_plane_upload_pel(hmme_plane* pl, const int16_t* origin, int stride) { return plane_upload<int16_t>(pl, origin, stride, nullptr, true); }
+int hmme_plane_upload_u8(hmme_plane* pl, const uint8_t* origin, int stride) { return plane_upload<uint8_t>(pl, origin, stride, nullptr, true); }
+
+int hmme_plane_upload_async(hmme_plane* pl, const void* origin, int stride, int sample_bytes, void* stream) {
+  if (!pl) return HMME_ERR_ARG;
+  if (sample_bytes == 1) return plane_upload<uint8_t>(pl, (const uint8_t*)origin, stride, (hipStream_t)stream, false);
+  // 16-bit samples (HM's Pel, or the unsigned words of a 16-bit YUV file: anything beyond the bit depth reads as negative or too large)
+  if (sample_bytes == 2) return plane_upload<int16_t>(pl, (const int16_t*)origin, stride, (hipStream_t)stream, false);
+  return fail(pl->ctx, HMME_ERR_ARG, "hmme_plane_upload_async: sample_bytes %d (1 or 2)", sample_bytes);
+}
+
+int hmme_upload_status(hmme_ctx* ctx, void* stream) {
+  if (!ctx) return HMME_ERR_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int flag = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&flag, ctx->d_flag, sizeof flag, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+  if (!flag) return HMME_OK;
+  HIP_TRY(ctx, hipMemset(ctx->d_flag, 0, sizeof(int)));
+  return fail(ctx, HMME_ERR_RANGE, "an asynchronous plane upload carried a sample outside the range of its plane's bit depth");
+}
+
+uint64_t hmme_debug_device_address(const hmme_ctx* ctx, const hmme_plane* pl) {
+  if (pl) return (uint64_t)(uintptr_t)pl->origin();
+  return ctx ? (uint64_t)(uintptr_t)(ctx->d_call + kCallCtu) : 0;
+}
+
+int hmme_abi_version(void) { return HMME_ABI_VERSION; }
+#ifndef HMME_BUILD_ID
+#define HMME_BUILD_ID "unknown"
+#endif
+const char* hmme_build_id(void) { return HMME_BUILD_ID; }
 
 int hmme_host_register(hmme_ctx* ctx, void* buffer, size_t bytes) {
   if (!ctx) return HMME_ERR_ARG;
@@ -856,49 +933,83 @@ static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_para
   return HMME_OK;
 }
 
-static int run_search(hmme_ctx* ctx, const hmme_plane* cur, const RefSet& refs, int ref_pitch, const hmme_frame_params* fp, const FramePlan& pl,
+static int run_search(hmme_ctx* ctx, const RefSet& curs, int cur_pitch, const RefSet& refs, int ref_pitch, const hmme_frame_params* fp, const FramePlan& pl,
                       int16_t* d_mv, uint32_t* d_sad, hipStream_t s) {
   if (fp->bit_depth > 8)
-    return launch_search16(ctx, cur->origin(), cur->pitch, refs, ref_pitch, (const MeJob16*)ctx->d_jobs, ctx->d_first_strip, pl.jobs, pl.n_wg16,
+    return launch_search16(ctx, curs, cur_pitch, refs, ref_pitch, (const MeJob16*)ctx->d_jobs, ctx->d_first_strip, pl.jobs, pl.n_wg16,
                            pl.pdw, pl.strip_rows, fp->fen, fp->bit_depth, d_mv, d_sad, s);
   if (pl.tile8)
-    return launch_search8_split(ctx, cur->origin(), cur->pitch, refs, ref_pitch, (const MeJob16*)ctx->d_jobs, ctx->d_first_strip, pl.jobs, 4,
+    return launch_search8_split(ctx, curs, cur_pitch, refs, ref_pitch, (const MeJob16*)ctx->d_jobs, ctx->d_first_strip, pl.jobs, 4,
                                 fp->fen, d_mv, d_sad, s);
   const int head = pl.tail_first, n_tail = pl.jobs - head;
   unsigned long long* best = nullptr;
   int rc = n_tail ? merge_table(ctx, n_tail, nullptr, s, &best) : HMME_OK;   // the tail's merge table is preset before the head runs, not between the two
-  if (rc == HMME_OK) rc = launch_search8(ctx, cur->origin(), cur->pitch, refs, ref_pitch, (const MeJob*)ctx->d_jobs, head, fp->fen, d_mv, d_sad, s);
+  if (rc == HMME_OK) rc = launch_search8(ctx, curs, cur_pitch, refs, ref_pitch, (const MeJob*)ctx->d_jobs, head, fp->fen, d_mv, d_sad, s);
   if (rc || !n_tail) return rc;
-  return launch_search8_split(ctx, cur->origin(), cur->pitch, refs, ref_pitch, (const MeJob16*)((const uint8_t*)ctx->d_jobs + pl.tail_jobs_off), ctx->d_first_strip,
+  return launch_search8_split(ctx, curs, cur_pitch, refs, ref_pitch, (const MeJob16*)((const uint8_t*)ctx->d_jobs + pl.tail_jobs_off), ctx->d_first_strip,
                               n_tail, pl.tail_parts, fp->fen, d_mv + (size_t)head * 2 * HMME_NUM_CTU_PARTS, d_sad + (size_t)head * HMME_NUM_CTU_PARTS, s, best);
+}
+
+// n_pairs (current, reference) picture pairs of one size in one launch: validates, orders the streams, fills the two plane sets
+namespace {
+struct PairLaunch {
+  RefSet curs, refs;
+  int first = 0, count = 0;
+};
+int pairs_begin(hmme_ctx* ctx, const hmme_plane* const* curs, const hmme_plane* const* refs, int n_pairs, const hmme_frame_params* fp,
+                hipStream_t s, PairLaunch* pl) {
+  if (!curs || !refs || n_pairs < 1 || n_pairs > hmme::kMaxRefs) return fail(ctx, HMME_ERR_ARG, "%d picture pairs outside 1..%d", n_pairs, hmme::kMaxRefs);
+  pl->curs = one_ref(nullptr); pl->refs = one_ref(nullptr);
+  for (int r = 0; r < n_pairs; ++r) {
+    int rc = check_frame_args(ctx, curs[r], refs[r], fp, &pl->first, &pl->count);
+    if (rc) return rc;
+    if (refs[r]->pitch != refs[0]->pitch || curs[r]->pitch != curs[0]->pitch || curs[r]->width != curs[0]->width || curs[r]->height != curs[0]->height)
+      return fail(ctx, HMME_ERR_ARG, "the planes of one launch differ in size");
+    pl->curs.base[r] = curs[r]->origin();
+    pl->refs.base[r] = refs[r]->origin();
+  }
+  if (pl->count == 0) return HMME_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = scratch_acquire(ctx, s);
+  for (int r = 0; r < n_pairs && rc == HMME_OK; ++r) {
+    rc = plane_wait(ctx, curs[r], s);
+    if (rc == HMME_OK) rc = plane_wait(ctx, refs[r], s);
+  }
+  return rc;
+}
+// after the kernels are enqueued (or an enqueue failed): the planes have a reader on `s`, the scratch a user
+int pairs_end(hmme_ctx* ctx, const hmme_plane* const* curs, const hmme_plane* const* refs, int n_pairs, hipStream_t s, int rc) {
+  for (int r = 0; r < n_pairs; ++r) {
+    int r2 = (r == 0 || curs[r] != curs[r - 1]) ? plane_read_mark(ctx, curs[r], s) : HMME_OK;
+    if (r2 == HMME_OK) r2 = plane_read_mark(ctx, refs[r], s);
+    if (rc == HMME_OK) rc = r2;
+  }
+  const int r3 = scratch_release(ctx, s);
+  return rc ? rc : r3;
+}
+}  // namespace
+
+int hmme_search_pairs_device(hmme_ctx* ctx, const hmme_plane* const* curs, const hmme_plane* const* refs, int n_pairs,
+                             const hmme_frame_params* fp, const void* d_pred_q, void* d_out_mv, void* d_out_sad, void* stream) {
+  if (!ctx) return HMME_ERR_ARG;
+  if (!d_out_mv || !d_out_sad) return fail(ctx, HMME_ERR_ARG, "null output buffer");
+  hipStream_t s = (hipStream_t)stream;
+  PairLaunch pl;
+  int rc = pairs_begin(ctx, curs, refs, n_pairs, fp, s, &pl);
+  if (rc || pl.count == 0) return rc;
+  FramePlan plan;
+  rc = prep_jobs(ctx, curs[0], fp, d_pred_q, pl.first, pl.count, n_pairs, s, &plan);
+  if (rc == HMME_OK) rc = run_search(ctx, pl.curs, curs[0]->pitch, pl.refs, refs[0]->pitch, fp, plan, (int16_t*)d_out_mv, (uint32_t*)d_out_sad, s);
+  return pairs_end(ctx, curs, refs, n_pairs, s, rc);
 }
 
 int hmme_search_frame_multi_device(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* const* refs, int n_refs,
                                    const hmme_frame_params* fp, const void* d_pred_q, void* d_out_mv, void* d_out_sad, void* stream) {
   if (!ctx) return HMME_ERR_ARG;
   if (!refs || n_refs < 1 || n_refs > hmme::kMaxRefs) return fail(ctx, HMME_ERR_ARG, "n_refs %d outside 1..%d", n_refs, hmme::kMaxRefs);
-  int first = 0, count = 0;
-  RefSet set = one_ref(nullptr);
-  for (int r = 0; r < n_refs; ++r) {
-    int rc = check_frame_args(ctx, cur, refs[r], fp, &first, &count);
-    if (rc) return rc;
-    if (refs[r]->pitch != refs[0]->pitch) return fail(ctx, HMME_ERR_ARG, "reference planes differ in pitch");
-    set.base[r] = refs[r]->origin();
-  }
-  if (!d_out_mv || !d_out_sad) return fail(ctx, HMME_ERR_ARG, "null output buffer");
-  if (count == 0) return HMME_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  hipStream_t s = (hipStream_t)stream;
-  int rc = scratch_acquire(ctx, s);
-  if (rc == HMME_OK) rc = plane_wait(ctx, cur, s);
-  for (int r = 0; r < n_refs && rc == HMME_OK; ++r) rc = plane_wait(ctx, refs[r], s);
-  if (rc) return rc;
-  FramePlan plan;
-  rc = prep_jobs(ctx, cur, fp, d_pred_q, first, count, n_refs, s, &plan);
-  if (rc) return rc;
-  rc = run_search(ctx, cur, set, refs[0]->pitch, fp, plan, (int16_t*)d_out_mv, (uint32_t*)d_out_sad, s);
-  if (rc) return rc;
-  return scratch_release(ctx, s);
+  const hmme_plane* curs[hmme::kMaxRefs];
+  for (int r = 0; r < n_refs; ++r) curs[r] = cur;
+  return hmme_search_pairs_device(ctx, curs, refs, n_refs, fp, d_pred_q, d_out_mv, d_out_sad, stream);
 }
 
 int hmme_search_frame_device(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp,
@@ -976,46 +1087,45 @@ int build_frac_cover(hmme_ctx* ctx) {
 }
 }  // namespace
 
+int hmme_refine_pairs_device(hmme_ctx* ctx, const hmme_plane* const* curs, const hmme_plane* const* refs, int n_pairs,
+                             const hmme_frame_params* fp, const void* d_pred_q, const void* d_int_mv, int use_hadamard,
+                             void* d_out_qmv, void* d_out_cost, void* stream) {
+  if (!ctx) return HMME_ERR_ARG;
+  if (!d_int_mv || !d_out_qmv || !d_out_cost) return fail(ctx, HMME_ERR_ARG, "null buffer");
+  hipStream_t s = (hipStream_t)stream;
+  PairLaunch pl;
+  int rc = pairs_begin(ctx, curs, refs, n_pairs, fp, s, &pl);
+  if (rc || pl.count == 0) return rc;
+  const int jobs = pl.count * n_pairs;
+  rc = build_frac_cover(ctx);
+  if (rc == HMME_OK) {
+    size_t cap = ctx->jobs_bytes;
+    rc = ensure(ctx, (uint8_t**)&ctx->d_jobs, &cap, sizeof(MeJob) * (size_t)jobs);
+    ctx->jobs_bytes = cap;
+  }
+  if (rc == HMME_OK) {
+    hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, dim3((jobs + 255) / 256), dim3(256), 0, s, (MeJob*)ctx->d_jobs, (const int16_t*)d_pred_q,
+                       pl.first, pl.count, n_pairs, curs[0]->width, curs[0]->height, fp->search_range, 0, jobs);
+    const int had = use_hadamard ? 1 : 0, wide = curs[0]->bps == 2 ? 1 : 0;
+    using frac_fn = void (*)(const RefSet, int, const RefSet, int, const MeJob*, const uint16_t*, const int16_t*, uint32_t, int, int16_t*, uint32_t*);
+    static const frac_fn fns[2][2] = {{hmme::me_frac_kernel<0, 1>, hmme::me_frac_kernel<1, 1>}, {hmme::me_frac_kernel<0, 2>, hmme::me_frac_kernel<1, 2>}};
+    hipLaunchKernelGGL(fns[wide][had], dim3(jobs), dim3(hmme::frac_threads(wide ? 2 : 1)), hmme::frac_lds_bytes(wide ? 2 : 1), s, pl.curs,
+                       curs[0]->pitch, pl.refs, refs[0]->pitch, (const MeJob*)ctx->d_jobs, ctx->d_frac_cover, (const int16_t*)d_int_mv, ctx->lambda_q16,
+                       fp->bit_depth, (int16_t*)d_out_qmv, (uint32_t*)d_out_cost);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) rc = fail(ctx, HMME_ERR_DEVICE, "refinement launch -> %s", hipGetErrorString(e));
+  }
+  return pairs_end(ctx, curs, refs, n_pairs, s, rc);
+}
+
 int hmme_refine_frame_multi_device(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* const* refs, int n_refs,
                                    const hmme_frame_params* fp, const void* d_pred_q, const void* d_int_mv, int use_hadamard,
                                    void* d_out_qmv, void* d_out_cost, void* stream) {
   if (!ctx) return HMME_ERR_ARG;
   if (!refs || n_refs < 1 || n_refs > hmme::kMaxRefs) return fail(ctx, HMME_ERR_ARG, "n_refs %d outside 1..%d", n_refs, hmme::kMaxRefs);
-  int first = 0, count = 0;
-  RefSet set = one_ref(nullptr);
-  for (int r = 0; r < n_refs; ++r) {
-    int rc = check_frame_args(ctx, cur, refs[r], fp, &first, &count);
-    if (rc) return rc;
-    if (refs[r]->pitch != refs[0]->pitch) return fail(ctx, HMME_ERR_ARG, "reference planes differ in pitch");
-    set.base[r] = refs[r]->origin();
-  }
-  if (!d_int_mv || !d_out_qmv || !d_out_cost) return fail(ctx, HMME_ERR_ARG, "null buffer");
-  if (count == 0) return HMME_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  int rc = build_frac_cover(ctx);
-  if (rc) return rc;
-  const int jobs = count * n_refs;
-  size_t cap = ctx->jobs_bytes;
-  rc = ensure(ctx, (uint8_t**)&ctx->d_jobs, &cap, sizeof(MeJob) * (size_t)jobs);
-  ctx->jobs_bytes = cap;
-  if (rc) return rc;
-  hipStream_t s = (hipStream_t)stream;
-  rc = scratch_acquire(ctx, s);
-  if (rc == HMME_OK) rc = plane_wait(ctx, cur, s);
-  for (int r = 0; r < n_refs && rc == HMME_OK; ++r) rc = plane_wait(ctx, refs[r], s);
-  if (rc) return rc;
-  hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, dim3((jobs + 255) / 256), dim3(256), 0, s, (MeJob*)ctx->d_jobs, (const int16_t*)d_pred_q,
-                     first, count, n_refs, cur->width, cur->height, fp->search_range, 0, jobs);
-  HIP_TRY(ctx, hipGetLastError());
-  const int had = use_hadamard ? 1 : 0, wide = cur->bps == 2 ? 1 : 0;
-  using frac_fn = void (*)(const uint8_t*, int, const RefSet, int, const MeJob*, const uint16_t*, const int16_t*, uint32_t, int, int16_t*,
-                           uint32_t*);
-  static const frac_fn fns[2][2] = {{hmme::me_frac_kernel<0, 1>, hmme::me_frac_kernel<1, 1>}, {hmme::me_frac_kernel<0, 2>, hmme::me_frac_kernel<1, 2>}};
-  hipLaunchKernelGGL(fns[wide][had], dim3(jobs), dim3(hmme::frac_threads(wide ? 2 : 1)), hmme::frac_lds_bytes(wide ? 2 : 1), s, cur->origin(),
-                     cur->pitch, set, refs[0]->pitch, (const MeJob*)ctx->d_jobs, ctx->d_frac_cover, (const int16_t*)d_int_mv, ctx->lambda_q16,
-                     fp->bit_depth, (int16_t*)d_out_qmv, (uint32_t*)d_out_cost);
-  HIP_TRY(ctx, hipGetLastError());
-  return scratch_release(ctx, s);
+  const hmme_plane* curs[hmme::kMaxRefs];
+  for (int r = 0; r < n_refs; ++r) curs[r] = cur;
+  return hmme_refine_pairs_device(ctx, curs, refs, n_refs, fp, d_pred_q, d_int_mv, use_hadamard, d_out_qmv, d_out_cost, stream);
 }
 
 int hmme_refine_frame(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp, const int16_t* pred_q,
@@ -1057,32 +1167,29 @@ int hmme_time_search_kernel(hmme_ctx* ctx, const hmme_plane* cur, const hmme_pla
   int rc = check_frame_args(ctx, cur, ref, fp, &first, &count);
   if (rc) return rc;
   if (!avg_ms || reps < 1) return fail(ctx, HMME_ERR_ARG, "hmme_time_search_kernel: bad reps/avg_ms");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
-  rc = scratch_acquire(ctx, s);
-  if (rc == HMME_OK) rc = plane_wait(ctx, cur, s);
-  if (rc == HMME_OK) rc = plane_wait(ctx, ref, s);
-  if (rc) return rc;
+  PairLaunch pl;
+  rc = pairs_begin(ctx, &cur, &ref, 1, fp, s, &pl);
+  if (rc || pl.count == 0) return rc;
   // job table once (it is not part of the timed kernel), then `reps` launches of the search kernel(s) alone
   FramePlan plan;
   rc = prep_jobs(ctx, cur, fp, d_pred_q, first, count, 1, s, &plan);
-  if (rc) return rc;
-  const RefSet set = one_ref(ref->origin());
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  HIP_TRY(ctx, hipEventCreate(&e0));
-  if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); return fail(ctx, HMME_ERR_DEVICE, "hipEventCreate failed"); }
+  hipError_t e = hipSuccess;
   float ms = 0.f;
-  hipError_t e = hipEventRecord(e0, s);
-  for (int i = 0; i < reps && rc == HMME_OK && e == hipSuccess; ++i)
-    rc = run_search(ctx, cur, set, ref->pitch, fp, plan, (int16_t*)d_out_mv, (uint32_t*)d_out_sad, s);
-  if (rc == HMME_OK && e == hipSuccess) e = hipEventRecord(e1, s);
-  if (rc == HMME_OK && e == hipSuccess) e = hipEventSynchronize(e1);
-  if (rc == HMME_OK && e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-  hipEventDestroy(e0); hipEventDestroy(e1);
-  if (rc) return rc;
-  if (e != hipSuccess) return fail(ctx, HMME_ERR_DEVICE, "timing the search kernel: %s", hipGetErrorString(e));
-  *avg_ms = ms / reps;
-  return scratch_release(ctx, s);
+  if (rc == HMME_OK && (e = hipEventCreate(&e0)) == hipSuccess && (e = hipEventCreate(&e1)) == hipSuccess) {
+    e = hipEventRecord(e0, s);
+    for (int i = 0; i < reps && rc == HMME_OK && e == hipSuccess; ++i)
+      rc = run_search(ctx, pl.curs, cur->pitch, pl.refs, ref->pitch, fp, plan, (int16_t*)d_out_mv, (uint32_t*)d_out_sad, s);
+    if (rc == HMME_OK && e == hipSuccess) e = hipEventRecord(e1, s);
+    if (rc == HMME_OK && e == hipSuccess) e = hipEventSynchronize(e1);
+    if (rc == HMME_OK && e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  }
+  if (e0) hipEventDestroy(e0);
+  if (e1) hipEventDestroy(e1);
+  if (rc == HMME_OK && e != hipSuccess) rc = fail(ctx, HMME_ERR_DEVICE, "timing the search kernel: %s", hipGetErrorString(e));
+  if (rc == HMME_OK) *avg_ms = ms / reps;
+  return pairs_end(ctx, &cur, &ref, 1, s, rc);
 }
 
 }  // extern "C"

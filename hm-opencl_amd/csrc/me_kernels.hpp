@@ -54,8 +54,9 @@ struct MeJob {
   int16_t pred_x, pred_y; // AMVP predictor, quarter pels
 };
 static_assert(sizeof(MeJob) == 16, "MeJob layout");
-// CTU origins are multiples of 64, so the low 6 bits of MeJob::ctu_x carry the index of the reference picture the
-// job searches (several references of one picture in one launch, hmme_search_frame_multi)
+// CTU origins are multiples of 64, so the low 6 bits of MeJob::ctu_x carry the index of the picture pair the job belongs to: one
+// launch searches up to 16 (current, reference) pairs -- several references of one picture (hmme_search_frame_multi: the same
+// current plane in every entry) or several pictures of a sequence (hmme_search_pairs_device).  Both sets travel by value.
 constexpr int kMaxRefs = 16;
 struct RefSet { const uint8_t* base[kMaxRefs]; };
 
@@ -245,14 +246,18 @@ __host__ __device__ inline int me_strip_rows16(int wx, int wy, int rows_max, int
 // iterations (the per-CTU call: 64 workgroups per search).  One wave issues the loads; nothing reads the results.
 template <int LINES>
 __device__ __forceinline__ void me_prefetch_cur(uint64_t curc, uint32_t pitch) {
+  // every load targets the SAME register `d`, an in-out operand of each statement and of the final wait: it stays allocated for the
+  // whole sequence, so the compiler can never hand it to another value (the offset temporary `o` of a later statement, say) while
+  // loads into it are still in flight -- the inline scalar loads are invisible to its own waitcnt / liveness tracking
+  uint32_t d = 0;
 #pragma unroll
   for (int r = 0; r < 64; ++r)
 #pragma unroll
     for (int l = 0; l < LINES; ++l) {
-      uint32_t d, o;
-      asm volatile("s_mul_i32 %1, %3, %4\n\ts_load_dword %0, %2, %1 offset:%5" : "=s"(d), "=&s"(o) : "s"(curc), "s"(pitch), "n"(r), "n"(64 * l));
+      uint32_t o;
+      asm volatile("s_mul_i32 %1, %3, %4\n\ts_load_dword %0, %2, %1 offset:%5" : "+s"(d), "=&s"(o) : "s"(curc), "s"(pitch), "n"(r), "n"(64 * l));
     }
-  asm volatile("s_waitcnt lgkmcnt(0)");
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d));
 }
 
 // Window staging shared by the search kernels: LDS dword i = window row i / PDW, dword i % PDW, realigned by `mis` bytes.  Eight
@@ -288,7 +293,7 @@ constexpr int kTileStep = 129, kTileJobMask = 0x1fffffff;
 //            (decoded afterwards by me_finalize16_kernel) -- used where one CTU must fill many CUs.
 template <int FEN, int SPLIT>
 __global__ void __launch_bounds__(kThreads, 2)
-me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet refs, int ref_pitch,
+me_search_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitch,
                  const void* __restrict__ jobs_v, uint32_t lambda_q16, int16_t* __restrict__ out_mv,
                  uint32_t* __restrict__ out_sad, unsigned long long* __restrict__ g_best) {
   __shared__ uint32_t win[kWinRowsMax * kPDW];
@@ -308,6 +313,7 @@ me_search_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefS
     job = ((const MeJob*)jobs_v)[blockIdx.x];
   }
   const uint8_t* __restrict__ ref_base = refs.base[job.ctu_x & 63];
+  const uint8_t* __restrict__ cur_base = curs.base[job.ctu_x & 63];
   job.ctu_x &= ~63;
   const int wx = job.rb_x - job.lt_x + 1, wy = job.rb_y - job.lt_y + 1;   // candidates per row / rows
 
@@ -564,7 +570,7 @@ __device__ __forceinline__ uint32_t me_keymin3(uint32_t s0, uint32_t s1, uint32_
 
 template <int FEN, int PDW>
 __global__ void __launch_bounds__(kThreads16, 2)
-me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet refs, int ref_pitch,
+me_search16_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitch,
                    const MeJob16* __restrict__ jobs, uint32_t lambda_q16, int sh, unsigned long long* __restrict__ g_best) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   unsigned long long* best64 = (unsigned long long*)smem;              // [593] (+1 pad)
@@ -576,6 +582,7 @@ me_search16_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const Re
   const MeJob16 jb = jobs[blockIdx.x];
   MeJob job = jb.j;
   const uint8_t* __restrict__ ref_base = refs.base[job.ctu_x & 63];
+  const uint8_t* __restrict__ cur_base = curs.base[job.ctu_x & 63];
   job.ctu_x &= ~63;
   const int wx = job.rb_x - job.lt_x + 1;
   const int ny = jb.y1 - jb.y0;                                        // candidate rows of this strip
@@ -1129,7 +1136,7 @@ __device__ __forceinline__ void me_frac_dedupe(const uint32_t* st, const uint16_
 
 template <int HAD, int BPS>
 __global__ void __launch_bounds__(frac_threads(BPS), 2)
-me_frac_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet refs, int ref_pitch,
+me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitch,
                const MeJob* __restrict__ jobs, const uint16_t* __restrict__ cover, const int16_t* __restrict__ int_mv,
                uint32_t lambda_q16, int bit_depth, int16_t* __restrict__ out_qmv, uint32_t* __restrict__ out_cost) {
   constexpr int NT = frac_threads(BPS);
@@ -1146,6 +1153,7 @@ me_frac_kernel(const uint8_t* __restrict__ cur_base, int cur_pitch, const RefSet
   const int tid = threadIdx.x;
   MeJob job = jobs[blockIdx.x];
   const uint8_t* __restrict__ ref_base = refs.base[job.ctu_x & 63];
+  const uint8_t* __restrict__ cur_base = curs.base[job.ctu_x & 63];
   job.ctu_x &= ~63;
   const int wy = job.rb_y - job.lt_y + 1;
   const int bd = BPS == 1 ? 8 : bit_depth;

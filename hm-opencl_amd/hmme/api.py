@@ -21,7 +21,9 @@ SYMBOLS = ["hmme_create", "hmme_destroy", "hmme_last_error", "hmme_device_info",
            "hmme_plane_upload_u8", "hmme_host_register", "hmme_host_unregister", "hmme_plane_set_device_u8", "hmme_plane_width", "hmme_plane_height",
            "hmme_num_ctus", "hmme_search_frame", "hmme_search_frame_device", "hmme_search_frame_multi",
            "hmme_search_frame_multi_device", "hmme_refine_frame", "hmme_refine_frame_multi_device",
-           "hmme_time_search_kernel"]
+           "hmme_time_search_kernel", "hmme_search_pairs_device", "hmme_refine_pairs_device", "hmme_plane_upload_async",
+           "hmme_upload_status", "hmme_debug_device_address", "hmme_abi_version", "hmme_build_id"]
+ABI_VERSION = 3   # HMME_ABI_VERSION of the include/hmme.h these bindings were written against
 
 
 class HmmeError(RuntimeError):
@@ -56,6 +58,10 @@ def load():
                         "The engine has no CPU fallback.")
     L = C.CDLL(LIB_PATH)
     vp, i = C.c_void_p, C.c_int
+    if not hasattr(L, "hmme_abi_version") or L.hmme_abi_version() != ABI_VERSION:
+        raise HmmeError(f"{LIB_PATH}: ABI version {L.hmme_abi_version() if hasattr(L, 'hmme_abi_version') else '< 3'}, "
+                        f"these bindings need {ABI_VERSION}: rebuild with `make -C {CSRC}`")
+    L.hmme_build_id.restype = C.c_char_p
     L.hmme_create.argtypes = [i, i, C.c_uint, C.POINTER(vp)]
     L.hmme_destroy.argtypes = [vp]
     L.hmme_destroy.restype = None
@@ -96,6 +102,12 @@ def load():
     L.hmme_refine_frame.argtypes = [vp, vp, vp, C.POINTER(FrameParams), vp, vp, i, vp, vp]
     L.hmme_refine_frame_multi_device.argtypes = [vp, vp, C.POINTER(vp), i, C.POINTER(FrameParams), vp, vp, i, vp, vp, vp]
     L.hmme_time_search_kernel.argtypes = [vp, vp, vp, C.POINTER(FrameParams), vp, vp, vp, vp, i, C.POINTER(C.c_float)]
+    L.hmme_search_pairs_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i, C.POINTER(FrameParams), vp, vp, vp, vp]
+    L.hmme_refine_pairs_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i, C.POINTER(FrameParams), vp, vp, i, vp, vp, vp]
+    L.hmme_plane_upload_async.argtypes = [vp, vp, i, i, vp]
+    L.hmme_upload_status.argtypes = [vp, vp]
+    L.hmme_debug_device_address.argtypes = [vp, vp]
+    L.hmme_debug_device_address.restype = C.c_uint64
     _lib = L
     return L
 
@@ -118,6 +130,14 @@ class Plane:
         a = np.ascontiguousarray(img, dtype=np.uint8)
         assert a.shape == (self.height, self.width)
         self.engine._check(self.engine.L.hmme_plane_upload_u8(self.h, a.ctypes.data, a.shape[1]))
+
+    def upload_async(self, host_ptr, stride, sample_bytes, stream):
+        """asynchronous upload from (page-locked) host memory on `stream`; host_ptr: address of sample (0,0)"""
+        self.engine._check(self.engine.L.hmme_plane_upload_async(self.h, host_ptr, stride, sample_bytes, stream))
+
+    @property
+    def device_address(self):
+        return int(self.engine.L.hmme_debug_device_address(self.engine.h, self.h))
 
     def set_device_u8(self, dptr, pitch, stream=0):
         self.engine._check(self.engine.L.hmme_plane_set_device_u8(self.h, dptr, pitch, stream))
@@ -281,6 +301,29 @@ class Engine:
         arr = (C.c_void_p * len(refs))(*[r.h for r in refs])
         self._check(self.L.hmme_search_frame_multi_device(self.h, cur.h, arr, len(refs), C.byref(fp), d_pred, d_mv, d_sad, stream))
 
+    def search_pairs_device(self, curs, refs, fp, d_pred, d_mv, d_sad, stream=0):
+        """up to 16 (current, reference) picture pairs of one size in one launch (hmme_search_pairs_device)"""
+        assert len(curs) == len(refs)
+        ca = (C.c_void_p * len(curs))(*[c.h for c in curs])
+        ra = (C.c_void_p * len(refs))(*[r.h for r in refs])
+        self._check(self.L.hmme_search_pairs_device(self.h, ca, ra, len(refs), C.byref(fp), d_pred, d_mv, d_sad, stream))
+
+    def refine_pairs_device(self, curs, refs, fp, d_pred, d_int_mv, use_hadamard, d_qmv, d_cost, stream=0):
+        assert len(curs) == len(refs)
+        ca = (C.c_void_p * len(curs))(*[c.h for c in curs])
+        ra = (C.c_void_p * len(refs))(*[r.h for r in refs])
+        self._check(self.L.hmme_refine_pairs_device(self.h, ca, ra, len(refs), C.byref(fp), d_pred, d_int_mv, int(use_hadamard),
+                                                    d_qmv, d_cost, stream))
+
+    def upload_status(self, stream=0):
+        """waits for `stream`; raises if an asynchronous upload carried an out-of-range sample"""
+        self._check(self.L.hmme_upload_status(self.h, stream))
+
+    @property
+    def call_block_address(self):
+        """device address of the per-CTU call's current-block staging area (high-address test)"""
+        return int(self.L.hmme_debug_device_address(self.h, None))
+
     def search_frame_device(self, cur, ref, fp, d_pred, d_mv, d_sad, stream=0):
         self._check(self.L.hmme_search_frame_device(self.h, cur.h, ref.h, C.byref(fp), d_pred, d_mv, d_sad, stream))
 
@@ -289,6 +332,11 @@ class Engine:
         self._check(self.L.hmme_time_search_kernel(self.h, cur.h, ref.h, C.byref(fp), d_pred, d_mv, d_sad, stream, reps,
                                                    C.byref(ms)))
         return float(ms.value)
+
+
+def build_id():
+    """identifies the kernel sources + flags the loaded library was built from (hmme_build_id)"""
+    return load().hmme_build_id().decode()
 
 
 def ocl_compat_params(lt_x, lt_y, sr):

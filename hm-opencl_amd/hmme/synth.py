@@ -53,6 +53,44 @@ def make_pair(width, height, seed=1234, bit_depth=8, max_mv=12, region=128, nois
     return pad_plane(cur, margin), pad_plane(ref, margin), mv
 
 
+class Sequence:
+    """Synthetic sequence for the open-loop sequence driver (tools/me_sequence.py, BASELINE config 4): picture t is ONE base
+    texture translated by t * step, so the best 64x64 MV of the pair (cur, ref) is (ref - cur) * step wherever the window reaches
+    it.  Pictures are unpadded (height, width) uint8 / uint16 arrays -- what a YUV file holds; padding happens on the device.
+    Equal to make_pair(..., max_mv=0, noise_sigma=0, shift=(3t, 2t), pad=3 * n_frames + 4)[0] without its margin."""
+
+    def __init__(self, width, height, n_frames, seed=777, bit_depth=8, step=(3, 2)):
+        self.width, self.height, self.n_frames, self.bit_depth, self.step = width, height, n_frames, bit_depth, step
+        rng = np.random.default_rng(seed)
+        maxv = (1 << bit_depth) - 1
+        g = self.g = max(step) * n_frames + 4
+        base = _box5(rng.integers(0, 256, size=(height + 2 * g, width + 2 * g)).astype(np.float64))
+        lo, hi = base.min(), base.max()
+        self.base = np.clip(np.rint((base - lo) * (maxv / (hi - lo))), 0, maxv).astype(np.uint8 if bit_depth == 8 else np.uint16)
+
+    def luma(self, t):
+        g, (sx, sy) = self.g, self.step
+        return np.ascontiguousarray(self.base[g + sy * t:g + sy * t + self.height, g + sx * t:g + sx * t + self.width])
+
+    def read_into(self, t, out):
+        g, (sx, sy) = self.g, self.step
+        np.copyto(out, self.base[g + sy * t:g + sy * t + self.height, g + sx * t:g + sx * t + self.width])
+
+    def padded(self, t, margin=MARGIN):
+        """HM-style padded int16 plane of picture t (what the CPU oracle takes)"""
+        return pad_plane(self.luma(t), margin)
+
+    def write_yuv(self, path, chroma="420"):
+        """planar file like HM's input: 8-bit samples, or 16-bit little-endian words above 8 bit (TVideoIOYuv.cpp:247)"""
+        bps = 1 if self.bit_depth == 8 else 2
+        n_c = {"400": 0, "420": self.width * self.height // 2}[chroma]
+        grey = np.full(n_c, 1 << (self.bit_depth - 1), np.uint8 if bps == 1 else np.dtype("<u2")).tobytes()
+        with open(path, "wb") as f:
+            for t in range(self.n_frames):
+                f.write(self.luma(t).astype(np.uint8 if bps == 1 else np.dtype("<u2")).tobytes())
+                f.write(grey)
+
+
 def random_predictors(n_ctu, seed, max_pel=16):
     """seeded quarter-pel AMVP predictors, |pred| <= max_pel pels"""
     rng = np.random.default_rng(seed)

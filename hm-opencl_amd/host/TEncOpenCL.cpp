@@ -9,7 +9,7 @@
 
 TEncOpenCL::TEncOpenCL()
     : m_ctx(0), m_deviceId(0), m_deviceFound(false), m_enabled(false), m_lastOk(false), m_searchRange(0),
-      m_mode(ME_MODE_OCL_COMPAT), m_fen(false), m_bitDepth(0), m_bi(0), m_lambda(0.0), m_calls(0), m_failed(0), m_edgeCalls(0),
+      m_mode(ME_MODE_OCL_COMPAT), m_fen(false), m_bitDepth(0), m_inferredDepth(8), m_bi(0), m_lambda(0.0), m_calls(0), m_failed(0), m_edgeCalls(0),
       m_biCalls(0), m_verified(0), m_verifyFailed(0), m_refine(false), m_refineHad(true), m_fracOk(false),
       m_fracMvTab(0), m_fracDistTab(0), m_fracCostTab(0) {
   for (Int b = 0; b < 2; b++) {
@@ -47,6 +47,10 @@ Bool TEncOpenCL::verifyEnabled() {
 Bool TEncOpenCL::findDevice(Int device) {
   m_deviceId = device;
   m_deviceFound = device >= 0;
+  if (hmme_abi_version() != HMME_ABI_VERSION) {   // a libhmme.so older or newer than the header this file was compiled against
+    fprintf(stderr, "ERROR: TEncOpenCL::findDevice: libhmme ABI version %d, this module was built for %d\n", hmme_abi_version(), HMME_ABI_VERSION);
+    m_deviceFound = false;
+  }
   return m_deviceFound;
 }
 
@@ -110,14 +114,23 @@ Void TEncOpenCL::calcMotionVectors(Pel* pelCtu, Pel* pelSearch, Int iRefStride, 
     p.bit_depth = m_bitDepth;
     if (m_bitDepth <= 0) {
       // nothing in the reference tree tells this class the bit depth (createBuffers has no such argument), and cl/sad.cl
-      // works on whatever Pel holds without a shift: take the sample width from the reference window itself
-      Int hi = 0;
+      // works on whatever Pel holds without a shift: take the sample width from the samples of the call -- the reference window
+      // AND the current block (a dark window under a bright block, a fade or a cut, must not pick too narrow a width).  The block
+      // may be a bi-prediction origin 2*org - pred (TEncSearch.cpp:3702-3712), so it only has to fit [-maxv, 2*maxv]: such a call
+      // never widens the estimate beyond the true depth.  The width is latched (only ever grows), so one sequence does not
+      // alternate between the 8-bit and the 16-bit kernel; with shift-free sums the results do not depend on it.
+      Int hi = 0, chi = 0, clo = 0;
       const Int side = 2 * i_areaSize + 64;   // the window the reference copies, TEncOpenCL.cpp:253-277
       const Pel* row = pelSearch + (long)p.lt_y * iRefStride + p.lt_x;
       for (Int y = 0; y < side; y++, row += iRefStride)
         for (Int x = 0; x < side; x++) hi = row[x] > hi ? row[x] : hi;
-      p.bit_depth = 8;
-      while (p.bit_depth < 12 && hi > (1 << p.bit_depth) - 1) ++p.bit_depth;
+      row = pelCtu;
+      for (Int y = 0; y < HMME_CTU_SIZE; y++, row += iCtuStride)
+        for (Int x = 0; x < HMME_CTU_SIZE; x++) { chi = row[x] > chi ? row[x] : chi; clo = row[x] < clo ? row[x] : clo; }
+      Int d = m_inferredDepth;
+      while (d < 12 && (hi > (1 << d) - 1 || chi > 2 * ((1 << d) - 1) || clo < -((1 << d) - 1))) ++d;
+      m_inferredDepth = d;
+      p.bit_depth = d;
     }
   } else {
     p.lt_x = pcMvSrchRngLT->getHor(); p.lt_y = pcMvSrchRngLT->getVer();

@@ -53,8 +53,10 @@ class TEncOpenCL {
   Void setSearchRangeRB(const TComMv& rb) { m_rb = rb; }            // cMvSrchRngRB, TEncSearch.cpp:3732
   Void setFastEnc(Bool b) { m_fen = b; }                            // getUseFastEnc(), TEncSearch.cpp:3853
   /// sample bit depth (SPS).  0 = unknown (the default: nothing in the reference tree tells this class): ME_MODE_OCL_COMPAT
-  /// then derives the sample width from the reference window and, like cl/sad.cl, never shifts the SAD; ME_MODE_HM assumes 8.
+  /// then derives the sample width from the samples of each call (reference window and current block), keeps the largest seen so
+  /// far and, like cl/sad.cl, never shifts the SAD; ME_MODE_HM assumes 8.
   Void setBitDepth(Int b) { m_bitDepth = b; }
+  Int getInferredBitDepth() const { return m_inferredDepth; }
   /// results in TComMv layout, ready for memcpy into TEncSearch::allMotionVectors[list][refIdx]
   const TComMv* getMvs() const { return m_tab[m_bi].mv; }
   Bool lastCallOk() const { return m_lastOk; }
@@ -138,6 +140,7 @@ class TEncOpenCL {
   TComMv m_pred, m_rb;
   Bool m_fen;
   Int m_bitDepth;
+  Int m_inferredDepth;                 // ME_MODE_OCL_COMPAT without setBitDepth: widest sample width seen so far (>= 8)
   Int m_bi;
   Double m_lambda;
   long m_calls, m_failed, m_edgeCalls, m_biCalls, m_verified, m_verifyFailed;

@@ -36,8 +36,10 @@
  * Streams: a context owns scratch (job tables, merge tables, staging) that every frame call reuses, and planes are filled
  * asynchronously by hmme_plane_set_device_u8.  The library orders these itself: a *_device call issued on another stream than the
  * context's previous frame call first waits -- on the device, with hipStreamWaitEvent, never blocking the host -- for that call's
- * last use of the scratch, and every search / refinement waits for the last fill of each plane it reads if that fill ran on
- * another stream.  So calls of one context may be spread over streams; they serialise where they share scratch.  Output buffers
+ * last use of the scratch, every search / refinement waits for the last fill of each plane it reads if that fill ran on
+ * another stream, and every fill / upload of a plane waits for the last search / refinement that read it on another stream (so a
+ * ring of planes can be refilled on a copy stream while the compute stream is still searching older contents: tools/me_sequence.py
+ * --stream).  So calls of one context may be spread over streams; they serialise where they share scratch.  Output buffers
  * are the caller's: reading d_out_* on another stream than the one passed in needs the caller's own event.  The synchronous
  * host-facing calls run on a private non-blocking stream of the context and return when done.
  * Every function returns HMME_OK (0) or a negative HMME_ERR_* code; nothing ever falls back
@@ -52,6 +54,16 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+/* Bumped whenever a struct of this header changes layout or an entry point changes meaning; hmme_abi_version() returns the value the
+ * library was built with.  TEncOpenCL::findDevice and hmme/api.py refuse a library whose version differs from the header they were
+ * written against (hmme_search_params grew by `shift_free` in version 2: a caller built against version 1 would have the library
+ * read 4 bytes past its struct).  3: hmme_search_pairs_device / hmme_refine_pairs_device, asynchronous uploads, bi-prediction
+ * origins in the refinement calls. */
+#define HMME_ABI_VERSION 3
+int hmme_abi_version(void);
+/* identifies the kernel sources + build flags the library was compiled from (bench.py ties committed counter summaries to it) */
+const char* hmme_build_id(void);
 
 #define HMME_NUM_CTU_PARTS 593 /* TLibCommon/TypeDef.h:263 */
 #define HMME_CTU_SIZE 64
@@ -149,6 +161,15 @@ void hmme_plane_destroy(hmme_plane* plane);
  * rejected with HMME_ERR_RANGE */
 int hmme_plane_upload_pel(hmme_plane* plane, const int16_t* origin, int stride);
 int hmme_plane_upload_u8(hmme_plane* plane, const uint8_t* origin, int stride);
+/* The same upload, asynchronous on `stream` (hipStream_t): returns once the copy and the border extension are enqueued.  origin:
+ * samples of sample_bytes 1 (u8) or 2 (HM's Pel / the little-endian words of a 16-bit YUV file, TVideoIOYuv.cpp:247); any plane
+ * bit depth.  The host buffer must stay untouched until the copy has run (the caller's event on `stream`) and should be page-locked
+ * (hmme_host_register), otherwise the runtime stages it and the call blocks.  Ordering against searches that still read the
+ * plane's previous contents on another stream is the library's (see "Streams").  A sample outside the plane's range cannot be
+ * reported by this call: it is latched and returned -- once -- by the next hmme_upload_status (or synchronous upload). */
+int hmme_plane_upload_async(hmme_plane* plane, const void* origin, int stride, int sample_bytes, void* stream);
+/* waits for `stream`; HMME_ERR_RANGE if an upload since the last check carried an out-of-range sample */
+int hmme_upload_status(hmme_ctx* ctx, void* stream);
 /* Optional: page-lock a long-lived host buffer (e.g. the TComPicYuv planes of the decoded picture buffer,
  * TComPicYuv.cpp:80-133) so that uploads from it run at PCIe rate instead of through the runtime's pageable staging.
  * The buffer must stay allocated until hmme_host_unregister; uploads work with or without registration. */
@@ -182,6 +203,13 @@ int hmme_search_frame_multi_device(hmme_ctx* ctx, const hmme_plane* cur, const h
                                    const hmme_frame_params* fp, const void* d_pred_q, void* d_out_mv, void* d_out_sad,
                                    void* stream);
 
+/* Several (current, reference) picture PAIRS of one size in one launch (<= 16): an open-loop pass over a sequence (BASELINE config 4:
+ * the pairs of cfg/encoder_randomaccess_main.cfg:28-31) searches small pictures several pairs at a time -- a single 1080p pair is
+ * 510 workgroups, less than one round of the chip's 512 slots.  hmme_search_frame_multi_device is the case curs[i] == cur.
+ * pred_q: int16[n_pairs][n_ctu][2] or NULL; out_mv: int16[n_pairs][count][593][2]; out_sad: uint32[n_pairs][count][593] */
+int hmme_search_pairs_device(hmme_ctx* ctx, const hmme_plane* const* curs, const hmme_plane* const* refs, int n_pairs,
+                             const hmme_frame_params* fp, const void* d_pred_q, void* d_out_mv, void* d_out_sad, void* stream);
+
 /* ---- fractional-pel refinement: the step after the integer search ------------------------------------------
  * TEncSearch::xPatternSearchFracDIF (TEncSearch.cpp:4294-4331) for every slot of every CTU: half- then quarter-pel
  * refinement around the slot's integer MV with HM's 8-tap interpolation, Hadamard (HadamardME = 1, xGetHADs) or SAD
@@ -195,7 +223,14 @@ int hmme_refine_frame_multi_device(hmme_ctx* ctx, const hmme_plane* cur, const h
                                    const hmme_frame_params* fp, const void* d_pred_q, const void* d_int_mv, int use_hadamard,
                                    void* d_out_qmv, void* d_out_cost, void* stream);
 
-/* ---- measurement helpers (bench.py) ------------------------------------------------------ */
+int hmme_refine_pairs_device(hmme_ctx* ctx, const hmme_plane* const* curs, const hmme_plane* const* refs, int n_pairs,
+                             const hmme_frame_params* fp, const void* d_pred_q, const void* d_int_mv, int use_hadamard,
+                             void* d_out_qmv, void* d_out_cost, void* stream);
+
+/* ---- measurement / test helpers ------------------------------------------------------------ */
+/* device address of a plane's sample (0,0) (plane != NULL) or of the context's per-CTU current-block staging area: lets a test
+ * prove that a launch ran on addresses whose low dword has bit 31 set (tests/test_gpu_parity.py, high-address case) */
+uint64_t hmme_debug_device_address(const hmme_ctx* ctx, const hmme_plane* plane);
 /* average device time in ms of the search kernel over `reps` back-to-back launches on `stream`,
  * measured with hipEvents recorded on that stream */
 int hmme_time_search_kernel(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp,

@@ -211,6 +211,40 @@ int main() {
       bad += me10.getX()[i] != ox[i] || me10.getY()[i] != oy[i] || me10.getRuiCost()[i] != osad[i];
     if (bad) { fprintf(stderr, "10-bit compat mode: %d slots differ from the oracle\n", bad); failures += bad; }
     if (osad[592] < 300000) { fprintf(stderr, "10-bit sums look shifted (%u)\n", osad[592]); ++failures; }
+    // a dark reference window (max <= 255) under a bright 10-bit block (> 2 * 255), as on a fade or a scene cut, on a FRESH object:
+    // the width must come from the block too, or the call is rejected as out of range and the encoder gets poisoned tables
+    TEncOpenCL meDark;
+    if (!meDark.findDevice(0) || !meDark.compileKernelSource("cl/sad.cl", "calcSAD_AMP") || !meDark.createBuffers(64, 64, SR)) return 2;
+    meDark.setLambda(lambda);
+    std::vector<Pel> dark(ref.size());
+    for (size_t i = 0; i < dark.size(); ++i) dark[i] = (Pel)(rnd() & 127);
+    Pel* cb = &c10[(M + cu_y) * stride + M + cu_x];
+    cb[5 * stride + 7] = 1023;
+    meDark.calcMotionVectors(cb, &dark[(M + cu_y) * stride + M + cu_x], stride, stride, SR, &lt);
+    if (!meDark.lastCallOk()) { fprintf(stderr, "dark window / bright block: call rejected\n"); ++failures; }
+    if (meDark.getInferredBitDepth() != 10) { fprintf(stderr, "dark window / bright block: inferred %d bits\n", meDark.getInferredBitDepth()); ++failures; }
+    hmo_search_ctu(cb, stride, &dark[(M + cu_y) * stride + M + cu_x], stride, &p, ox, oy, osad, NULL);
+    bad = 0;
+    for (int i = 0; i < NUM_CTU_PARTS; i++) bad += meDark.getX()[i] != ox[i] || meDark.getY()[i] != oy[i] || meDark.getRuiCost()[i] != osad[i];
+    if (bad) { fprintf(stderr, "dark window / bright block: %d slots differ from the oracle\n", bad); failures += bad; }
+    // ... and the width stays latched: a dark block over the same dark window afterwards still runs as 10-bit content, same results
+    std::vector<Pel> dcur(64 * 64);
+    for (size_t i = 0; i < dcur.size(); ++i) dcur[i] = (Pel)(rnd() & 127);
+    meDark.calcMotionVectors(&dcur[0], &dark[(M + cu_y) * stride + M + cu_x], stride, 64, SR, &lt);
+    if (!meDark.lastCallOk() || meDark.getInferredBitDepth() != 10) { fprintf(stderr, "width not latched (%d)\n", meDark.getInferredBitDepth()); ++failures; }
+    hmo_search_ctu(&dcur[0], 64, &dark[(M + cu_y) * stride + M + cu_x], stride, &p, ox, oy, osad, NULL);
+    bad = 0;
+    for (int i = 0; i < NUM_CTU_PARTS; i++) bad += meDark.getX()[i] != ox[i] || meDark.getY()[i] != oy[i] || meDark.getRuiCost()[i] != osad[i];
+    if (bad) { fprintf(stderr, "latched width: %d slots differ from the oracle\n", bad); failures += bad; }
+    // an 8-bit bi-prediction origin (samples in [-255, 510]) through the unmodified call sites must NOT widen the estimate
+    TEncOpenCL me8;
+    if (!me8.findDevice(0) || !me8.compileKernelSource("cl/sad.cl", "calcSAD_AMP") || !me8.createBuffers(64, 64, SR)) return 2;
+    me8.setLambda(lambda);
+    std::vector<Pel> bi8(64 * 64);
+    for (size_t i = 0; i < bi8.size(); ++i) bi8[i] = (Pel)(2 * (Pel)(rnd() & 255) - (Pel)(rnd() & 255));
+    bi8[0] = 510; bi8[1] = -255;
+    me8.calcMotionVectors(&bi8[0], &ref[(M + cu_y) * stride + M + cu_x], stride, 64, SR, &lt);
+    if (!me8.lastCallOk() || me8.getInferredBitDepth() != 8) { fprintf(stderr, "8-bit bi-prediction origin: ok %d, inferred %d bits\n", (int)me8.lastCallOk(), me8.getInferredBitDepth()); ++failures; }
   }
   // error behaviour: a sample outside [0,255] is reported, results flagged not-ok, no crash
   cur[(M)*stride + M] = 9999;   // beyond any bit depth the class could derive

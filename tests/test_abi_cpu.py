@@ -87,7 +87,7 @@ def test_generated_isa_has_no_dpp_hazard():
     csrc = os.path.join(ROOT, "hm-opencl_amd", "csrc")
     r = subprocess.run(["make", "-C", csrc, "check-isa"], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "0 hazard(s)" in r.stdout
+    assert "0 hazard(s)" in r.stdout and "0 SGPR(s) touched" in r.stdout
 
 
 def test_dpp_hazard_checker_treats_branch_targets_as_joins(tmp_path):
@@ -108,6 +108,26 @@ def test_dpp_hazard_checker_treats_branch_targets_as_joins(tmp_path):
     assert run("\tv_add_u32 v9, v3, v4\n\ts_nop 1\n.LBB0_3:\n" + dpp).returncode == 1             # join: unknown writer + branch
     assert run("\tv_add_u32 v9, v3, v4\n.LBB0_3:\n\ts_nop 0\n" + dpp).returncode == 0             # ... padded once: fine
     assert run("\tv_add_u32 v9, v3, v4\n.LBB0_3:\n\tv_mov_b32 v7, v8\n" + dpp).returncode == 0
+
+
+def test_isa_checker_flags_sgprs_touched_while_a_scalar_load_is_pending(tmp_path):
+    """tools/check_dpp_hazard.py, second check: the inline-asm s_load_dword* are invisible to the compiler; nothing may read or
+    write their destination before the next `s_waitcnt lgkmcnt(0)` (scalar loads return out of order: lgkmcnt(N > 0) retires none)"""
+    import subprocess
+    import sys
+    tool = os.path.join(ROOT, "tools", "check_dpp_hazard.py")
+
+    def run(body):
+        p = tmp_path / "k.s"
+        p.write_text("kernel_a:\n" + body)
+        return subprocess.run([sys.executable, tool, str(p)], capture_output=True, text=True)
+    ld = "\ts_load_dwordx2 s[8:9], s[4:5], s6 offset:16\n"
+    assert run(ld + "\ts_waitcnt lgkmcnt(0)\n\tv_qsad_pk_u16_u8 v[0:1], v[2:3], s8, v[0:1]\n").returncode == 0
+    assert run(ld + "\tv_qsad_pk_u16_u8 v[0:1], v[2:3], s8, v[0:1]\n\ts_waitcnt lgkmcnt(0)\n").returncode == 1       # stale read
+    assert run(ld + "\ts_mul_i32 s9, s3, 7\n\ts_waitcnt lgkmcnt(0)\n").returncode == 1                              # destination reused
+    assert run(ld + "\ts_waitcnt lgkmcnt(1)\n\ts_add_u32 s2, s8, 1\n").returncode == 1                              # lgkmcnt(1) retires nothing
+    assert run(ld + "\ts_mul_i32 s6, s3, 7\n\ts_load_dwordx2 s[8:9], s[4:5], s6 offset:80\n\ts_waitcnt lgkmcnt(0)\n").returncode == 0   # prefetch pattern
+    assert run(ld + "\ts_load_dwordx2 s[10:11], s[4:5], s8 offset:80\n\ts_waitcnt lgkmcnt(0)\n").returncode == 1     # pending register as offset
 
 
 def test_cpu_side_code_is_clean_under_asan_and_ubsan(tmp_path):

@@ -397,7 +397,10 @@ def test_sequence_driver_single_gpu(tmp_path):
 @pytest.mark.parametrize("bd", [8, 10])
 def test_multi_reference_launch_equals_per_reference_searches(engine, bd):
     """hmme_search_frame_multi: the low-delay P structure searches 4 references per picture (reference
-    cfg/encoder_lowdelay_P_main.cfg:24-27); one launch must equal four single-reference searches"""
+    cfg/encoder_lowdelay_P_main.cfg:24-27); one launch must equal four single-reference searches.
+    NOTE: this compares the HIP path with ITSELF (batched launch vs single launches); the oracle comparison of a multi-reference
+    launch is in test_tail_plan_pictures_whose_searches_do_not_fill_whole_rounds (refs = 2) and, for launches of different
+    picture PAIRS, in tests/test_gpu_sequence.py::test_pairs_per_launch_equals_single_launches_and_oracle."""
     from hmme import synth
     w, h, sr = 256, 192, 16
     m = synth.MARGIN

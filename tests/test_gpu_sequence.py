@@ -1,0 +1,332 @@
+"""GPU tests of the sequence path (BASELINE.json config 4): picture pairs of a GOP searched pair-sharded, several pairs per
+launch, streamed through a ring of planes, gathered with RCCL -- every table that comes out compared with the CPU oracle."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+TOOL = os.path.join(ROOT, "tools", "me_sequence.py")
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from hmme import api
+    e = api.Engine(0, 128)
+    yield e
+    e.close()
+
+
+def _run_tool(args, torchrun=False, env=None, timeout=900):
+    e = dict(os.environ)
+    e.update(env or {})
+    if torchrun:
+        import socket
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), TOOL] + args
+    else:
+        cmd = [sys.executable, TOOL] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=e)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1]
+    return json.loads(line)
+
+
+def _check_dump_against_oracle(oracle_lib, dump, seq, w, h, sr, bd, lq, n_threads=16):
+    """every dumped (pair, CTU, slot) against the oracle's exhaustive search of that picture pair"""
+    from hmme import synth
+    d = np.load(dump)
+    m = synth.MARGIN
+    c0, cn = int(d["ctu_first"]), d["mv"].shape[1]
+    padded = {}
+    for i, (cur, ref) in enumerate(d["pairs"].tolist()):
+        for t in (cur, ref):
+            if t not in padded:
+                padded[t] = seq.padded(t)
+        ox, oy, osad = oracle_lib.search_frame(padded[cur], padded[ref], (m, m), w, h, sr, None, lq, 1, bd, c0, cn, n_threads)
+        mv, sad = d["mv"][i], d["sad"][i]
+        bad = np.flatnonzero((mv[:, :, 0] != ox).any(axis=1) | (mv[:, :, 1] != oy).any(axis=1) | (sad != osad).any(axis=1))
+        assert bad.size == 0, f"pair {d['pair_index'][i]} ({cur}, {ref}): CTUs {bad[:10] + c0} differ from the oracle"
+    return d
+
+
+@pytest.mark.parametrize("mode", ["resident", "stream", "torchrun_rccl"])
+def test_config4_small_gathered_tables_vs_oracle(tmp_path, oracle_lib, mode):
+    """BASELINE config 4 at 640x448 x 6 pictures: the tables that come out of shard.gather_pair_results -- every pair of the
+    random-access GOP (cfg/encoder_randomaccess_main.cfg:28-31), every CTU, all 593 slots -- against the oracle.  `stream`:
+    pictures through a 4-slot plane ring, three pairs per launch, tables downloaded on a third stream; `torchrun_rccl`: the same
+    run under torchrun with one rank, the tables carried by all_gather_into_tensor on RCCL."""
+    from hmme import shard, synth
+    w, h, n, sr = 640, 448, 6, 16
+    dump = os.path.join(tmp_path, "t.npz")
+    args = ["--frames", str(n), "--gop", "randomaccess", "--size", f"{w}x{h}", "--search-range", str(sr), "--dump", dump]
+    if mode == "stream":
+        args += ["--stream", "--slots", "5", "--pairs-per-launch", "3", "--download"]
+    d = _run_tool(args, torchrun=(mode == "torchrun_rccl"), env={"HMME_SEQ_FORCE_DIST": "1"} if mode == "torchrun_rccl" else None)
+    pairs = shard.gop_pairs(n, "randomaccess")
+    assert d["pairs"] == len(pairs) == 9 and d["pair_list"] == [list(p) for p in pairs]
+    if mode == "torchrun_rccl":
+        assert "nccl" in d["mode"]["collective"]
+    if mode == "stream":
+        assert d["rank0"]["launches"] == 3 and d["rank0"]["plane_slots"] <= 5 and d["rank0"]["uploads"] >= 6
+    lq = oracle_lib.oracle().hmo_lambda_q16(57.9)
+    seq = synth.Sequence(w, h, n, seed=777, bit_depth=8)
+    out = _check_dump_against_oracle(oracle_lib, dump, seq, w, h, sr, 8, lq)
+    assert out["mv"].shape == (9, 70, 593, 2)
+    if mode == "stream":
+        assert bool(out["host_equal"]), "the tables the download stream delivered differ from the device tables"
+    # picture t is the texture displaced by (3t, 2t): the 64x64 winner of pair (cur, ref) is (3, 2) * (cur - ref)
+    for (cur, ref), med in zip(pairs, d["median_mv_64x64"]):
+        assert med == [3 * (cur - ref), 2 * (cur - ref)]
+
+
+def test_config4_full_size_2160p_64_pictures(tmp_path, oracle_lib):
+    """BASELINE config 4 itself on one GPU: 3840x2160, 64 pictures, random-access GOP = 124 picture pairs, SR 64.  Every pair's
+    median 64x64 MV is the planted displacement; one CTU row of three pairs (the first, a B picture with a forward reference,
+    the last) equals the oracle in all 593 slots."""
+    from hmme import shard, synth
+    w, h, n, sr = 3840, 2160, 64, 64
+    pairs = shard.gop_pairs(n, "randomaccess")
+    assert len(pairs) == 124
+    fwd = next(i for i, (c, r) in enumerate(pairs) if r > c and c % 4 == 1)      # POC 4k+1 referencing 4k+4 (+3)
+    sel = [0, fwd, len(pairs) - 1]
+    dump = os.path.join(tmp_path, "t.npz")
+    d = _run_tool(["--frames", str(n), "--gop", "randomaccess", "--size", "2160p", "--search-range", str(sr), "--dump", dump,
+                   "--dump-pairs", ",".join(str(i) for i in sel), "--dump-ctus", f"{60 * 17}:60"])
+    assert d["pairs"] == 124 and d["gpus"] == 1 and d["rank0"]["launches"] == 124
+    for (cur, ref), med in zip(pairs, d["median_mv_64x64"]):
+        assert med == [3 * (cur - ref), 2 * (cur - ref)], (cur, ref, med)
+    lq = oracle_lib.oracle().hmo_lambda_q16(57.9)
+    seq = synth.Sequence(w, h, n, seed=777, bit_depth=8)
+    out = _check_dump_against_oracle(oracle_lib, dump, seq, w, h, sr, 8, lq)
+    assert out["mv"].shape == (3, 60, 593, 2) and pairs[fwd][1] - pairs[fwd][0] == 3
+    assert d["pairs_per_s"] > 100      # ~2.6 ms per pair resident; a generous floor that still catches a serialised path
+
+
+@pytest.mark.parametrize("bd,w,h,n,sr,k,slots", [(8, 832, 480, 10, 32, 2, 4), (10, 640, 360, 6, 24, 1, 2)])
+def test_streamed_yuv_file_equals_resident_equals_oracle(tmp_path, oracle_lib, bd, w, h, n, sr, k, slots):
+    """the frame feeder end to end: an 8-bit and a 16-bit little-endian YUV file (TVideoIOYuv.cpp:247) read by
+    the reader thread into page-locked buffers, uploaded on the copy stream into a plane ring smaller than the sequence (the
+    two-slot ring of the 10-bit case re-uploads pictures: every refill there evicts a plane the previous launch read), searched
+    k pairs per launch and refined on the compute stream, tables downloaded on a third -- equal to the resident run of the same
+    file, and to the oracle for every pair, CTU and slot."""
+    from hmme import sequence, shard, synth
+    seq = synth.Sequence(w, h, n, seed=777, bit_depth=bd)
+    path = os.path.join(tmp_path, "seq.yuv")
+    seq.write_yuv(path)
+    base = ["--frames", str(n), "--gop", "randomaccess", "--size", f"{w}x{h}", "--search-range", str(sr), "--bit-depth", str(bd), "--yuv", path,
+            "--refine"]
+    d_res, d_str = os.path.join(tmp_path, "res.npz"), os.path.join(tmp_path, "str.npz")
+    r1 = _run_tool(base + ["--dump", d_res])
+    r2 = _run_tool(base + ["--dump", d_str, "--stream", "--slots", str(slots), "--pairs-per-launch", str(k), "--download"])
+    assert r1["mode"]["stream"] is False and r2["mode"]["stream"] is True and r2["rank0"]["plane_slots"] == slots
+    pairs = shard.gop_pairs(n, "randomaccess")
+    loads, _ = sequence.plan_plane_loads(pairs, sequence.plan_batches(pairs, k), slots)
+    assert r2["rank0"]["uploads"] == sum(len(l) for l in loads) and r1["rank0"]["uploads"] == n
+    if slots == 2:
+        assert r2["rank0"]["uploads"] > n, "a two-slot ring cannot hold the GOP's working set: pictures must have been re-uploaded"
+    a, b = np.load(d_res), np.load(d_str)
+    for k in ("mv", "sad", "qmv", "cost"):
+        assert np.array_equal(a[k], b[k]), f"streamed {k} tables differ from the resident ones"
+    assert bool(b["host_equal"])
+    lq = oracle_lib.oracle().hmo_lambda_q16(57.9)
+    out = _check_dump_against_oracle(oracle_lib, d_str, seq, w, h, sr, bd, lq)
+    # refinement of the streamed run against the oracle's xPatternSearchFracDIF, first and last pair
+    m = synth.MARGIN
+    for i in (0, out["mv"].shape[0] - 1):
+        cur, ref = (int(v) for v in out["pairs"][i])
+        oq, oc = oracle_lib.refine_frame(seq.padded(cur), seq.padded(ref), (m, m), w, h, out["mv"][i], None, lq, 1, bd, n_threads=16)
+        assert np.array_equal(out["qmv"][i], oq) and np.array_equal(out["cost"][i], oc)
+
+
+def _planes(engine, w, h, bd, imgs):
+    pls = []
+    for img in imgs:
+        pl = engine.plane(w, h, bd)
+        pl.upload_pel(img, (80, 80))
+        pls.append(pl)
+    return pls
+
+
+@pytest.mark.parametrize("bd,w,h,sr,k", [(8, 320, 192, 24, 3), (8, 1280, 720, 64, 4), (10, 256, 192, 16, 5), (8, 192, 128, 100, 2)])
+def test_pairs_per_launch_equals_single_launches_and_oracle(engine, oracle_lib, bd, w, h, sr, k):
+    """hmme_search_pairs_device / hmme_refine_pairs_device: k DIFFERENT (current, reference) pairs in one launch == k single
+    launches == the oracle (all CTUs at the small sizes, a CTU sample at 720p where the launch also has a tail plan)"""
+    import torch
+    from hmme import api, synth
+    engine.set_lambda(57.9)
+    lq = engine.lambda_q16
+    n_ctu = ((w + 63) // 64) * ((h + 63) // 64)
+    imgs = [synth.make_pair(w, h, seed=100 + i, bit_depth=bd, max_mv=min(sr, 9), region=64) for i in range(k)]
+    curs = _planes(engine, w, h, bd, [p[0] for p in imgs])
+    refs = _planes(engine, w, h, bd, [p[1] for p in imgs])
+    pred = np.stack([synth.random_predictors(n_ctu, seed=7 + i, max_pel=min(sr, 12)) for i in range(k)])
+    dev = torch.device("cuda", 0)
+    d_pred = torch.from_numpy(pred).to(dev)
+    d_mv = torch.zeros((k, n_ctu, 593, 2), dtype=torch.int16, device=dev)
+    d_sad = torch.zeros((k, n_ctu, 593), dtype=torch.int32, device=dev)
+    d_q = torch.zeros_like(d_mv)
+    d_c = torch.zeros_like(d_sad)
+    fp = api.FrameParams(sr, 1, bd, 0, n_ctu)
+    s = torch.cuda.current_stream().cuda_stream
+    engine.search_pairs_device(curs, refs, fp, d_pred.data_ptr(), d_mv.data_ptr(), d_sad.data_ptr(), s)
+    engine.refine_pairs_device(curs, refs, fp, d_pred.data_ptr(), d_mv.data_ptr(), 1, d_q.data_ptr(), d_c.data_ptr(), s)
+    torch.cuda.synchronize()
+    mv, sad = d_mv.cpu().numpy(), d_sad.cpu().numpy().view(np.uint32)
+    qmv, cost = d_q.cpu().numpy(), d_c.cpu().numpy().view(np.uint32)
+    sample = list(range(n_ctu)) if n_ctu <= 20 else [0, n_ctu // 2 + 3, n_ctu - 1]
+    for i in range(k):
+        mv1, sad1 = engine.search_frame(curs[i], refs[i], sr, pred[i])
+        assert np.array_equal(mv[i], mv1) and np.array_equal(sad[i], sad1), f"pair {i} of the batched launch differs from its own launch"
+        q1, c1 = engine.refine_frame(curs[i], refs[i], sr, mv1, pred[i])
+        assert np.array_equal(qmv[i], q1) and np.array_equal(cost[i], c1), f"pair {i}: batched refinement differs"
+        for ctu in sample:
+            ox, oy, osad = oracle_lib.search_frame(imgs[i][0], imgs[i][1], (80, 80), w, h, sr, pred[i], lq, 1, bd, ctu, 1, 1)
+            assert np.array_equal(mv[i, ctu, :, 0], ox[0]) and np.array_equal(mv[i, ctu, :, 1], oy[0]) and np.array_equal(sad[i, ctu], osad[0]), (i, ctu)
+    assert len({tuple(mv[i, 1, 592]) for i in range(k)}) > 1      # the pairs really differ
+    # argument checks: planes of another size / too many pairs
+    other = engine.plane(w + 64, h, bd)
+    with pytest.raises(api.HmmeError):
+        engine.search_pairs_device([curs[0], other], [refs[0], other], fp, None, d_mv.data_ptr(), d_sad.data_ptr(), s)
+    with pytest.raises(api.HmmeError):
+        engine.search_pairs_device([curs[0]] * 17, [refs[0]] * 17, fp, None, d_mv.data_ptr(), d_sad.data_ptr(), s)
+    other.close()
+    for pl in curs + refs:
+        pl.close()
+
+
+def test_plane_refill_on_another_stream_waits_for_the_search_that_reads_it(engine):
+    """write-after-read across streams (include/hmme.h "Streams"): a 2160p search (~2.5 ms) is enqueued on stream A, then the
+    plane it reads is refilled from page-locked memory on stream B (hmme_plane_upload_async, ~1 ms) without any host-side wait.
+    The first search must see the old picture in every CTU, a second one (stream A again) the new picture."""
+    import torch
+    from hmme import api, synth
+    w, h, sr = 3840, 2160, 64
+    engine.set_lambda(57.9)
+    seq = synth.Sequence(w, h, 3, seed=31)
+    a_img, b_img, c_img = seq.luma(0), seq.luma(1), seq.luma(2)
+    cur, ref = engine.plane(w, h), engine.plane(w, h)
+    cur.upload_u8(a_img)
+    ref.upload_u8(b_img)
+    want_b = engine.search_frame(cur, ref, sr)              # reference picture = b
+    ref.upload_u8(c_img)
+    want_c = engine.search_frame(cur, ref, sr)              # reference picture = c
+    assert not np.array_equal(want_b[0], want_c[0])
+    ref.upload_u8(b_img)
+    dev = torch.device("cuda", 0)
+    n_ctu = 2040
+    fp = api.FrameParams(sr, 1, 8, 0, n_ctu)
+    host_c = torch.from_numpy(c_img).pin_memory()
+    s_a, s_b = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = [(torch.zeros((n_ctu, 593, 2), dtype=torch.int16, device=dev), torch.zeros((n_ctu, 593), dtype=torch.int32, device=dev)) for _ in range(2)]
+    torch.cuda.synchronize()
+    for rep in range(3):                                     # a few rounds: b -> c -> b ...
+        first, second = (want_b, want_c) if rep % 2 == 0 else (want_c, want_b)
+        nxt = host_c if rep % 2 == 0 else torch.from_numpy(b_img).pin_memory()
+        engine.search_frame_device(cur, ref, fp, None, outs[0][0].data_ptr(), outs[0][1].data_ptr(), s_a.cuda_stream)
+        ref.upload_async(nxt.data_ptr(), w, 1, s_b.cuda_stream)          # no synchronisation in between
+        engine.search_frame_device(cur, ref, fp, None, outs[1][0].data_ptr(), outs[1][1].data_ptr(), s_a.cuda_stream)
+        torch.cuda.synchronize()
+        engine.upload_status(s_b.cuda_stream)
+        assert np.array_equal(outs[0][0].cpu().numpy(), first[0]) and np.array_equal(outs[0][1].cpu().numpy().view(np.uint32), first[1]), \
+            f"round {rep}: the search saw a plane that was being refilled on another stream"
+        assert np.array_equal(outs[1][0].cpu().numpy(), second[0]) and np.array_equal(outs[1][1].cpu().numpy().view(np.uint32), second[1]), \
+            f"round {rep}: the search after the refill did not see the new picture"
+    cur.close(); ref.close()
+
+
+def test_async_upload_reports_out_of_range_samples_once(engine):
+    import torch
+    from hmme import api
+    w, h = 128, 64
+    pl = engine.plane(w, h, 10)
+    good = torch.full((h, w), 1023, dtype=torch.int16).pin_memory()
+    bad = good.clone().pin_memory()
+    bad[5, 7] = 1024
+    s = torch.cuda.Stream()
+    pl.upload_async(good.data_ptr(), w, 2, s.cuda_stream)
+    engine.upload_status(s.cuda_stream)
+    pl.upload_async(bad.data_ptr(), w, 2, s.cuda_stream)
+    with pytest.raises(api.HmmeError, match="range"):
+        engine.upload_status(s.cuda_stream)
+    engine.upload_status(s.cuda_stream)                      # latched once, then clear
+    with pytest.raises(api.HmmeError):
+        pl.upload_async(good.data_ptr(), w, 3, s.cuda_stream)
+    pl.close()
+
+
+def test_searches_on_device_addresses_with_bit_31_set(oracle_lib):
+    """Pins the round-2 fault (gpurun_out/r02H): the kernels read the current block through scalar loads from a 64-bit base
+    assembled out of two readfirstlane halves; widening the `int` the builtin returns sign-extended a low half with bit 31 set
+    and the load went to 0xffffffff........  Whether a launch meets such an address depends on where hipMalloc puts a plane, so
+    this test walks the allocator (filler blocks of 192 MB) until planes AND a context's per-CTU staging block sit on addresses
+    whose low dword has bit 31 set -- asserted -- and then runs the frame path and the per-CTU call, 8- and 10-bit, against the
+    oracle on exactly those buffers."""
+    import torch
+    from hmme import api, synth
+    w, h, sr = 256, 192, 16
+    m = synth.MARGIN
+    lq = oracle_lib.oracle().hmo_lambda_q16(57.9)
+    dev = torch.device("cuda", 0)
+    fillers, tried = [], []
+    found = {}
+
+    def high(addr, span):       # every byte the kernels address from this base has bit 31 set
+        return (addr & 0x80000000) and ((addr + span) & 0x80000000) and ((addr & 0xffffffff) + span < (1 << 32))
+
+    graveyard = []              # nothing is freed while walking: a freed block's address would simply be handed out again
+    for step in range(64):
+        if len(found) == 3:
+            break
+        eng = api.Engine(0, 64)
+        p8, p10 = eng.plane(w, h, 8), eng.plane(w, h, 10)
+        graveyard.append((eng, p8, p10))
+        a = {"ctx": eng.call_block_address, "p8": p8.device_address, "p10": p10.device_address}
+        tried.append({k: hex(v) for k, v in a.items()})
+        if "ctx" not in found and high(a["ctx"], 8192):
+            found["ctx"] = eng
+        if "p8" not in found and high(a["p8"], 512 * 300):
+            found["p8"] = (eng, p8)
+        if "p10" not in found and high(a["p10"], 1024 * 300):
+            found["p10"] = (eng, p10)
+        fillers.append(torch.empty(192 << 20, dtype=torch.uint8, device=dev))
+    try:
+        assert len(found) == 3, f"no buffer with bit 31 set in its low address dword after {len(tried)} rounds: {tried[-6:]}"
+        for bd, key in ((8, "p8"), (10, "p10")):
+            eng, cur_plane = found[key]
+            assert cur_plane.device_address & 0x80000000
+            eng.set_lambda(57.9)
+            cur, ref, _ = synth.make_pair(w, h, seed=40 + bd, bit_depth=bd, max_mv=8, region=64)
+            cur_plane.upload_pel(cur, (m, m))
+            ref_plane = eng.plane(w, h, bd)
+            ref_plane.upload_pel(ref, (m, m))
+            mv, sad = eng.search_frame(cur_plane, ref_plane, sr, None, ctu_first=5, ctu_count=4)
+            ox, oy, osad = oracle_lib.search_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, bd, 5, 4, 4)
+            assert np.array_equal(mv[:, :, 0], ox) and np.array_equal(mv[:, :, 1], oy) and np.array_equal(sad, osad), f"{bd}-bit frame path"
+            q, c = eng.refine_frame(cur_plane, ref_plane, sr, mv, None, ctu_first=5, ctu_count=4)
+            oq, oc = oracle_lib.refine_frame(cur, ref, (m, m), w, h, mv, None, lq, 1, bd, 5, 4, 4)
+            assert np.array_equal(q, oq) and np.array_equal(c, oc), f"{bd}-bit refinement"
+            ref_plane.close()
+        eng = found["ctx"]
+        assert eng.call_block_address & 0x80000000
+        eng.set_lambda(57.9)
+        for bd in (8, 10):
+            cur, ref, _ = synth.make_pair(w, h, seed=50 + bd, bit_depth=bd, max_mv=8, region=64)
+            p = api.SearchParams(-sr, -sr, sr, sr, 3, -5, 1, bd)
+            mv, sad = eng.search_ctu(cur, (m + 64, m + 64), ref, (m + 64, m + 64), p)
+            op = oracle_lib.make_params((-sr, -sr), (sr, sr), (3, -5), lq, 1, bd)
+            ox, oy, osad = oracle_lib.search_ctu(cur, (m + 64, m + 64), ref, (m + 64, m + 64), op)
+            assert np.array_equal(mv[:, 0], ox) and np.array_equal(mv[:, 1], oy) and np.array_equal(sad, osad), f"{bd}-bit per-CTU call"
+    finally:
+        for eng, p8, p10 in graveyard:
+            p8.close(); p10.close(); eng.close()
+        del fillers
+        torch.cuda.empty_cache()

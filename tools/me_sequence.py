@@ -3,17 +3,21 @@
 (BASELINE.json config 4: 3840x2160, 64 pictures, randomaccess GOP, 8 x MI355X).
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
-        tools/me_sequence.py --frames 64 --gop randomaccess --size 2160p [--yuv file.yuv]
+        tools/me_sequence.py --frames 64 --gop randomaccess --size 2160p [--yuv file.yuv] [--bit-depth 10]
+                             [--stream] [--pairs-per-launch K] [--refine] [--download] [--dump out.npz]
 
-Every rank keeps the pictures it needs resident in HBM (a 64-picture 2160p sequence is 0.65 GB of the
-288 GB), searches pairs p = rank, rank+N, ... and the 593-entry tables of all pairs are gathered with one
-RCCL all-gather per table (hmme/shard.py).  Rank 0 prints a JSON summary.
+Rank r searches pairs r, r+N, ... (hmme/shard.py); the 593-entry tables of all pairs are gathered with one RCCL all-gather per
+table.  Default: every picture the rank needs is resident in HBM before the clock starts (a 64-picture 2160p sequence is 0.6 GB
+of the 288 GB).  --stream: pictures come from the file (or the generator) through a ring of plane slots while the GPU searches
+(hmme/sequence.py): reader thread -> page-locked buffers -> copy stream || compute stream || download stream; the clock then
+includes reading and uploading.  --pairs-per-launch K puts K picture pairs into one launch (small pictures do not fill the
+chip one pair at a time).  --dump writes tables (a subset with --dump-pairs / --dump-ctus) for the parity tests; this tool
+itself never touches the CPU oracle.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
 import sys
-import time
 
 import numpy as np
 
@@ -27,55 +31,108 @@ def main():
     ap.add_argument("--gop", default="randomaccess", choices=["randomaccess", "lowdelay_P"])
     ap.add_argument("--size", default="2160p")
     ap.add_argument("--search-range", type=int, default=64)
-    ap.add_argument("--yuv", default=None, help="planar 8-bit 4:2:0 file; synthetic frames if omitted")
+    ap.add_argument("--bit-depth", type=int, default=8, help="8: 8-bit file / planes; 9..12: 16-bit little-endian file, u16 planes")
+    ap.add_argument("--yuv", default=None, help="planar 4:2:0 file (8-bit samples, or 16-bit LE words with --bit-depth > 8); synthetic pictures if omitted")
+    ap.add_argument("--chroma", default="420", choices=["400", "420", "422", "444"])
+    ap.add_argument("--stream", action="store_true", help="stream pictures through a ring of plane slots instead of uploading all first")
+    ap.add_argument("--slots", type=int, default=0, help="plane slots of the ring (--stream); default max(8, 2K + 2)")
+    ap.add_argument("--pairs-per-launch", type=int, default=1)
+    ap.add_argument("--refine", action="store_true", help="also run the fractional-pel refinement of every pair (hmme_refine_pairs_device)")
+    ap.add_argument("--download", action="store_true", help="bring each batch's tables into page-locked host memory on a third stream")
+    ap.add_argument("--dump", default=None, help="rank 0 writes the gathered tables (npz) for the parity tests")
+    ap.add_argument("--dump-pairs", default=None, help="comma-separated pair indices to dump (default all)")
+    ap.add_argument("--dump-ctus", default=None, help="first:count CTU range to dump (default all)")
+    ap.add_argument("--repeat", type=int, default=1, help="run the pass this many times, report the last (the first includes allocations)")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
-    from hmme import api, shard, synth, yuv
+    from hmme import api, sequence, shard, synth, yuv
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or (os.environ.get("HMME_SEQ_FORCE_DIST") == "1" and "RANK" in os.environ)   # world 1: rehearses the RCCL gather
+    if use_dist:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
-    w, h = {"2160p": (3840, 2160), "1080p": (1920, 1080)}.get(args.size) or tuple(int(v) for v in args.size.split("x"))
+    w, h = {"2160p": (3840, 2160), "1080p": (1920, 1080), "720p": (1280, 720)}.get(args.size) or tuple(int(v) for v in args.size.split("x"))
+    bd = args.bit_depth
     pairs = shard.gop_pairs(args.frames, args.gop)
     mine = [pairs[p] for p in shard.pairs_for_rank(len(pairs), rank, world)]
-    eng = api.Engine(local, 64)
+    eng = api.Engine(local, max(64, args.search_range))
     eng.set_lambda(57.9)
-    planes = {}
-    for poc in sorted({f for pr in mine for f in pr}):
-        pl = eng.plane(w, h)
-        if args.yuv:
-            pl.upload_u8(yuv.read_luma(args.yuv, w, h, poc))
-        else:   # frame poc = texture translated by a per-frame global motion (synthetic sequence)
-            cur, _, _ = synth.make_pair(w, h, seed=777, max_mv=0, noise_sigma=0.0, shift=(3 * poc, 2 * poc),
-                                        pad=3 * args.frames + 4)
-            pl.upload_pel(cur, (synth.MARGIN, synth.MARGIN))
-        planes[poc] = pl
+    if args.yuv:
+        source = yuv.LumaFile(args.yuv, w, h, 8 if bd == 8 else 16, args.chroma)
+    else:   # picture t = one texture translated by (3t, 2t)
+        source = synth.Sequence(w, h, args.frames, seed=777, bit_depth=bd)
     n_ctu = api.load().hmme_num_ctus(w, h)
-    fp = api.FrameParams(args.search_range, 1, 8, 0, n_ctu)
-    stream = torch.cuda.current_stream().cuda_stream
+    res = None
+    for _ in range(max(1, args.repeat)):
+        res = None   # frees the previous pass's tables before the next allocates
+        if use_dist:
+            dist.barrier()
+        res = sequence.run_rank(eng, source, mine, w, h, bd, args.search_range, stream_mode=args.stream,
+                                pairs_per_launch=args.pairs_per_launch, refine=args.refine, download=args.download,
+                                n_slots=args.slots or None, device=dev)
+    dt = res["seconds"]
+    if use_dist:   # the slowest rank's time is the job's
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # the one exchange step: every rank's tables to every rank, in pair order (ranks with one pair fewer pad)
+    k = shard.pairs_per_rank(len(pairs), world)
 
-    def search_pair(p, out_mv, out_sad):
-        cur_poc, ref_poc = pairs[p]
-        eng.search_frame_device(planes[cur_poc], planes[ref_poc], fp, None, out_mv.data_ptr(), out_sad.data_ptr(), stream)
+    def padded(t):
+        if t.shape[0] == k:
+            return t
+        return torch.cat([t, torch.zeros((k - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)])
 
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    import time
     t0 = time.perf_counter()
-    mv, sad = shard.search_sequence(search_pair, len(pairs), n_ctu, dev)
+    if use_dist:
+        mv, sad = shard.gather_pair_results(padded(res["mv"]), padded(res["sad"]), len(pairs))
+        if args.refine:
+            qmv, cost = shard.gather_pair_results(padded(res["qmv"]), padded(res["cost"]), len(pairs))
+    else:
+        mv, sad = res["mv"], res["sad"]
+        if args.refine:
+            qmv, cost = res["qmv"], res["cost"]
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    gather_s = time.perf_counter() - t0
     if rank == 0:
+        sads = 0   # 4x4-block SAD evaluations of one picture search (clipped windows at the picture edges)
+        for cy in range(0, h, 64):
+            for cx in range(0, w, 64):
+                ltx, lty, rbx, rby = api.set_search_range(0, 0, args.search_range, cx, cy, w, h)
+                sads += (min(64, w - cx) // 4) * (min(64, h - cy) // 4) * (rbx - ltx + 1) * (rby - lty + 1)
         m = mv[:, :, 592].to(torch.int32)
-        print(json.dumps({"pairs": len(pairs), "gpus": world, "seconds": round(dt, 4),
-                          "pairs_per_s": round(len(pairs) / dt, 2), "ctus_per_s": round(len(pairs) * n_ctu / dt, 1),
-                          "median_mv_64x64_of_first_pairs": [[int(m[i, :, 0].median()), int(m[i, :, 1].median())] for i in range(min(4, len(pairs)))],
-                          "first_pairs": pairs[:4]}))
-    if world > 1:
+        med = torch.stack([m[:, :, 0].median(dim=1).values, m[:, :, 1].median(dim=1).values], dim=1).cpu().tolist()
+        total = dt + gather_s
+        print(json.dumps({"pairs": len(pairs), "gpus": world, "seconds": round(dt, 4), "gather_seconds": round(gather_s, 4),
+                          "pairs_per_s": round(len(pairs) / total, 2), "ctus_per_s": round(len(pairs) * n_ctu / total, 1),
+                          "gsad_per_s": round(len(pairs) * sads / total / 1e9, 1),
+                          "mode": {"stream": bool(args.stream), "pairs_per_launch": args.pairs_per_launch, "refine": bool(args.refine),
+                                   "download": bool(args.download), "bit_depth": bd, "source": args.yuv or "synthetic",
+                                   "collective": "all_gather_into_tensor (nccl), world %d" % world if use_dist else "none (one rank)"},
+                          "size": [w, h], "search_range": args.search_range,
+                          "rank0": {"pairs": len(mine), "launches": res["launches"], "plane_slots": res["plane_slots"], "uploads": res["uploads"],
+                                    "stages": res["stages"]},
+                          "median_mv_64x64": med, "pair_list": pairs,
+                          "median_mv_64x64_of_first_pairs": med[:4], "first_pairs": pairs[:4]}))
+        if args.dump:
+            sel = [int(v) for v in args.dump_pairs.split(",")] if args.dump_pairs else list(range(len(pairs)))
+            c0, cn = (int(v) for v in args.dump_ctus.split(":")) if args.dump_ctus else (0, n_ctu)
+            d = {"pairs": np.array([pairs[i] for i in sel], np.int32), "pair_index": np.array(sel, np.int32), "ctu_first": c0,
+                 "mv": mv[sel, c0:c0 + cn].cpu().numpy(), "sad": sad[sel, c0:c0 + cn].cpu().numpy().view(np.uint32)}
+            if args.refine:
+                d["qmv"] = qmv[sel, c0:c0 + cn].cpu().numpy()
+                d["cost"] = cost[sel, c0:c0 + cn].cpu().numpy().view(np.uint32)
+            if args.download and world == 1:   # what the download stream delivered must equal the device tables
+                d["host_equal"] = bool(torch.equal(res["host_mv"], res["mv"].cpu()) and torch.equal(res["host_sad"], res["sad"].cpu()))
+            np.savez(args.dump, **d)
+    eng.close()
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

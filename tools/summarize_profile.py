@@ -3,7 +3,7 @@
    <tag>_kernel_stats_<label>.csv   rocprofv3 --kernel-trace --stats summary
    <tag>_pmc_summary_<label>.json   per-dispatch means of every counter, per engine kernel, + derived figures
 and refresh profiles/latest_pmc_<label>.json (read by bench.py for roofline.traffic / valu_roofline; it carries the hash of
-the kernel sources so that bench.py can tell whether the counters belong to the library it runs).
+the loaded library's hmme_build_id() so that bench.py can tell whether the counters belong to the library it runs).
 usage: summarize_profile.py <out_dir> <tag> <label>"""
 import collections
 import csv
@@ -89,9 +89,9 @@ for k, c in counters.items():
 
 try:
     import bench
-    summary["kernel_source_hash"] = bench.kernel_source_hash()
-except Exception as e:   # noqa: BLE001 -- the summary is still useful without the tie to the sources
-    summary["kernel_source_hash"] = None
+    summary["library_build_id"] = bench.library_build_id()
+except Exception as e:   # noqa: BLE001 -- the summary is still useful without the tie to the library
+    summary["library_build_id"] = None
     summary["hash_error"] = repr(e)
 p = os.path.join(prof, f"{tag}_pmc_summary_{label}.json")
 json.dump(summary, open(p, "w"), indent=1)
