@@ -96,7 +96,7 @@ def test_config4_full_size_2160p_64_pictures(tmp_path, oracle_lib):
     w, h, n, sr = 3840, 2160, 64, 64
     pairs = shard.gop_pairs(n, "randomaccess")
     assert len(pairs) == 124
-    fwd = next(i for i, (c, r) in enumerate(pairs) if r > c and c % 4 == 1)      # POC 4k+1 referencing 4k+4 (+3)
+    fwd = next(i for i, (c, r) in enumerate(pairs) if r - c == 3 and c > 32)      # a B picture POC 4k+1 referencing 4k+4 (+3)
     sel = [0, fwd, len(pairs) - 1]
     dump = os.path.join(tmp_path, "t.npz")
     d = _run_tool(["--frames", str(n), "--gop", "randomaccess", "--size", "2160p", "--search-range", str(sr), "--dump", dump,
