@@ -566,8 +566,8 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
     return fail(ctx, HMME_ERR_RANGE, "hmme_search_ctu: current-block sample outside [%d, %d] (bit depth %d)", -maxv, 2 * maxv, p->bit_depth);
   const bool wide = p->bit_depth > 8 || bipred_origin;
   const int bias = bipred_origin ? (1 << p->bit_depth) : 0;
-  // xPatternSearchFracDIF on 2*org - pred_other (the bBi pass) stays with the caller: the refinement kernel works on samples
-  if (refine && bipred_origin) return fail(ctx, HMME_ERR_UNSUPPORTED, "refinement of a bi-prediction origin (current-block samples outside [0, %d])", maxv);
+  // xPatternSearchFracDIF on 2*org - pred_other (the bBi pass, TEncSearch.cpp:3798 with bBi): the refinement kernel runs on the same
+  // biased u16 staging as the search; the bias passes HM's interpolation exactly and shifts its clip bounds (me_frac_eval)
   const int shift_bd = p->shift_free ? 8 : p->bit_depth;   // the kernels shift by (this - 8)
   const int sr_cap = ctx->sr_max;
   if (wx < 1 || wy < 1 || wx > 2 * sr_cap + 1 || wy > 2 * sr_cap + 1)
@@ -682,7 +682,7 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
     const int16_t* d_imv = do_search ? d_mv1 : (const int16_t*)(ctx->d_call + kCallImv);
     hipLaunchKernelGGL(fns[wide ? 1 : 0][refine_had ? 1 : 0], dim3(1), dim3(hmme::frac_threads(bps)), hmme::frac_lds_bytes(bps), s, one_ref(ctx->d_call + kCallCtu),
                        64 * bps, one_ref(ref_base), kWinPitch, (const MeJob*)(ctx->d_call + kCallFracJob), ctx->d_frac_cover, d_imv, ctx->lambda_q16,
-                       p->bit_depth, (int16_t*)(ctx->d_res + kResQmv), (uint32_t*)(ctx->d_res + kResCost));
+                       p->bit_depth | (bipred_origin ? 0x100 : 0), (int16_t*)(ctx->d_res + kResQmv), (uint32_t*)(ctx->d_res + kResCost));
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(hmme::me_publish_kernel, dim3(1), dim3(1), 0, s, (volatile uint32_t*)(ctx->d_res + kResDone2), seq);
     HIP_TRY(ctx, hipGetLastError());

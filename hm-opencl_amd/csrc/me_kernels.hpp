@@ -854,10 +854,11 @@ __global__ void me_prep_jobs_tile_kernel(MeJob16* jobs, int* first_strip_of_job,
 // quad_perm DPP butterflies, so slots whose size is a multiple of 8 (8x8 Hadamard blocks) and the others (4x4
 // blocks) run the same code.  Per-slot distortions accumulate in LDS (ds_add_u32); 593 threads then add the MV cost
 // and pick the winner in HM's point order (strict '<', tables TEncSearch.cpp:51-75).
-constexpr int kFracAcc = 593 * 9;
+// per-slot distortion sums of the nine refinement points
+constexpr int kFracAccRow = 9, kFracAcc = 593 * kFracAccRow, kFracAccDw = (kFracAcc + 15) & ~15;
 // BPS = bytes per sample of the planes (1: 8-bit video, 2: 9..12 bit)
 constexpr int frac_threads(int bps) { return 256; }
-constexpr size_t frac_lds_bytes(int bps) { return (size_t)(5344 + 600 + 160 + (64 * 18 + 256 * 6) / 2 + 1024 * bps) * 4; }
+constexpr size_t frac_lds_bytes(int bps) { return (size_t)(kFracAccDw + 600 + 160 + (64 * 18 + 256 * 6) / 2 + 1024 * bps) * 4; }
 
 __device__ __forceinline__ uint32_t me_mv_cost_q(uint32_t lambda_q16, int vx_q, int vy_q, int pred_x, int pred_y) {
   return (lambda_q16 * (me_component_bits(vx_q - pred_x) + me_component_bits(vy_q - pred_y))) >> 16;
@@ -887,6 +888,11 @@ __host__ __device__ constexpr uint32_t me_htap_dw(int q, int c, int k) {
   }
   return w;
 }
+// waves per SIMD of the 8-bit refinement kernel: it needs 194 VGPRs; capped at 168 (three waves) it spills 19 dwords per lane but the
+// third wave hides more latency than the spills cost (measured); the u16 kernel would spill 200 and stays at two
+#ifndef ME_FRAC_WAVES8
+#define ME_FRAC_WAVES8 3
+#endif
 constexpr int kFracTabH = 8, kFracTabV = 12;   // LDS tap tables: 7 rows (q = -3..3) of packed horizontal / float vertical taps
 
 #define ME_FRAC_BFLY(R, T, PERM) "v_fmac_f32_dpp " #R ", " #R ", " #T " quad_perm:" PERM " row_mask:0xf bank_mask:0xf\n\t"
@@ -908,7 +914,7 @@ constexpr float kRoundMagic = 12582912.0f;   // 1.5 * 2^23: x + magic rounds x t
 // KIND8: the lane is one quadrant (role 0..3 = TL, TR, BL, BR) of an 8x8 Hadamard block; all four lanes of the quad
 // return the block's distortion.  out[point]: distortion of the 9 refinement points in HM's point order.
 template <int STAGE, int HAD, int BPS, int KIND8>
-__device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3 * BPS], const float (&orgM)[16], int cqx, int cqy, int role, int bd,
+__device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3 * BPS], const float (&orgM)[16], int cqx, int cqy, int role, int bd, float clip_lo,
                                              const uint32_t* tab_h, const float* tab_v, uint32_t (&out)[9]) {
   constexpr int step = STAGE == 0 ? 2 : 1, PW = 3 * BPS;
   // point index of (dx, dy) in s_acMvRefineH / s_acMvRefineQ order (reference TEncSearch.cpp:51-75)
@@ -918,7 +924,10 @@ __device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3 * BPS], c
   const int off1 = BPS == 1 ? 0 : -(8192 << sh1);
   // second pass: floor((S + 2^(sh2-1) + (8192 << 6)) >> sh2) = nearest integer of (S + 524288 + 0.5) * 2^-sh2 (never a tie)
   const float sc2 = BPS == 1 ? 1.f / 4096.f : __int_as_float((127 - (20 - bd)) << 23);
-  const float maxv = BPS == 1 ? 255.f : (float)((1 << bd) - 1);
+  // clip_lo: 0, or the bias 2^bd that block and window of a bi-prediction origin carry (hmme.hip ctu_call).  The taps sum to 64, so a
+  // bias B = 2^bd passes both filter stages exactly (64 * B >> (bd - 8) = 2^14, 64 * 2^14 >> (20 - bd) = B): the predicted sample
+  // comes out as pred + B, is clipped to [B, B + maxv] and meets a current sample that carries the same B
+  const float maxv = clip_lo + (BPS == 1 ? 255.f : (float)((1 << bd) - 1));
 #pragma unroll
   for (int dxi = 0; dxi < 3; ++dxi) {
     uint32_t T[4][PW];
@@ -990,7 +999,7 @@ __device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3 * BPS], c
             if (STAGE == 0 && me_tap9(step * (dyi - 1), j) == 0) continue;
             a = __builtin_fmaf(cv[j], tmp[r + j][c], a);
           }
-          const float y = __builtin_amdgcn_fmed3f(a, 0.f, maxv);   // clip, then round (the bounds are integers)
+          const float y = __builtin_amdgcn_fmed3f(a, clip_lo, maxv);   // clip, then round (the bounds are integers)
           d[4 * r + c] = orgM[4 * r + c] - (y + kRoundMagic);
         }
       uint32_t contrib;
@@ -1065,7 +1074,7 @@ constexpr uint32_t kFracKey0 = 0x3ffffu, kFracKey1 = 0x3fffffu;
 // was no faster while it capped the search range at 64 and the occupancy at one 16-bit workgroup per CU.
 template <int STAGE, int HAD, int BPS, int KIND8>
 __device__ __forceinline__ void me_frac_item(const uint8_t* __restrict__ src, int gpitch, const uint32_t* curl, const uint32_t* st,
-                                             const uint16_t* __restrict__ cover, int pair, int role, int bd, const uint32_t* tab_h,
+                                             const uint16_t* __restrict__ cover, int pair, int role, int bd, float clip_lo, const uint32_t* tab_h,
                                              const float* tab_v, uint32_t* acc) {
   constexpr int PW = 3 * BPS, NCOV = KIND8 ? kFracCover8 : kFracCover4;
   constexpr uint32_t keymask = STAGE ? kFracKey1 : kFracKey0;
@@ -1106,13 +1115,17 @@ __device__ __forceinline__ void me_frac_item(const uint8_t* __restrict__ src, in
   }
   uint32_t dist[9];
   const int cqx = STAGE ? 2 * ((int)((sv >> 18) & 3) - 1) : 0, cqy = STAGE ? 2 * ((int)((sv >> 20) & 3) - 1) : 0;
-  me_frac_eval<STAGE, HAD, BPS, KIND8>(P, orgM, cqx, cqy, role, bd, tab_h, tab_v, dist);
-  // every slot of this position with the same key takes the distortions; the quad's lanes split the slot list
+  me_frac_eval<STAGE, HAD, BPS, KIND8>(P, orgM, cqx, cqy, role, bd, clip_lo, tab_h, tab_v, dist);
+  // Every slot of this position with the same key takes the distortions; the quad's lanes split the slot list.
+  // (Round 3 tried to relieve these adds -- the large slots cover many positions, so lanes of one wave often add to the same address:
+  // each quad starting its walk at another list position and two points per ds_add_u64 cut the kernel's LDS conflict cycles by 27 %
+  // and its LDS waits by 90 %, and changed its time by -2 % .. +3 %: LDS is busy 10 % of the CU cycles here, the kernel waits on its
+  // VALU chains and loads, not on these atomics.  profiles/r03d_frac_ab.txt)
   for (int j2 = j + (KIND8 ? role : 0); j2 < NCOV; j2 += KIND8 ? 4 : 1) {
     const int s2 = cov[j2];
     if (j2 == j || ((st[s2] ^ sv) & keymask) == 0) {
 #pragma unroll
-      for (int i = 0; i < 9; ++i) atomicAdd(&acc[s2 * 9 + i], dist[i]);
+      for (int i = 0; i < 9; ++i) atomicAdd(&acc[s2 * kFracAccRow + i], dist[i]);
     }
   }
 }
@@ -1135,14 +1148,18 @@ __device__ __forceinline__ void me_frac_dedupe(const uint32_t* st, const uint16_
 }
 
 template <int HAD, int BPS>
-__global__ void __launch_bounds__(frac_threads(BPS), 2)
+__global__ void __launch_bounds__(frac_threads(BPS), BPS == 1 ? ME_FRAC_WAVES8 : 2)
 me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitch,
                const MeJob* __restrict__ jobs, const uint16_t* __restrict__ cover, const int16_t* __restrict__ int_mv,
-               uint32_t lambda_q16, int bit_depth, int16_t* __restrict__ out_qmv, uint32_t* __restrict__ out_cost) {
+               uint32_t lambda_q16, int bit_depth_bias, int16_t* __restrict__ out_qmv, uint32_t* __restrict__ out_cost) {
+  // bit_depth_bias: bit depth in the low 8 bits; bit 8 set = block and window carry the bias 2^bitDepth of a bi-prediction origin
+  // (2*org - pred, TEncSearch.cpp:3702-3712: current samples in [-maxv, 2*maxv]; per-CTU calls only, u16 staging)
+  const int bit_depth = bit_depth_bias & 0xff;
+  const float clip_lo = (bit_depth_bias & 0x100) ? (float)(1 << bit_depth) : 0.f;
   constexpr int NT = frac_threads(BPS);
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  uint32_t* acc = smem;                 // [593][9] distortion sums of the current stage
-  uint32_t* st = smem + 5344;           // [593] slot state: (mx - lt_x) | (my - lt_y) << 9 | (half_x + 1) << 18 | (half_y + 1) << 20
+  uint32_t* acc = smem;                 // [593][kFracAccRow] distortion sums of the current stage
+  uint32_t* st = smem + kFracAccDw;     // [593] slot state: (mx - lt_x) | (my - lt_y) << 9 | (half_x + 1) << 18 | (half_y + 1) << 20
   uint32_t* tab_h = st + 600;           // [7][kFracTabH] packed horizontal taps of q = -3..3
   float* tab_v = (float*)(tab_h + 7 * kFracTabH);   // [7][kFracTabV] vertical taps
   uint32_t* counter = tab_h + 152;      // [2] lengths of the two work lists
@@ -1189,13 +1206,13 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
     const int n8 = 4 * (int)counter[0], n4 = (int)counter[1];
 #pragma unroll 1
     for (int i = tid; i < n8; i += NT) {   // whole quads: n8 and NT are multiples of 4
-      if (stage == 0) me_frac_item<0, HAD, BPS, 1>(src, ref_pitch, curl, st, cover, list8[i >> 2], tid & 3, bd, tab_h, tab_v, acc);
-      else me_frac_item<1, HAD, BPS, 1>(src, ref_pitch, curl, st, cover, list8[i >> 2], tid & 3, bd, tab_h, tab_v, acc);
+      if (stage == 0) me_frac_item<0, HAD, BPS, 1>(src, ref_pitch, curl, st, cover, list8[i >> 2], tid & 3, bd, clip_lo, tab_h, tab_v, acc);
+      else me_frac_item<1, HAD, BPS, 1>(src, ref_pitch, curl, st, cover, list8[i >> 2], tid & 3, bd, clip_lo, tab_h, tab_v, acc);
     }
 #pragma unroll 1
     for (int i = tid; i < n4; i += NT) {
-      if (stage == 0) me_frac_item<0, HAD, BPS, 0>(src, ref_pitch, curl, st, cover, list4[i], 0, bd, tab_h, tab_v, acc);
-      else me_frac_item<1, HAD, BPS, 0>(src, ref_pitch, curl, st, cover, list4[i], 0, bd, tab_h, tab_v, acc);
+      if (stage == 0) me_frac_item<0, HAD, BPS, 0>(src, ref_pitch, curl, st, cover, list4[i], 0, bd, clip_lo, tab_h, tab_v, acc);
+      else me_frac_item<1, HAD, BPS, 0>(src, ref_pitch, curl, st, cover, list4[i], 0, bd, clip_lo, tab_h, tab_v, acc);
     }
     __syncthreads();
     for (int s = tid; s < kParts; s += NT) {
@@ -1211,7 +1228,7 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
       for (int i = 0; i < 9; ++i) {
         const int ox = stage ? pq[i][0] : 2 * ph[i][0], oy = stage ? pq[i][1] : 2 * ph[i][1];
         // whole-PU distortion >> (bitDepth - 8) (TComRdCost.cpp:520-521, :1604), then the MV cost
-        const uint32_t d = (acc[s * 9 + i] >> (bd - 8)) + me_mv_cost_q(lambda_q16, bxq + ox, byq + oy, job.pred_x, job.pred_y);
+        const uint32_t d = (acc[s * kFracAccRow + i] >> (bd - 8)) + me_mv_cost_q(lambda_q16, bxq + ox, byq + oy, job.pred_x, job.pred_y);
         if (d < best) { best = d; bi = i; }
       }
       if (stage == 0) {

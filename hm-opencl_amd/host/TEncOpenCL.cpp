@@ -10,7 +10,7 @@
 TEncOpenCL::TEncOpenCL()
     : m_ctx(0), m_deviceId(0), m_deviceFound(false), m_enabled(false), m_lastOk(false), m_searchRange(0),
       m_mode(ME_MODE_OCL_COMPAT), m_fen(false), m_bitDepth(0), m_inferredDepth(8), m_bi(0), m_lambda(0.0), m_calls(0), m_failed(0), m_edgeCalls(0),
-      m_biCalls(0), m_verified(0), m_verifyFailed(0), m_refine(false), m_refineHad(true), m_fracOk(false),
+      m_biCalls(0), m_verified(0), m_verifyFailed(0), m_refine(false), m_refineHad(true), m_fracOk(false), m_fracBi(false),
       m_fracMvTab(0), m_fracDistTab(0), m_fracCostTab(0) {
   for (Int b = 0; b < 2; b++) {
     xPoison(m_tab[b]);   // tables nobody filled yet must not look like results either
@@ -144,10 +144,11 @@ Void TEncOpenCL::calcMotionVectors(Pel* pelCtu, Pel* pelSearch, Int iRefStride, 
   typedef char tcommv_is_two_shorts[sizeof(TComMv) == 4 ? 1 : -1];   // C++98-friendly static asserts
   typedef char distortion_is_u32[sizeof(Distortion) == 4 ? 1 : -1];
   (void)sizeof(tcommv_is_two_shorts); (void)sizeof(distortion_is_u32);
-  // refinement rides along on uni-prediction calls with HM's arithmetic; where the engine cannot refine (a bi-prediction origin
-  // slipped in, ...) the integer search still runs and fracOk() says so
-  const Bool wantFrac = m_refine && !m_bi && m_mode == ME_MODE_HM;
+  // refinement rides along on calls with HM's arithmetic, uni-prediction and bi-prediction origins alike (the bBi call of
+  // TEncSearch.cpp:3798); where the engine cannot refine the integer search still runs and fracOk() says so
+  const Bool wantFrac = m_refine && m_mode == ME_MODE_HM;
   m_fracOk = false;
+  m_fracBi = m_bi != 0;
   Int rc = HMME_ERR_UNSUPPORTED;
   if (wantFrac) {
     rc = hmme_search_refine_ctu(m_ctx, pelCtu, iCtuStride, pelSearch, iRefStride, &p, m_refineHad ? 1 : 0, reinterpret_cast<int16_t*>(t.mv),

@@ -71,12 +71,15 @@ class TEncOpenCL {
   const Distortion* getRuiCost(Bool bi) const { return m_tab[bi ? 1 : 0].cost; }
 
   // ---- additive: fractional-pel refinement tables ----
-  /// While on, every uni-prediction ME_MODE_HM call also runs TEncSearch::xPatternSearchFracDIF (TEncSearch.cpp:4294-4331) for the
+  /// While on, every ME_MODE_HM call also runs TEncSearch::xPatternSearchFracDIF (TEncSearch.cpp:4294-4331) for the
   /// 593 slots on the device (one engine call, hmme_search_refine_ctu): getQMvs() / getFracCost() then hold, per slot, the
   /// quarter-pel MV (int << 2) + (half << 1) + quarter and the ruiCost that function returns, MV cost priced against the CTU's
-  /// predictor.  fracOk() tells whether the last call produced them (bi-prediction origins and failed calls do not).
+  /// predictor.  fracOk() tells whether the last call produced them (failed calls do not).  A bi-prediction call (setBiPred(true):
+  /// the block is 2*org - pred_other) is refined as well -- HM's bBi pass runs xPatternSearchFracDIF on that origin
+  /// (TEncSearch.cpp:3798) -- and fracWasBi() tells which kind the tables of the last call belong to.
   Void setRefine(Bool on, Bool hadamard = true) { m_refine = on; m_refineHad = hadamard; }
   Bool fracOk() const { return m_fracOk; }
+  Bool fracWasBi() const { return m_fracBi; }
   const TComMv* getQMvs() const { return m_qmv; }
   const Distortion* getFracCost() const { return m_fracCost; }
   /// keep the refinement tables of the last call for [list][refIdx] (the caller's allMotionVectors / allRuiCost have no room for
@@ -147,7 +150,7 @@ class TEncOpenCL {
   TComMv m_lastLT, m_lastRB;
   Tables m_tab[2];                     // [0] uni-prediction, [1] bi-prediction refinement
   Int m_tagPoc[2][33], m_tagCtu[2][33];
-  Bool m_refine, m_refineHad, m_fracOk;
+  Bool m_refine, m_refineHad, m_fracOk, m_fracBi;
   TComMv m_qmv[NUM_CTU_PARTS];
   Distortion m_fracCost[NUM_CTU_PARTS];
   TComMv m_fracPred;                   // predictor the refinement of the last call priced its MVs against

@@ -144,7 +144,11 @@ int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
  * hmme_refine_ctu refines the caller's integer MVs int_mv[593][2] (entries outside the window LT..RB are clamped to it).
  * Unlike hmme_search_ctu these read the reference 4 samples (+ up to 3 for alignment) beyond the window (64 + 2*SR)^2 on every
  * side -- the interpolation filter's support, which xPatternSearchFracDIF reads as well (HM planes carry an 80-sample margin).
- * Bi-prediction origins (current-block samples outside [0, maxv]) are HMME_ERR_UNSUPPORTED here; shift_free is ignored. */
+ * Bi-prediction origins (current-block samples in [-maxv, 2*maxv]: the bBi pass, TEncSearch.cpp:3702-3712, :3798) are refined
+ * like any other block: the interpolated reference is clipped to the sample range, the origin is not.
+ * shift_free: hmme_search_refine_ctu's integer leg honours it (out_sad unshifted); the refinement never does -- out_cost is always
+ * HM's ((distortion >> (bitDepth-8)) + MV cost), so with shift_free = 1 at more than 8 bits the two outputs are on different
+ * scales.  HM-arithmetic callers leave it 0. */
 int hmme_search_refine_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref_at_ctu_origin, int ref_stride,
                            const hmme_search_params* p, int use_hadamard, int16_t* out_mv, uint32_t* out_sad, int16_t* out_qmv,
                            uint32_t* out_cost);

@@ -141,6 +141,8 @@ def ref():
         L.ref_frac_refine.argtypes = ([C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int16), C.c_int]
                                       + [C.c_int] * 4 + [C.c_double, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4
                                       + [C.POINTER(C.c_uint32)])
+        L.ref_frac_refine_bi.restype = None
+        L.ref_frac_refine_bi.argtypes = L.ref_frac_refine.argtypes
         _ref = L
     return _ref
 
@@ -258,17 +260,18 @@ def tz_frame(cur, ref_plane, origin, pic_w, pic_h, sr, pred_q, lambda_q16, fen, 
     return probes.value, s4.value
 
 
-def frac_refine(plane_cur, cur_xy, plane_ref, ref_xy, w, h, int_mv, pred, lam_or_q16, use_had, bit_depth, use_ref=False):
-    """xPatternSearchFracDIF for one PU: the oracle (lam_or_q16 = lambda_q16) or the reference (lam_or_q16 = lambda).
-    -> (half_x, half_y, qter_x, qter_y, cost)"""
+def frac_refine(plane_cur, cur_xy, plane_ref, ref_xy, w, h, int_mv, pred, lam_or_q16, use_had, bit_depth, use_ref=False, bi=False):
+    """xPatternSearchFracDIF for one PU: the oracle (lam_or_q16 = lambda_q16) or the reference (lam_or_q16 = lambda; bi: the call is
+    made with biPred = true, as for a bi-prediction origin).  -> (half_x, half_y, qter_x, qter_y, cost)"""
     cs, rs = plane_cur.shape[1], plane_ref.shape[1]
     org = _addr(plane_cur, cur_xy[1] * cs + cur_xy[0])
     rf = _addr(plane_ref, ref_xy[1] * rs + ref_xy[0])
     o = [C.c_int() for _ in range(4)]
     cost = C.c_uint32()
     if use_ref:
-        ref().ref_frac_refine(org, cs, w, h, rf, rs, int_mv[0], int_mv[1], pred[0], pred[1], float(lam_or_q16), int(use_had),
-                              bit_depth, *[C.byref(v) for v in o], C.byref(cost))
+        fn = ref().ref_frac_refine_bi if bi else ref().ref_frac_refine
+        fn(org, cs, w, h, rf, rs, int_mv[0], int_mv[1], pred[0], pred[1], float(lam_or_q16), int(use_had),
+           bit_depth, *[C.byref(v) for v in o], C.byref(cost))
     else:
         oracle().hmo_frac_refine(org, cs, w, h, rf, rs, int_mv[0], int_mv[1], pred[0], pred[1], int(lam_or_q16), int(use_had),
                                  bit_depth, *[C.byref(v) for v in o], C.byref(cost))

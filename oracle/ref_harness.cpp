@@ -172,6 +172,7 @@ void ref_tz_search(int16_t* org, int org_stride, int w, int h, int16_t* ref_at_p
 
 // TEncSearch::xPatternSearchFracDIF for one PU, set up like xMotionEstimation does (TEncSearch.cpp:3792-3798):
 // getMotionCost(true, 0, ...), cost scale 1; the function itself switches to scale 0 for the quarter stage.
+static bool g_frac_bipred = false;
 void ref_frac_refine(int16_t* org, int org_stride, int w, int h, int16_t* ref_at_pu, int ref_stride, int int_x, int int_y,
                      int pred_x, int pred_y, double lambda, int use_had, int bit_depth, int* half_x, int* half_y,
                      int* qter_x, int* qter_y, uint32_t* cost) {
@@ -185,8 +186,19 @@ void ref_frac_refine(int16_t* org, int org_stride, int w, int h, int16_t* ref_at
   pat.initPattern(org, w, h, org_stride, bit_depth);
   TComMv mv((Short)int_x, (Short)int_y), half, qter;
   Distortion d = 0;
-  r.search->xPatternSearchFracDIF(false, &pat, ref_at_pu, ref_stride, &mv, half, qter, d, false);
+  r.search->xPatternSearchFracDIF(false, &pat, ref_at_pu, ref_stride, &mv, half, qter, d, g_frac_bipred);
   *half_x = half.getHor(); *half_y = half.getVer(); *qter_x = qter.getHor(); *qter_y = qter.getVer(); *cost = d;
+}
+
+// the bBi call of TEncSearch::xMotionEstimation (TEncSearch.cpp:3798 with bBi = true): `org` is the bi-prediction origin
+// 2*org - pred_other (TEncSearch.cpp:3702-3712, TComYuv::removeHighFreq: unclipped, so samples lie in [-maxv, 2*maxv])
+void ref_frac_refine_bi(int16_t* org, int org_stride, int w, int h, int16_t* ref_at_pu, int ref_stride, int int_x, int int_y,
+                        int pred_x, int pred_y, double lambda, int use_had, int bit_depth, int* half_x, int* half_y,
+                        int* qter_x, int* qter_y, uint32_t* cost) {
+  g_frac_bipred = true;
+  ref_frac_refine(org, org_stride, w, h, ref_at_pu, ref_stride, int_x, int_y, pred_x, pred_y, lambda, use_had, bit_depth, half_x, half_y,
+                  qter_x, qter_y, cost);
+  g_frac_bipred = false;
 }
 
 // TComPicYuv::create + extendPicBorder (TComPicYuv.cpp:80-133, :214-262): a w x h luma picture goes in, the whole padded buffer

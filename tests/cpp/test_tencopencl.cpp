@@ -113,6 +113,28 @@ int main() {
         if (failures < 10) fprintf(stderr, "bi-pred slot %d differs from the oracle\n", i);
         ++failures;
       }
+    // the bBi pass also refines that origin (xPatternSearchFracDIF(..., bBi), TEncSearch.cpp:3798): with setRefine the same call
+    // fills the refinement tables, flagged as bi-prediction tables
+    me.setRefine(true, true);
+    me.calcMotionVectors(&bi[0], piRefY, stride, 64, BSR, &ltb);
+    if (!me.lastCallOk() || !me.fracOk() || !me.fracWasBi()) { fprintf(stderr, "bi-pred search + refine call failed\n"); ++failures; }
+    for (int slot = 0; slot < NUM_CTU_PARTS; slot += 37) {
+      hmo_rect r;
+      hmo_slot_rect(slot, &r);
+      const TComMv imv = me.getMvs()[slot];
+      if (imv.getHor() != ox[slot] || imv.getVer() != oy[slot]) { fprintf(stderr, "bi-pred search+refine: integer slot %d differs\n", slot); ++failures; }
+      int hx, hy, qx, qy;
+      uint32_t cost;
+      hmo_frac_refine(&bi[r.y * 64 + r.x], 64, r.w, r.h, piRefY + r.y * stride + r.x, stride, imv.getHor(), imv.getVer(), -3, 5, hmo_lambda_q16(lambda), 1, 8,
+                      &hx, &hy, &qx, &qy, &cost);
+      const int wx = 4 * imv.getHor() + 2 * hx + qx, wy = 4 * imv.getVer() + 2 * hy + qy;
+      if (me.getQMvs()[slot].getHor() != wx || me.getQMvs()[slot].getVer() != wy || me.getFracCost()[slot] != cost) {
+        if (failures < 10) fprintf(stderr, "bi-pred refinement slot %d: got (%d,%d,%u) want (%d,%d,%u)\n", slot, me.getQMvs()[slot].getHor(),
+                                   me.getQMvs()[slot].getVer(), me.getFracCost()[slot], wx, wy, cost);
+        ++failures;
+      }
+    }
+    me.setRefine(false);
     me.setBiPred(false);
     if (std::memcmp(uniMv, me.getMvs(), sizeof uniMv) != 0 || std::memcmp(uniCost, me.getRuiCost(), sizeof uniCost) != 0 ||
         std::memcmp(uniMv, me.getMvs(false), sizeof uniMv) != 0) {

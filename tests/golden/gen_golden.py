@@ -14,6 +14,8 @@ Every .npz holds inputs and the reference's outputs -- data only.
   tz.npz           G5  xTZSearch for a set of PUs
   frac.npz             xPatternSearchFracDIF (half + quarter-pel refinement, HAD or SAD) for a set of PUs
   border.npz           TComPicYuv::create + extendPicBorder: small pictures in, the whole padded luma buffer out
+  frac_bipred.npz      xPatternSearchFracDIF(..., biPred = true) on bi-prediction origins 2*org - pred_other (samples outside the
+                       sample range, TEncSearch.cpp:3702-3712): `python tests/golden/gen_golden.py frac_bipred` makes this file alone
 """
 import ctypes as C
 import os
@@ -288,10 +290,56 @@ def gen_frac(table):
     print("frac:", len(rows))
 
 
+def gen_frac_bipred(table):
+    """the bBi call: (PU of the origin plane 2*org - pred_other, integer MV, predictor, lambda, HAD on/off, bit depth) -> (half, quarter, cost)"""
+    rng = np.random.default_rng(29)
+    planes = {}
+    for bd in (8, 10):
+        cur_p, ref_p, _ = synth.make_pair(192, 192, seed=70 + bd, bit_depth=bd, max_mv=3, region=64, margin=16, noise_sigma=2.0)
+        _, other, _ = synth.make_pair(192, 192, seed=90 + bd, bit_depth=bd, max_mv=3, region=64, margin=16, noise_sigma=2.0)
+        # TComYuv::removeHighFreq with DISABLING_CLIP_FOR_BIPREDME: 2 * org - pred, unclipped.  `other` is an unrelated picture for the
+        # first plane (origins spread over the whole [-maxv, 2*maxv]) and a close prediction for the second (what an encoder sees)
+        near = np.clip(cur_p.astype(np.int32) + rng.integers(-12, 13, size=cur_p.shape) * (1 << (bd - 8)), 0, (1 << bd) - 1)
+        maxv = (1 << bd) - 1
+        stretch = lambda a: np.clip((a.astype(np.int32) - maxv // 2) * 4 + maxv // 2, 0, maxv)   # saturates: origins reach -maxv and 2*maxv
+        planes[bd] = ((2 * stretch(cur_p) - stretch(other)).astype(np.int16), (2 * cur_p.astype(np.int32) - near).astype(np.int16), ref_p)
+    rows, outs = [], []
+    for it in range(96):
+        bd = 10 if it % 3 == 2 else 8
+        which = it % 2
+        org_p, ref_p = planes[bd][which], planes[bd][2]
+        slot = int(rng.integers(0, 593)) if it >= 12 else [592, 588, 590, 576, 512, 544, 448, 256, 384, 0, 128, 584][it]
+        x, y, w, h = (int(v) for v in table[table[:, 0] == slot][0, 6:10])
+        mv = [int(v) for v in rng.integers(-4, 5, size=2)]
+        pred = [int(v) for v in rng.integers(-40, 41, size=2)]
+        lam = float(rng.choice([0.0, 4.7, 57.9, 900.0]))
+        had = int(it % 5 != 4)
+        o = 16 + 64
+        cs = org_p.shape[1]
+        off = (o + y) * cs + o + x
+        h_ = [C.c_int() for _ in range(4)]
+        cost = C.c_uint32()
+        R.ref_frac_refine_bi(O._addr(org_p, off), cs, w, h, O._addr(ref_p, off), cs, mv[0], mv[1], pred[0], pred[1], lam, had, bd,
+                             *[C.byref(v) for v in h_], C.byref(cost))
+        rows.append((slot, x, y, w, h, mv[0], mv[1], pred[0], pred[1], had, bd, R.ref_lambda_q16(lam), o, which))
+        outs.append(tuple(v.value for v in h_) + (cost.value,))
+    for bd in (8, 10):
+        maxv = (1 << bd) - 1
+        assert planes[bd][0].min() == -maxv and planes[bd][0].max() == 2 * maxv, (bd, planes[bd][0].min(), planes[bd][0].max())
+    np.savez_compressed(os.path.join(HERE, "frac_bipred.npz"), rows=np.array(rows, np.int64), out=np.array(outs, np.int64),
+                        org8_0=planes[8][0], org8_1=planes[8][1], ref8=planes[8][2], org10_0=planes[10][0], org10_1=planes[10][1],
+                        ref10=planes[10][2],
+                        columns=np.array("slot x y w h int_x int_y pred_x pred_y had bit_depth lambda_q16 origin which_plane".split()))
+    print("frac_bipred:", len(rows))
+
+
 def main():
     global R
     O.build(ref=True)
     R = O.ref()
+    if sys.argv[1:] == ["frac_bipred"]:   # this file alone; the slot table comes from the committed slots.npz
+        gen_frac_bipred(np.load(os.path.join(HERE, "slots.npz"))["table"])
+        return
     table = gen_slots()
     gen_cost()
     gen_sad()
@@ -323,6 +371,7 @@ def main():
     gen_search(table, "search_sr64.npz", sr64)
     gen_tz(table)
     gen_frac(table)
+    gen_frac_bipred(table)
     gen_border()
 
 

@@ -937,13 +937,49 @@ def test_search_refine_ctu_vs_oracle(engine, oracle_lib, bd, sr, had):
         imv = (int(mv[s, 0]), int(mv[s, 1]))
         hx, hy, qx, qy, c = oracle_lib.frac_refine(cur_p, (o + x, o + y), ref_p, (o + x, o + y), bw, bh, imv, pred, engine.lambda_q16, had, bd)
         assert (int(qmv[s, 0]), int(qmv[s, 1]), int(cost[s])) == (4 * imv[0] + 2 * hx + qx, 4 * imv[1] + 2 * hy + qy, c), (s, imv)
-    # refinement of a bi-prediction origin stays with the caller
-    cur2 = cur_p.copy()
-    cur2[o + 3, o + 3] = -7
-    with pytest.raises(api.HmmeError, match="bi-prediction"):
-        engine.search_refine_ctu(cur2, (o, o), ref_p, (o, o), p)
-    mv2, sad2 = engine.search_ctu(cur2, (o, o), ref_p, (o, o), p)     # ... the search itself takes it
-    assert mv2.shape == (593, 2)
+    # a bi-prediction origin (2*org - pred_other, samples outside the range) is refined too: every slot against the oracle
+    rng2 = np.random.default_rng(bd + sr)
+    maxv = (1 << bd) - 1
+    near = np.clip(cur_p.astype(np.int32) + rng2.integers(-40, 41, size=cur_p.shape) * (1 << (bd - 8)), 0, maxv)
+    cur2 = (2 * cur_p.astype(np.int32) - near).astype(np.int16)
+    cur2[o + 3, o + 3], cur2[o + 40, o + 17] = -maxv, 2 * maxv
+    assert cur2[o:o + 64, o:o + 64].min() < 0 and cur2[o:o + 64, o:o + 64].max() > maxv
+    mv2, sad2, qmv2, cost2 = engine.search_refine_ctu(cur2, (o, o), ref_p, (o, o), p, use_hadamard=bool(had))
+    ox, oy, osad = oracle_lib.search_ctu(cur2, (o, o), ref_p, (o, o), oracle_lib.make_params((-sr, -sr), (sr, sr - 1), pred, engine.lambda_q16, 1, bd))
+    assert np.array_equal(mv2[:, 0], ox) and np.array_equal(mv2[:, 1], oy) and np.array_equal(sad2, osad)
+    for s in range(0, 593, 7):
+        x, y, bw, bh = (int(v) for v in table[s])
+        imv = (int(mv2[s, 0]), int(mv2[s, 1]))
+        hx, hy, qx, qy, c = oracle_lib.frac_refine(cur2, (o + x, o + y), ref_p, (o + x, o + y), bw, bh, imv, pred, engine.lambda_q16, had, bd)
+        assert (int(qmv2[s, 0]), int(qmv2[s, 1]), int(cost2[s])) == (4 * imv[0] + 2 * hx + qx, 4 * imv[1] + 2 * hy + qy, c), ("bi-prediction origin", s, imv)
+    cur3 = cur2.copy()
+    cur3[o + 1, o + 1] = 2 * maxv + 1                                  # beyond what 2*org - pred can produce
+    with pytest.raises(api.HmmeError, match="outside"):
+        engine.search_refine_ctu(cur3, (o, o), ref_p, (o, o), p)
+
+
+def test_refine_ctu_matches_reference_goldens_of_biprediction_origins(engine):
+    """hmme_refine_ctu on bi-prediction origins == the reference's own xPatternSearchFracDIF(..., biPred = true) on 2*org - pred_other
+    (tests/golden/frac_bipred.npz: 96 PUs, 8/10 bit, Hadamard / SAD, origins over the whole [-maxv, 2*maxv], from the compiled reference)"""
+    from hmme import api
+    d = np.load(os.path.join(GOLDEN, "frac_bipred.npz"))
+    planes = {(bd, k): np.ascontiguousarray(d[f"org{bd}_{k}"]) for bd in (8, 10) for k in (0, 1)}
+    refs = {bd: np.ascontiguousarray(d[f"ref{bd}"]) for bd in (8, 10)}
+    n = n_out = 0
+    for row, want in zip(d["rows"], d["out"]):
+        slot, x, y, w, h, ix, iy, px, py, had, bd, lq, o, which = (int(v) for v in row)
+        cur = planes[(bd, which)]
+        blk = cur[o:o + 64, o:o + 64]
+        n_out += int(blk.min() < 0 or blk.max() > (1 << bd) - 1)
+        engine.set_lambda_q16(lq)
+        imv = np.zeros((593, 2), np.int16)
+        imv[slot] = (ix, iy)
+        p = api.SearchParams(-8, -8, 8, 8, px, py, 1, bd)
+        qmv, cost = engine.refine_ctu(cur, (o, o), refs[bd], (o, o), p, imv, use_hadamard=bool(had))
+        hx, hy, qx, qy, c = (int(v) for v in want)
+        assert (int(qmv[slot, 0]), int(qmv[slot, 1]), int(cost[slot])) == (4 * ix + 2 * hx + qx, 4 * iy + 2 * hy + qy, c), row
+        n += 1
+    assert n == 96 and n_out == 48      # plane 0 (unrelated other prediction): origins over the whole [-maxv, 2*maxv]; plane 1 (close prediction): in range
 
 
 def test_device_border_extension_matches_reference_goldens(engine, oracle_lib):

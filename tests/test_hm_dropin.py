@@ -127,6 +127,32 @@ def test_patched_encoder_gpu_refinement_tables(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg,frames,extra", [(CFG_B, 4, ()), (CFG_RA, 9, ()), (CFG_B, 3, ("--Profile=main10", "--InternalBitDepth=10"))])
+def test_patched_encoder_gpu_refinement_of_the_biprediction_pass(tmp_path, cfg, frames, extra):
+    """HMME_GPU_FRAC=1 in B pictures: the bBi pass runs xPatternSearchFracDIF on the origin 2*org - pred_other (TEncSearch.cpp:3702-3712,
+    :3798); the engine refines that origin in the same call as its integer search (hmme_search_refine_ctu on samples outside the
+    range) and the patch serves the 64x64 PU from those tables.  HMME_VERIFY=1 runs HM's OWN xPatternSearchFracDIF(..., bBi) beside
+    every such lookup: quarter-pel MV and ruiCost must be identical, for every bi-prediction call, 8 and 10 bit."""
+    _build()
+    common = dict(frames=frames, w=208, h=120, exe=EXE_HM, cfg=cfg, extra=("--SearchRange=24",) + extra)
+    r, p = _encode(tmp_path, 1, env_extra={"HMME_VERIFY": "1", "HMME_GPU_FRAC": "1"}, **common)
+    m = _TRACE.search(r.stderr)
+    assert m, r.stderr[-1500:]
+    calls, failed, edge, bi, verified, differ = (int(v) for v in m.groups())
+    assert failed == 0 and differ == 0 and bi > 0, m.group(0)
+    r1, p1 = _encode(tmp_path, 1, env_extra={"HMME_VERIFY": "1"}, **common)
+    m1 = _TRACE.search(r1.stderr)
+    calls1, _, edge1, bi1, verified1, differ1 = (int(v) for v in m1.groups())
+    assert differ1 == 0
+    # with the tables on, every whole-CTU call adds a refinement check: the uni-prediction ones AND the bi-prediction ones (the
+    # encoders may take different decisions later on, so compare per-call rates, not totals)
+    assert verified - 4 * (calls - edge - bi) - bi >= (calls - edge - bi) + bi - 2, (m.group(0), m1.group(0))
+    bits, bits_cpu_frac = sum(b for _, b, _ in p[1:]), sum(b for _, b, _ in p1[1:])
+    assert abs(bits - bits_cpu_frac) < 0.05 * bits_cpu_frac + 300, (bits, bits_cpu_frac)
+    print("bi-prediction refinement from the tables:", p, "\nCPU xPatternSearchFracDIF:", p1, "\n", m.group(0))
+
+
+@pytest.mark.gpu
 def test_encoders_at_10_bit_internal_depth(tmp_path):
     """InternalBitDepth 10 (8-bit input, 10-bit coding): the unmodified call sites cannot tell the class the bit depth -- it takes the
     sample width from the reference window and, like cl/sad.cl, leaves the sums unshifted; no call may fail or serve stale tables.

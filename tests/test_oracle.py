@@ -175,3 +175,16 @@ def test_fractional_refinement(oracle_lib):
         cur, ref = planes[bd]
         got = oracle_lib.frac_refine(cur, (o + x, o + y), ref, (o + x, o + y), w, h, (ix, iy), (px, py), lq, had, bd)
         assert got == tuple(int(v) for v in want), row
+
+
+def test_fractional_refinement_of_biprediction_origins(oracle_lib):
+    # the bBi call xPatternSearchFracDIF(..., biPred = true) (TEncSearch.cpp:3798) on 2*org - pred_other (TEncSearch.cpp:3702-3712):
+    # origins outside the sample range, interpolated reference clipped to it
+    d = g("frac_bipred.npz")
+    planes = {(bd, k): np.ascontiguousarray(d[f"org{bd}_{k}"]) for bd in (8, 10) for k in (0, 1)}
+    refs = {bd: np.ascontiguousarray(d[f"ref{bd}"]) for bd in (8, 10)}
+    assert planes[(8, 0)].min() == -255 and planes[(8, 0)].max() == 510 and planes[(10, 0)].min() == -1023 and planes[(10, 0)].max() == 2046
+    for row, want in zip(d["rows"], d["out"]):
+        slot, x, y, w, h, ix, iy, px, py, had, bd, lq, o, which = (int(v) for v in row)
+        got = oracle_lib.frac_refine(planes[(bd, which)], (o + x, o + y), refs[bd], (o + x, o + y), w, h, (ix, iy), (px, py), lq, had, bd)
+        assert got == tuple(int(v) for v in want), row

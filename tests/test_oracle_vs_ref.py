@@ -67,3 +67,9 @@ def test_fractional_refinement_matches_reference(oracle_lib):
         a = oracle_lib.frac_refine(cur, (o + x, o + y), ref, (o + x, o + y), w, h, mv, pred, lq, had, bd)
         b = oracle_lib.frac_refine(cur, (o + x, o + y), ref, (o + x, o + y), w, h, mv, pred, lam, had, bd, use_ref=True)
         assert a == b, (it, w, h, mv, pred, lam, had, bd)
+        # the bBi call: origin 2*org - pred_other (unclipped, TComYuv.cpp:409-440), biPred = true
+        other = np.roll(cur, (int(rng.integers(-3, 4)), int(rng.integers(-3, 4))), axis=(0, 1)).astype(np.int32) + rng.integers(-30, 31, size=cur.shape)
+        org = (2 * cur.astype(np.int32) - np.clip(other, 0, (1 << bd) - 1)).astype(np.int16)
+        a = oracle_lib.frac_refine(org, (o + x, o + y), ref, (o + x, o + y), w, h, mv, pred, lq, had, bd)
+        b = oracle_lib.frac_refine(org, (o + x, o + y), ref, (o + x, o + y), w, h, mv, pred, lam, had, bd, use_ref=True, bi=True)
+        assert a == b, ("bi", it, w, h, mv, pred, lam, had, bd)
