@@ -41,17 +41,29 @@ constexpr size_t kResMv = 0, kResSad = 4 * HMME_NUM_CTU_PARTS, kResDone = 8 * HM
 constexpr size_t kLdsBudget16Default = 78 * 1024;
 size_t lds_budget16_from_env();
 const size_t kLdsBudget16 = lds_budget16_from_env();
-// 16-bit window pitch in dwords for windows up to 129 / 257 candidates wide (row = (wx + 63 + 1) samples / 2, + 34 dwords the
-// last lane of a row reaches beyond its first candidate)
-// LDS window pitch of the 16-bit kernel in dwords, for windows up to 129 / 257 candidates wide.  A lane reads dwords
-// 3 * (lane in row) + 0..33 of its row, so 97 / 160 would do; the pitch decides which banks the rows of one wave-wide read share
-// (64 lanes cover 1.5 .. 3 window rows).  Measured (profiles/r02Y_pdw_sweep.txt, GSAD/s at 2160p 10-bit): SR 128 -- 160: 1 782,
-// 161: 1 812, 162: 1 780, 163: 1 777, 164..170: 1 698..1 724; SR 64 -- 130: 1 687, 98: 1 693, 97..106 otherwise: 1 630..1 651.
-#ifndef ME16_PDW_SMALL
-#define ME16_PDW_SMALL 130
-#define ME16_PDW_LARGE 161
-#endif
-constexpr int kPdw16Small = ME16_PDW_SMALL, kPdw16Large = ME16_PDW_LARGE;
+// LDS window pitch of the 16-bit kernel in dwords -- a template parameter of the kernel (the odd row of a row pair is addressed by
+// an immediate).  A lane reads dwords 3 * (lane in row) + 0..33 of its window row, lanes-per-row L = ceil(ceil(wx / 2) / 3), so a
+// row needs 3 * (L - 1) + 34 dwords; the pitch also decides which banks the rows of one wave-wide read share (64 lanes cover 1.5 .. 6
+// window rows): with pitch == 3 * L (mod 32) the 64 lanes form ONE stride-3 progression over the 32 banks and a ds_read2_b32 costs
+// its minimum.  Measured (profiles/r02Y_pdw_sweep.txt, GSAD/s at 2160p 10-bit): SR 128 -- 160: 1 782, 161: 1 812, 162: 1 780,
+// 164..170: 1 698..1 724; SR 64 -- 130: 1 687, 97..106 otherwise: 1 630..1 651.  Four pitches are compiled, the right ones for the
+// full windows of SR 32 / 64 / 96 / 128 (round 2 had two, and SR 32 / 96 ran 5 % below the tuned ranges); any other window takes the
+// smallest pitch that holds it, preferring the right residue (pick_pdw16).
+constexpr int kPdw16[4] = {65, 130, 131, 161};
+constexpr int kPdw16Large = kPdw16[3];
+inline int pdw16_index(int pdw) { return pdw == kPdw16[0] ? 0 : pdw == kPdw16[1] ? 1 : pdw == kPdw16[2] ? 2 : 3; }
+// pitch for windows up to wx candidates wide
+int pick_pdw16(int wx) {
+  const int lanes = (((wx + 1) >> 1) + 2) / 3, need = 3 * (lanes - 1) + 34, want = (3 * lanes) & 31;
+  int best = kPdw16Large;
+  bool best_match = false;
+  for (int i = 3; i >= 0; --i) {
+    if (kPdw16[i] < need) continue;
+    const bool match = (kPdw16[i] & 31) == want;
+    if (match || !best_match) { best = kPdw16[i]; best_match = match; }   // descending: the smallest fitting one wins among equals
+  }
+  return best;
+}
 thread_local std::string g_create_error;   // hmme_last_error(NULL): per host thread, like the contexts themselves
 constexpr size_t lds_bytes16_c(int pdw, int strip_rows) { return (size_t)(2 * 594 + 4 + (strip_rows + 63) * pdw) * 4; }
 size_t lds_budget16_from_env() {
@@ -100,7 +112,7 @@ struct hmme_ctx {
   uint32_t* d_sad = nullptr;
   int out_cap = 0;
   int* d_flag = nullptr;
-  bool lds_optin[4] = {false, false, false, false};
+  bool lds_optin[8] = {false, false, false, false, false, false, false, false};
   uint16_t* d_frac_cover = nullptr;   // fractional refinement: slots covering each 8x8 / 4x4 position, same for every CTU
   int16_t* d_imv = nullptr;           // host-facing refine call: integer MVs / quarter-pel MVs / costs on the device
   int16_t* d_qmv = nullptr;
@@ -263,7 +275,7 @@ int strips_for(int pdw, int wy_max) {
 template <int FEN, int PDW>
 int launch16_t(hmme_ctx* ctx, const RefSet& cur, int cur_pitch, const RefSet& ref, int ref_pitch, const MeJob16* d_jobs, int n_wg,
                size_t lds, int sh, unsigned long long* d_best, hipStream_t stream) {
-  bool& attr_set = ctx->lds_optin[FEN * 2 + (PDW == kPdw16Large ? 1 : 0)];   // > 64 KiB of dynamic LDS: opt in once per
+  bool& attr_set = ctx->lds_optin[FEN * 4 + pdw16_index(PDW)];   // > 64 KiB of dynamic LDS: opt in once per
   if (!attr_set) {                                                            // kernel and device (= per context)
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)hmme::me_search16_kernel<FEN, PDW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
@@ -284,12 +296,16 @@ int launch_search16(hmme_ctx* ctx, const RefSet& cur, int cur_pitch, const RefSe
   if (rc) return rc;
   const size_t lds = lds_bytes16(pdw, strip_rows_max);
   const int sh = bit_depth - 8;
-  if (pdw == kPdw16Small)
-    rc = fen ? launch16_t<1, kPdw16Small>(ctx, cur, cur_pitch, ref, ref_pitch, d_jobs, n_wg, lds, sh, best, stream)
-             : launch16_t<0, kPdw16Small>(ctx, cur, cur_pitch, ref, ref_pitch, d_jobs, n_wg, lds, sh, best, stream);
-  else
-    rc = fen ? launch16_t<1, kPdw16Large>(ctx, cur, cur_pitch, ref, ref_pitch, d_jobs, n_wg, lds, sh, best, stream)
-             : launch16_t<0, kPdw16Large>(ctx, cur, cur_pitch, ref, ref_pitch, d_jobs, n_wg, lds, sh, best, stream);
+#define LAUNCH16(I)                                                                                                       \
+  rc = fen ? launch16_t<1, kPdw16[I]>(ctx, cur, cur_pitch, ref, ref_pitch, d_jobs, n_wg, lds, sh, best, stream)            \
+           : launch16_t<0, kPdw16[I]>(ctx, cur, cur_pitch, ref, ref_pitch, d_jobs, n_wg, lds, sh, best, stream)
+  switch (pdw16_index(pdw)) {
+    case 0: LAUNCH16(0); break;
+    case 1: LAUNCH16(1); break;
+    case 2: LAUNCH16(2); break;
+    default: LAUNCH16(3); break;
+  }
+#undef LAUNCH16
   if (rc) return rc;
   return finalize ? finalize_best(ctx, best, d_jobs, d_first_strip, n_jobs, d_mv, d_sad, stream) : HMME_OK;
 }
@@ -634,7 +650,7 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
         }
       }
   } else {
-    pdw = (wx <= 129 && wy <= 129) ? kPdw16Small : kPdw16Large;
+    pdw = pick_pdw16(wx);
     // at least as many strips as the LDS needs, and enough of them to spread the CTU over the chip: a strip is
     // >= 4 candidate rows (each also stages the 63 rows below it)
     n_wg = std::max(strips_for(pdw, wy), std::min(kCallMaxJobs, (wy + 3) / 4));
@@ -854,7 +870,7 @@ static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_para
   const bool wide = fp->bit_depth > 8;
   const int jobs = count * n_refs, slots = ctx->wg_slots, w = 2 * fp->search_range + 1;
   pl->jobs = jobs;
-  pl->pdw = fp->search_range <= 64 ? kPdw16Small : kPdw16Large;
+  pl->pdw = pick_pdw16(w);
   pl->n_strips = 1;
   pl->strip_rows = w;
   pl->tile8 = !wide && fp->search_range > 64;   // window beyond 129 x 129: four tile searches per CTU, merged like split tasks

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--log", default=None, help="append progress lines to this file as configurations start and finish (long runs on the "
                                                 "GPU box must keep writing under gpurun_out/)")
     ap.add_argument("--hm-args", default="", help="extra TAppEncoder arguments for every configuration, e.g. '--Profile=main10 --InternalBitDepth=10'")
+    ap.add_argument("--only", default=None, help="run only the configurations whose name contains this text (e.g. GPU_FRAC)")
     ap.add_argument("--verify", action="store_true", help="HMME_VERIFY=1 on the patched encoder (slower: runs HM's xPatternSearch beside the engine)")
     args = ap.parse_args()
     CFG = CFGS[args.gop]
@@ -52,6 +53,8 @@ def main():
                              ("hmme, tools/hm_patch (ME_MODE_HM, bi-pred tables, edge CTUs)", EXE_HM, ["--OpenCL=1", "--FastSearch=1", "--KernelOpenCL=embedded"]),
                              ("hmme, tools/hm_patch + HMME_GPU_FRAC=1 (refinement tables too)", EXE_HM, ["--OpenCL=1", "--FastSearch=1", "--KernelOpenCL=embedded"])):
         if args.skip_full_search and "--FastSearch=0" in extra:
+            continue
+        if args.only and args.only not in name:
             continue
         if args.log:
             with open(args.log, "a") as f:
