@@ -348,6 +348,29 @@ def main():
         out["refine"] = {"what": "xPatternSearchFracDIF (half + quarter-pel, Hadamard) for all 593 slots of every CTU, on the integer winners",
                          "kernel": "me_frac_kernel<1, %d>" % (1 if bd == 8 else 2), "ms_per_step": round(r_ms, 4),
                          "slots_per_s": round(n_ctu * n_refs * api.NUM_PARTS / (r_ms * 1e-3))}
+        # beside the headline, never `value`: the same picture against the FOUR reference pictures a lowdelay_P_main picture searches
+        # (cfg/encoder_lowdelay_P_main.cfg:24-27) in one launch -- what the encoder configuration the metric is quoted on asks of a step
+        # (not under --no-cpu-baseline: tools/profile_bench.sh profiles that command, and launches of another size would enter the
+        # per-kernel averages of its rocprofv3 summaries)
+        if n_refs == 1 and n_pairs == 1 and world == 1 and not args.no_cpu_baseline:
+            refs4 = [pr] + [eng.plane(w, h, bd) for _ in range(3)]
+            for i, pl in enumerate(refs4[1:]):
+                _, r2, _ = synth.make_pair(w, h, seed=7000 + 13 * i, bit_depth=bd)
+                pl.upload_pel(r2, (synth.MARGIN, synth.MARGIN))
+            b4 = torch.zeros((2, 4, n_ctu, api.NUM_PARTS), dtype=torch.int32, device=dev)
+            reps4 = max(3, min(10, args.steps // 2))
+            for i in range(reps4 + 2):
+                if i == 2:
+                    ev[0].record()
+                eng.search_frame_multi_device(pc, refs4, fp, None, b4[0].data_ptr(), b4[1].data_ptr(), stream)
+            ev[1].record()
+            torch.cuda.synchronize()
+            ms4 = ev[0].elapsed_time(ev[1]) / reps4
+            out["four_references_per_launch"] = {"what": "one current picture against 4 reference pictures in ONE launch (hmme_search_frame_multi_device)",
+                                                 "ms_per_launch": round(ms4, 4), "gsad_per_s": round(4 * sads / (ms4 * 1e-3) / 1e9, 1),
+                                                 "ctus_per_s": round(4 * n_ctu / (ms4 * 1e-3), 1)}
+            for pl in refs4[1:]:
+                pl.close()
         fprof = prof.get("kernels", {}).get("me_frac_kernel", {})
         if fprof.get("hbm_traffic_bytes_per_launch") is not None:
             out["refine"]["hbm_traffic_bytes_per_launch"] = int(fprof["hbm_traffic_bytes_per_launch"])

@@ -858,7 +858,7 @@ __global__ void me_prep_jobs_tile_kernel(MeJob16* jobs, int* first_strip_of_job,
 constexpr int kFracAccRow = 9, kFracAcc = 593 * kFracAccRow, kFracAccDw = (kFracAcc + 15) & ~15;
 // BPS = bytes per sample of the planes (1: 8-bit video, 2: 9..12 bit)
 constexpr int frac_threads(int bps) { return 256; }
-constexpr size_t frac_lds_bytes(int bps) { return (size_t)(kFracAccDw + 600 + 160 + (64 * 18 + 256 * 6) / 2 + 1024 * bps) * 4; }
+constexpr size_t frac_lds_bytes(int bps) { return (size_t)(kFracAccDw + 600 + 160 + (64 * 18 + 256 * 6) / 2 + 1024 * bps + 600) * 4; }
 
 __device__ __forceinline__ uint32_t me_mv_cost_q(uint32_t lambda_q16, int vx_q, int vy_q, int pred_x, int pred_y) {
   return (lambda_q16 * (me_component_bits(vx_q - pred_x) + me_component_bits(vy_q - pred_y))) >> 16;
@@ -984,6 +984,9 @@ __device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3 * BPS], c
       }
 #pragma unroll
     for (int dyi = 0; dyi < 3; ++dyi) {
+      // the centre of the quarter-pel stage IS the half-pel stage's winning point: same position, same interpolated samples, same
+      // distortion -- HM evaluates it again (TEncSearch.cpp:4324-4331), here the slot's winner thread carries the sum over
+      if (STAGE == 1 && dxi == 1 && dyi == 1) { out[0] = 0; continue; }
       float cv[9];   // taps * 2^-sh2 (exact): the accumulator is the sample value with its fraction
 #pragma unroll
       for (int j = 0; j < 9; ++j)
@@ -1125,7 +1128,7 @@ __device__ __forceinline__ void me_frac_item(const uint8_t* __restrict__ src, in
     const int s2 = cov[j2];
     if (j2 == j || ((st[s2] ^ sv) & keymask) == 0) {
 #pragma unroll
-      for (int i = 0; i < 9; ++i) atomicAdd(&acc[s2 * kFracAccRow + i], dist[i]);
+      for (int i = STAGE; i < 9; ++i) atomicAdd(&acc[s2 * kFracAccRow + i], dist[i]);   // stage 1: point 0 is carried over, not evaluated
     }
   }
 }
@@ -1166,6 +1169,7 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
   uint16_t* list8 = (uint16_t*)(tab_h + 160);                  // distinct (8x8 position, key) pairs
   uint16_t* list4 = (uint16_t*)(tab_h + 160 + kFracPairs8 / 2);   // distinct (4x4 position, key) pairs
   uint32_t* curl = tab_h + 160 + (kFracPairs8 + kFracPairs4) / 2;   // 64 x 64 current block
+  uint32_t* carry = curl + 1024 * BPS;  // [593] stage 0: each slot's distortion sum at its winning half-pel point
 
   const int tid = threadIdx.x;
   MeJob job = jobs[blockIdx.x];
@@ -1233,6 +1237,7 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
       }
       if (stage == 0) {
         st[s] = (sv & kFracKey0) | (uint32_t)(ph[bi][0] + 1) << 18 | (uint32_t)(ph[bi][1] + 1) << 20;
+        carry[s] = acc[s * kFracAccRow + bi];
       } else {
         const long o = (long)blockIdx.x * kParts + s;
         out_qmv[2 * o] = (int16_t)(bxq + pq[bi][0]);
@@ -1245,6 +1250,8 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
       __syncthreads();   // every thread has read its acc entries
       for (int i = tid; i < kFracAcc; i += NT) acc[i] = 0;
       __syncthreads();
+      // centre of the quarter-pel stage (point 0): nothing adds to it in stage 1, its owner thread reads it back after the barrier
+      for (int s = tid; s < kParts; s += NT) acc[s * kFracAccRow] = carry[s];
     }
   }
 }
