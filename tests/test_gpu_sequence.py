@@ -203,6 +203,56 @@ def test_pairs_per_launch_equals_single_launches_and_oracle(engine, oracle_lib, 
         pl.close()
 
 
+def _fuzz_pairs_case(engine, oracle_lib, seed):
+    import torch
+    from hmme import api, synth
+    rng = np.random.default_rng(seed)
+    w, h = 8 * int(rng.integers(1, 30)), 8 * int(rng.integers(1, 20))
+    bd = int(rng.choice([8, 8, 10, 12]))
+    k = int(rng.integers(1, 7))
+    sr = int(rng.choice([1, 3, 8, 16, 31, 64, 65, 100]))
+    n = api.load().hmme_num_ctus(w, h)
+    if k * n * (2 * sr + 1) ** 2 > 8 * 129 * 129:     # keep the oracle's share of the run in seconds
+        sr = 12
+    fen = int(rng.integers(0, 2))
+    max_pel = int(rng.choice([0, 6, 60]))
+    lam = float(rng.choice([0.0, 57.9, 900.0]))
+    engine.set_lambda(lam)
+    m = synth.MARGIN
+    # a small pool of pictures; pairs draw current and reference from it, so planes are shared between pairs in both roles
+    pool = [synth.make_pair(w, h, seed=seed * 10 + i, bit_depth=bd, max_mv=min(sr, 8), region=32, noise_sigma=float(rng.choice([0.0, 2.0])))
+            for i in range(max(2, (k + 1) // 2))]
+    imgs = [p[0] for p in pool] + [p[1] for p in pool]
+    planes = _planes(engine, w, h, bd, imgs)
+    pick = [(int(rng.integers(0, len(imgs))), int(rng.integers(0, len(imgs)))) for _ in range(k)]
+    pred = np.stack([synth.random_predictors(n, seed=seed + i, max_pel=max(max_pel, 1)) for i in range(k)]) if max_pel else None
+    dev = torch.device("cuda", 0)
+    d_pred = torch.from_numpy(pred).to(dev) if pred is not None else None
+    d_mv = torch.zeros((k, n, 593, 2), dtype=torch.int16, device=dev)
+    d_sad = torch.zeros((k, n, 593), dtype=torch.int32, device=dev)
+    fp = api.FrameParams(sr, fen, bd, 0, n)
+    engine.search_pairs_device([planes[c] for c, _ in pick], [planes[r] for _, r in pick], fp, d_pred.data_ptr() if pred is not None else None,
+                               d_mv.data_ptr(), d_sad.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    mv, sad = d_mv.cpu().numpy(), d_sad.cpu().numpy().view(np.uint32)
+    tag = dict(seed=seed, w=w, h=h, bd=bd, k=k, sr=sr, fen=fen, max_pel=max_pel, lam=lam, pick=pick)
+    for i, (c, r) in enumerate(pick):
+        ox, oy, osad = oracle_lib.search_frame(imgs[c], imgs[r], (m, m), w, h, sr, pred[i] if pred is not None else None, engine.lambda_q16, fen, bd,
+                                               n_threads=8)
+        assert np.array_equal(mv[i, :, :, 0], ox) and np.array_equal(mv[i, :, :, 1], oy) and np.array_equal(sad[i], osad), (tag, i)
+    for pl in planes:
+        pl.close()
+
+
+def test_fuzz_pair_launches_vs_oracle(engine, oracle_lib):
+    """random numbers of picture pairs (1..6) drawn from a shared pool of planes, random picture sizes, bit depths, search ranges
+    (tiled 8-bit windows included), FEN, predictors: every CTU of every pair of the launch against the oracle"""
+    n = int(os.environ.get("HMME_FUZZ_CASES", "10"))
+    base = int(os.environ.get("HMME_FUZZ_SEED", "3000"))
+    for i in range(n):
+        _fuzz_pairs_case(engine, oracle_lib, base + i)
+
+
 def test_plane_refill_on_another_stream_waits_for_the_search_that_reads_it(engine):
     """write-after-read across streams (include/hmme.h "Streams"): a 2160p search (~2.5 ms) is enqueued on stream A, then the
     plane it reads is refilled from page-locked memory on stream B (hmme_plane_upload_async, ~1 ms) without any host-side wait.
