@@ -317,23 +317,22 @@ def test_searches_on_device_addresses_with_bit_31_set(oracle_lib):
     """Pins the round-2 fault (gpurun_out/r02H): the kernels read the current block through scalar loads from a 64-bit base
     assembled out of two readfirstlane halves; widening the `int` the builtin returns sign-extended a low half with bit 31 set
     and the load went to 0xffffffff........  Whether a launch meets such an address depends on where hipMalloc puts a plane, so
-    this test walks the allocator (filler blocks of 192 MB) until planes AND a context's per-CTU staging block sit on addresses
+    this test walks the allocator (filler planes of 186 MB, straight hipMalloc) until planes AND a context's per-CTU staging block sit on addresses
     whose low dword has bit 31 set -- asserted -- and then runs the frame path and the per-CTU call, 8- and 10-bit, against the
     oracle on exactly those buffers."""
-    import torch
     from hmme import api, synth
     w, h, sr = 256, 192, 16
     m = synth.MARGIN
     lq = oracle_lib.oracle().hmo_lambda_q16(57.9)
-    dev = torch.device("cuda", 0)
     fillers, tried = [], []
     found = {}
+    filler_eng = api.Engine(0, 64)
 
     def high(addr, span):       # every byte the kernels address from this base has bit 31 set
         return (addr & 0x80000000) and ((addr + span) & 0x80000000) and ((addr & 0xffffffff) + span < (1 << 32))
 
     graveyard = []              # nothing is freed while walking: a freed block's address would simply be handed out again
-    for step in range(64):
+    for step in range(200):                                  # up to 37 GB of address space: bit 31 flips every 2 GiB
         if len(found) == 3:
             break
         eng = api.Engine(0, 64)
@@ -347,7 +346,8 @@ def test_searches_on_device_addresses_with_bit_31_set(oracle_lib):
             found["p8"] = (eng, p8)
         if "p10" not in found and high(a["p10"], 1024 * 300):
             found["p10"] = (eng, p10)
-        fillers.append(torch.empty(192 << 20, dtype=torch.uint8, device=dev))
+        fillers.append(filler_eng.plane(16384, 11000, 8))      # 16 640 B x 11 161 rows, not touched
+    print(f"high-address walk: {len(tried)} rounds; last addresses {tried[-1]}")
     try:
         assert len(found) == 3, f"no buffer with bit 31 set in its low address dword after {len(tried)} rounds: {tried[-6:]}"
         for bd, key in ((8, "p8"), (10, "p10")):
@@ -378,5 +378,6 @@ def test_searches_on_device_addresses_with_bit_31_set(oracle_lib):
     finally:
         for eng, p8, p10 in graveyard:
             p8.close(); p10.close(); eng.close()
-        del fillers
-        torch.cuda.empty_cache()
+        for pl in fillers:
+            pl.close()
+        filler_eng.close()
