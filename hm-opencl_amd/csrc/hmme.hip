@@ -452,6 +452,7 @@ void hmme_destroy(hmme_ctx* ctx) {
 
 const char* hmme_last_error(const hmme_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 const char* hmme_device_info(const hmme_ctx* ctx) { return ctx ? ctx->info.c_str() : ""; }
+int hmme_device_index(const hmme_ctx* ctx) { return ctx ? ctx->device : -1; }
 
 int hmme_set_lambda(hmme_ctx* ctx, double lambda) {
   if (!ctx) return HMME_ERR_ARG;

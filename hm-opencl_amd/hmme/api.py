@@ -22,7 +22,7 @@ SYMBOLS = ["hmme_create", "hmme_destroy", "hmme_last_error", "hmme_device_info",
            "hmme_num_ctus", "hmme_search_frame", "hmme_search_frame_device", "hmme_search_frame_multi",
            "hmme_search_frame_multi_device", "hmme_refine_frame", "hmme_refine_frame_multi_device",
            "hmme_time_search_kernel", "hmme_search_pairs_device", "hmme_refine_pairs_device", "hmme_plane_upload_async",
-           "hmme_upload_status", "hmme_debug_device_address", "hmme_abi_version", "hmme_build_id"]
+           "hmme_upload_status", "hmme_debug_device_address", "hmme_abi_version", "hmme_build_id", "hmme_device_index"]
 ABI_VERSION = 3   # HMME_ABI_VERSION of the include/hmme.h these bindings were written against
 
 

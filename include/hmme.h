@@ -110,6 +110,7 @@ int hmme_create(int device, int sr_max, unsigned flags, hmme_ctx** out);
 void hmme_destroy(hmme_ctx* ctx);
 const char* hmme_last_error(const hmme_ctx* ctx); /* ctx may be NULL: error of the calling thread's last failed hmme_create */
 const char* hmme_device_info(const hmme_ctx* ctx);
+int hmme_device_index(const hmme_ctx* ctx);   /* the HIP device the context lives on (host code that makes its own HIP calls beside the library's) */
 int hmme_set_lambda(hmme_ctx* ctx, double lambda);         /* m_lambda = floor(65536*sqrt(lambda)) */
 int hmme_set_lambda_q16(hmme_ctx* ctx, uint32_t lambda_q16);
 uint32_t hmme_get_lambda_q16(const hmme_ctx* ctx);

@@ -1,0 +1,70 @@
+// CPU test of the C++ sequence driver's planning (hm-opencl_amd/host/SequenceME.h): launches cover the pairs in order, every launch
+// finds its pictures in the slots the plan says, no launch's own picture is evicted for it.  Exit code 0 = all invariants hold.
+#include <cstdio>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../hm-opencl_amd/host/SequenceME.h"
+
+using namespace hmme_host;
+
+static int check(const std::vector<std::pair<int, int> >& pairs, int k, int slots, bool expect_ok) {
+  const std::vector<std::pair<int, int> > batches = plan_batches((int)pairs.size(), k);
+  int next = 0;
+  for (size_t b = 0; b < batches.size(); ++b) {
+    if (batches[b].first != next || batches[b].second <= batches[b].first || batches[b].second - batches[b].first > k) return 1;
+    next = batches[b].second;
+  }
+  if (next != (int)pairs.size()) return 2;
+  std::vector<std::vector<PlaneLoad> > loads;
+  std::vector<std::vector<std::pair<int, int> > > where;
+  std::string err;
+  const bool ok = plan_plane_loads(pairs, batches, slots, &loads, &where, &err);
+  if (ok != expect_ok) return 3;
+  if (!ok) return err.empty() ? 4 : 0;
+  std::map<int, int> held;   // slot -> picture
+  std::set<int> distinct;
+  int n_loads = 0;
+  for (size_t b = 0; b < batches.size(); ++b) {
+    std::set<int> need;
+    for (int i = batches[b].first; i < batches[b].second; ++i) { need.insert(pairs[i].first); need.insert(pairs[i].second); }
+    for (size_t j = 0; j < loads[b].size(); ++j) {
+      const PlaneLoad& l = loads[b][j];
+      if (l.slot < 0 || l.slot >= slots) return 5;
+      if (held.count(l.slot) && need.count(held[l.slot])) return 6;   // evicted a picture this very launch reads
+      held[l.slot] = l.poc;
+      ++n_loads;
+    }
+    if ((int)where[b].size() != batches[b].second - batches[b].first) return 7;
+    for (int i = batches[b].first; i < batches[b].second; ++i) {
+      const std::pair<int, int>& w = where[b][i - batches[b].first];
+      if (held[w.first] != pairs[i].first || held[w.second] != pairs[i].second) return 8;
+      distinct.insert(pairs[i].first); distinct.insert(pairs[i].second);
+    }
+  }
+  if (slots >= 8 && k == 1 && n_loads != (int)distinct.size()) return 10;   // the GOP's working set fits 8 slots: one upload per picture
+  return n_loads >= (int)distinct.size() ? 0 : 9;
+}
+
+int main() {
+  // the random-access GOP of cfg/encoder_randomaccess_main.cfg:28-31 over 64 pictures
+  std::vector<std::pair<int, int> > ra;
+  const int pos[4] = {4, 2, 1, 3}, nref[5] = {0, 3, 2, 2, 1}, refs[5][3] = {{0, 0, 0}, {-1, 1, 3}, {-2, 2, 0}, {-1, 1, 0}, {-4, 0, 0}};
+  for (int base = 0; base < 64; base += 4)
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < nref[pos[i]]; ++j) {
+        const int cur = base + pos[i], ref = cur + refs[pos[i]][j];
+        if (cur < 64 && ref >= 0 && ref < 64) ra.push_back(std::make_pair(cur, ref));
+      }
+  if (ra.size() != 124) { printf("FAIL: %zu pairs\n", ra.size()); return 1; }
+  int rc = 0;
+  const int cases[][3] = {{1, 8, 1}, {4, 10, 1}, {1, 2, 1}, {16, 34, 1}, {2, 4, 1}, {4, 3, 0}, {3, 5, 1}};
+  for (size_t c = 0; c < sizeof cases / sizeof cases[0]; ++c) {
+    const int r = check(ra, cases[c][0], cases[c][1], cases[c][2] != 0);
+    if (r) { printf("FAIL: k=%d slots=%d -> %d\n", cases[c][0], cases[c][1], r); rc = 1; }
+  }
+  printf("%s\n", rc ? "FAIL" : "PASS");
+  return rc;
+}

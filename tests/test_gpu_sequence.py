@@ -147,6 +147,48 @@ def test_streamed_yuv_file_equals_resident_equals_oracle(tmp_path, oracle_lib, b
         assert np.array_equal(out["qmv"][i], oq) and np.array_equal(out["cost"][i], oc)
 
 
+@pytest.mark.parametrize("bd,w,h,n,sr,k,slots,gop", [(8, 640, 448, 6, 16, 1, 0, "randomaccess"), (8, 832, 480, 10, 32, 3, 5, "randomaccess"),
+                                                    (10, 640, 360, 6, 24, 2, 4, "randomaccess"), (8, 320, 192, 7, 16, 4, 0, "lowdelay_P")])
+def test_cpp_sequence_driver_streams_a_yuv_file_equal_to_the_oracle(tmp_path, oracle_lib, bd, w, h, n, sr, k, slots, gop):
+    """tools/me_stream.cpp over hm-opencl_amd/host/SequenceME (C++: reader thread, page-locked buffers, copy / compute / download
+    streams, the C ABI and the HIP runtime only -- no Python, no torch in the process): tables of every pair, CTU and slot of a
+    streamed 8- / 16-bit YUV file, search and refinement, against the oracle; the pair list equals hmme.shard.gop_pairs."""
+    from conftest import ROOT
+    from hmme import shard, synth
+    host = os.path.join(ROOT, "hm-opencl_amd", "host")
+    subprocess.run(["make", "-s", "-C", host], check=True)
+    seq = synth.Sequence(w, h, n, seed=777, bit_depth=bd)
+    path, out = os.path.join(tmp_path, "seq.yuv"), os.path.join(tmp_path, "tables.bin")
+    seq.write_yuv(path)
+    r = subprocess.run([os.path.join(host, "me_stream"), "--yuv", path, "--size", f"{w}x{h}", "--frames", str(n), "--gop", gop, "--search-range", str(sr),
+                        "--bit-depth", str(bd), "--pairs-per-launch", str(k), "--slots", str(slots), "--refine", "--out", out, "--repeat", "2"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    pairs = shard.gop_pairs(n, gop)
+    raw = np.fromfile(out, np.int32)
+    n_pairs, n_ctu, refined = (int(v) for v in raw[:3])
+    assert n_pairs == len(pairs) == d["pairs"] and n_ctu == ((w + 63) // 64) * ((h + 63) // 64) and refined == 1
+    got_pairs = raw[4:4 + 2 * n_pairs].reshape(n_pairs, 2)
+    assert got_pairs.tolist() == [list(p) for p in pairs]
+    body = raw[4 + 2 * n_pairs:]
+    per = n_pairs * n_ctu * 593
+    mv = body[:per].view(np.int16).reshape(n_pairs, n_ctu, 593, 2)
+    sad = body[per:2 * per].view(np.uint32).reshape(n_pairs, n_ctu, 593)
+    qmv = body[2 * per:3 * per].view(np.int16).reshape(n_pairs, n_ctu, 593, 2)
+    cost = body[3 * per:4 * per].view(np.uint32).reshape(n_pairs, n_ctu, 593)
+    assert d["launches"] == (n_pairs + k - 1) // k and d["uploads"] >= len({p for pr in pairs for p in pr})
+    lq = oracle_lib.oracle().hmo_lambda_q16(57.9)
+    m = synth.MARGIN
+    padded = {t: seq.padded(t) for t in {p for pr in pairs for p in pr}}
+    for i, (cur, ref) in enumerate(pairs):
+        ox, oy, osad = oracle_lib.search_frame(padded[cur], padded[ref], (m, m), w, h, sr, None, lq, 1, bd, n_threads=16)
+        assert np.array_equal(mv[i, :, :, 0], ox) and np.array_equal(mv[i, :, :, 1], oy) and np.array_equal(sad[i], osad), (i, cur, ref)
+        if i in (0, n_pairs - 1):
+            oq, oc = oracle_lib.refine_frame(padded[cur], padded[ref], (m, m), w, h, mv[i], None, lq, 1, bd, n_threads=16)
+            assert np.array_equal(qmv[i], oq) and np.array_equal(cost[i], oc), (i, cur, ref)
+
+
 def _planes(engine, w, h, bd, imgs):
     pls = []
     for img in imgs:
