@@ -141,6 +141,25 @@ def cpu_baseline(cur, ref, w, h, sr, lq, bd=8, budget_s=14.0):
     # the same exhaustive search on one core (SURVEY 8d asks for both figures)
     n_one = max(4, min(64, int(n_full / max(dt_full, 1e-3) / cores * 1.5)))
     t0 = time.time(); O.search_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, bd, first, n_one, 1); dt_one = time.time() - t0
+    # HM's OWN scalar xTZSearch (the reference's code compiled in place, oracle/_ref/libhmref.so -- prebuilt, it travels with the
+    # snapshot; test infrastructure like the oracle) over the same CTUs on ONE core, as the single-threaded encoder runs it; its
+    # tables must equal the oracle restatement's on the sample, or nothing is reported
+    ref_tz = None
+    try:
+        have_ref = O.ref_available() and hasattr(O.ref(), "ref_tz_frame")
+    except OSError:              # the prebuilt library does not load on this host: the oracle legs stand alone
+        have_ref = False
+    if have_ref:
+        n_ref = 64
+        t0 = time.time(); O.ref_tz_frame(cur, ref, (m, m), w, h, sr, LAMBDA, 1, bd, first, n_ref); dt = time.time() - t0
+        n_ref = max(64, min(ctus_x * 28, int(n_ref * 3.0 / max(dt, 1e-3))))
+        t0 = time.time(); rx, ry, rs = O.ref_tz_frame(cur, ref, (m, m), w, h, sr, LAMBDA, 1, bd, first, n_ref); dt_ref = time.time() - t0
+        _, _, ox, oy, os_ = O.tz_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, bd, first, n_ref, cores, True, True)
+        if not (np.array_equal(rx, ox) and np.array_equal(ry, oy) and np.array_equal(rs, os_)):
+            raise SystemExit("bench.py: the reference's xTZSearch and the oracle's restatement disagree on the timed sample: nothing reported")
+        ref_tz = {"kind": "reference", "cores": 1, "ctus_per_s": round(n_ref / dt_ref, 1),
+                  "sample": f"the reference's own TEncSearch::xTZSearch (oracle/_ref/libhmref.so), all 593 PUs of {n_ref} CTUs, 1 thread, {dt_ref:.2f} s; "
+                            f"tables identical to the oracle restatement's on these CTUs"}
     model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -158,6 +177,7 @@ def cpu_baseline(cur, ref, w, h, sr, lq, bd=8, budget_s=14.0):
         "tz": {"ctus_per_s": round(n_tz / dt_tz, 1), "gsad_equiv_per_s": round(s4 / dt_tz / 1e9, 4),
                "probes_per_s": round(probes / dt_tz, 0), "cores": cores,
                "sample": f"oracle xTZSearch restatement, all 593 PUs of {n_tz} CTUs, {dt_tz:.2f} s"},
+        "tz_reference": ref_tz,
     }
 
 

@@ -141,6 +141,10 @@ def ref():
         L.ref_frac_refine.argtypes = ([C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int16), C.c_int]
                                       + [C.c_int] * 4 + [C.c_double, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4
                                       + [C.POINTER(C.c_uint32)])
+        if hasattr(L, "ref_tz_frame"):   # harness of round 3 and later
+            L.ref_tz_frame.restype = C.c_long
+            L.ref_tz_frame.argtypes = [C.POINTER(C.c_int16), C.c_int, C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p, _i32p, _u32p]
         L.ref_frac_refine_bi.restype = None
         L.ref_frac_refine_bi.argtypes = L.ref_frac_refine.argtypes
         _ref = L
@@ -258,6 +262,20 @@ def tz_frame(cur, ref_plane, origin, pic_w, pic_h, sr, pred_q, lambda_q16, fen, 
     if want_results:
         return probes.value, s4.value, ox, oy, osad
     return probes.value, s4.value
+
+
+def ref_tz_frame(cur, ref_plane, origin, pic_w, pic_h, sr, lam, fen, bit_depth, ctu_first, ctu_count):
+    """the REFERENCE's own xTZSearch over all 593 PU shapes of a CTU range (oracle/_ref/libhmref.so, single-threaded like HM);
+    predictor (0,0).  -> (x, y, sad) int arrays [count, 593]"""
+    L = ref()
+    ox = np.zeros((ctu_count, NUM_PARTS), np.int32)
+    oy = np.zeros((ctu_count, NUM_PARTS), np.int32)
+    osad = np.zeros((ctu_count, NUM_PARTS), np.uint32)
+    cs, rs = cur.shape[1], ref_plane.shape[1]
+    rects = np.ascontiguousarray(slot_table().astype(np.int32))
+    L.ref_tz_frame(_addr(cur, origin[1] * cs + origin[0]), cs, _addr(ref_plane, origin[1] * rs + origin[0]), rs, pic_w, pic_h, sr, float(lam),
+                   int(fen), int(bit_depth), ctu_first, ctu_count, rects.reshape(-1), ox.reshape(-1), oy.reshape(-1), osad.reshape(-1))
+    return ox, oy, osad
 
 
 def frac_refine(plane_cur, cur_xy, plane_ref, ref_xy, w, h, int_mv, pred, lam_or_q16, use_had, bit_depth, use_ref=False, bi=False):

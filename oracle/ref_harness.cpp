@@ -170,6 +170,36 @@ void ref_tz_search(int16_t* org, int org_stride, int w, int h, int16_t* ref_at_p
   *mvx = mv.getHor(); *mvy = mv.getVer(); *sad = d;
 }
 
+// The reference's fast search over every PU shape of CTUs [ctu_first, ctu_first + ctu_count) of a picture pair: xTZSearch (what HM runs
+// with FastSearch=1, its default) for the 64x64 2Nx2N PU first, then the other 592 shapes seeded with its result like
+// m_integerMv2Nx2N (TEncSearch.cpp:3780-3789); predictor (0,0), window from xSetSearchRange.  rects: int32[593][4] (x, y, w, h) in slot
+// order.  The CPU baseline bench.py times on the GPU node's host (kind "reference", one core: HM is single-threaded); the same loop
+// as oracle/hm_oracle.c tz_worker, whose results must be identical.  Returns the number of PU searches.
+long ref_tz_frame(int16_t* cur, int cur_stride, int16_t* ref, int ref_stride, int pic_w, int pic_h, int sr, double lambda, int fen,
+                  int bit_depth, int ctu_first, int ctu_count, const int32_t* rects, int32_t* out_x, int32_t* out_y, uint32_t* out_sad) {
+  const int ctus_x = (pic_w + 63) / 64;
+  long n_searches = 0;
+  for (int i = 0; i < ctu_count; ++i) {
+    const int ctu = ctu_first + i, cu_x = (ctu % ctus_x) * 64, cu_y = (ctu / ctus_x) * 64;
+    int ltx, lty, rbx, rby;
+    ref_set_search_range(0, 0, sr, cu_x, cu_y, pic_w, pic_h, 64, &ltx, &lty, &rbx, &rby);
+    int imv_x = 0, imv_y = 0;
+    for (int n = 0; n < 593; ++n) {
+      const int s = n == 0 ? 592 : n - 1;
+      const int32_t* r = rects + 4 * s;
+      int mx, my;
+      uint32_t sad;
+      ref_tz_search(cur + (long)(cu_y + r[1]) * cur_stride + cu_x + r[0], cur_stride, r[2], r[3],
+                    ref + (long)(cu_y + r[1]) * ref_stride + cu_x + r[0], ref_stride, ltx, lty, rbx, rby, 0, 0, lambda, fen, bit_depth, sr,
+                    cu_x, cu_y, pic_w, pic_h, 64, n == 0 ? 0 : 1, imv_x, imv_y, &mx, &my, &sad);
+      if (n == 0) { imv_x = mx; imv_y = my; }
+      if (out_x) { out_x[(long)i * 593 + s] = mx; out_y[(long)i * 593 + s] = my; out_sad[(long)i * 593 + s] = sad; }
+      ++n_searches;
+    }
+  }
+  return n_searches;
+}
+
 // TEncSearch::xPatternSearchFracDIF for one PU, set up like xMotionEstimation does (TEncSearch.cpp:3792-3798):
 // getMotionCost(true, 0, ...), cost scale 1; the function itself switches to scale 0 for the quarter stage.
 static bool g_frac_bipred = false;
