@@ -73,3 +73,17 @@ def test_fractional_refinement_matches_reference(oracle_lib):
         a = oracle_lib.frac_refine(org, (o + x, o + y), ref, (o + x, o + y), w, h, mv, pred, lq, had, bd)
         b = oracle_lib.frac_refine(org, (o + x, o + y), ref, (o + x, o + y), w, h, mv, pred, lam, had, bd, use_ref=True, bi=True)
         assert a == b, ("bi", it, w, h, mv, pred, lam, had, bd)
+
+
+def test_tz_search_over_whole_ctus_matches_reference(oracle_lib):
+    """bench.py's CPU baseline legs: the reference's own xTZSearch over all 593 PU shapes of a CTU range (ref_tz_frame: 64x64 PU first,
+    the others seeded with its integer MV, TEncSearch.cpp:3780-3789) == the oracle's threaded restatement (hmo_tz_frame), 8 and 10 bit"""
+    from hmme import synth
+    for bd, sr in ((8, 64), (10, 24)):
+        w, h = 448, 320
+        cur, ref, _ = synth.make_pair(w, h, seed=60 + bd, bit_depth=bd)
+        m = synth.MARGIN
+        lq = oracle_lib.oracle().hmo_lambda_q16(57.9)
+        rx, ry, rs = oracle_lib.ref_tz_frame(cur, ref, (m, m), w, h, sr, 57.9, 1, bd, 8, 9)
+        _, _, ox, oy, os_ = oracle_lib.tz_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, bd, 8, 9, 4, True, True)
+        assert np.array_equal(rx, ox) and np.array_equal(ry, oy) and np.array_equal(rs, os_)
