@@ -901,6 +901,64 @@ __device__ __forceinline__ float me_dpp_f(float v, const int ctrl_b1) {
                  : __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));
 }
 
+// distortion of one 4x4 difference block d (row-major): SAD, or the Hadamard sum (xCalcHADs4x4; with KIND8 the quad's four 4x4
+// transforms are combined into the 8x8 transform, xCalcHADs8x8, and all four lanes return the block's value)
+template <int HAD, int KIND8>
+__device__ __forceinline__ uint32_t me_frac_dist(const float (&d)[16], float s1, float s2) {
+  uint32_t contrib;
+  if (!HAD) {
+    float sad = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sad += __builtin_fabsf(d[i]);
+    if (KIND8) {   // the quad's four 4x4 SADs belong to the same slots: hand out their sum
+      sad += me_dpp_f(sad, 1);
+      sad += me_dpp_f(sad, 0);
+    }
+    contrib = (uint32_t)sad;
+  } else {
+    float m[16];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {   // 4x4 Walsh-Hadamard: rows, then columns (xCalcHADs4x4)
+      const float a = d[4 * r] + d[4 * r + 3], b = d[4 * r + 1] + d[4 * r + 2], e = d[4 * r + 1] - d[4 * r + 2], f = d[4 * r] - d[4 * r + 3];
+      m[4 * r] = a + b; m[4 * r + 1] = a - b; m[4 * r + 2] = f + e; m[4 * r + 3] = f - e;
+    }
+    float z[16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float a = m[k] + m[12 + k], b = m[4 + k] + m[8 + k], e = m[4 + k] - m[8 + k], f = m[k] - m[12 + k];
+      z[k] = a + b; z[4 + k] = a - b; z[8 + k] = f + e; z[12 + k] = f - e;
+    }
+    float sum = 0.f;
+    if (KIND8) {   // combine the quad's four 4x4 transforms into the 8x8 transform (xCalcHADs8x8)
+      // two butterflies across the quad, each one v_fmac_f32 with a DPP source: z += t * z[neighbour], t = +-1 by
+      // role.  Odd roles hold the negated difference, which the absolute sum does not see.  One asm block keeps
+      // 16 instructions between a register's write and its DPP read (the hazard the assembler does not pad for).
+      asm("s_nop 1\n\t"
+          ME_FRAC_BFLY(%0, %16, "[1,0,3,2]") ME_FRAC_BFLY(%1, %16, "[1,0,3,2]") ME_FRAC_BFLY(%2, %16, "[1,0,3,2]") ME_FRAC_BFLY(%3, %16, "[1,0,3,2]")
+          ME_FRAC_BFLY(%4, %16, "[1,0,3,2]") ME_FRAC_BFLY(%5, %16, "[1,0,3,2]") ME_FRAC_BFLY(%6, %16, "[1,0,3,2]") ME_FRAC_BFLY(%7, %16, "[1,0,3,2]")
+          ME_FRAC_BFLY(%8, %16, "[1,0,3,2]") ME_FRAC_BFLY(%9, %16, "[1,0,3,2]") ME_FRAC_BFLY(%10, %16, "[1,0,3,2]") ME_FRAC_BFLY(%11, %16, "[1,0,3,2]")
+          ME_FRAC_BFLY(%12, %16, "[1,0,3,2]") ME_FRAC_BFLY(%13, %16, "[1,0,3,2]") ME_FRAC_BFLY(%14, %16, "[1,0,3,2]") ME_FRAC_BFLY(%15, %16, "[1,0,3,2]")
+          ME_FRAC_BFLY(%0, %17, "[2,3,0,1]") ME_FRAC_BFLY(%1, %17, "[2,3,0,1]") ME_FRAC_BFLY(%2, %17, "[2,3,0,1]") ME_FRAC_BFLY(%3, %17, "[2,3,0,1]")
+          ME_FRAC_BFLY(%4, %17, "[2,3,0,1]") ME_FRAC_BFLY(%5, %17, "[2,3,0,1]") ME_FRAC_BFLY(%6, %17, "[2,3,0,1]") ME_FRAC_BFLY(%7, %17, "[2,3,0,1]")
+          ME_FRAC_BFLY(%8, %17, "[2,3,0,1]") ME_FRAC_BFLY(%9, %17, "[2,3,0,1]") ME_FRAC_BFLY(%10, %17, "[2,3,0,1]") ME_FRAC_BFLY(%11, %17, "[2,3,0,1]")
+          ME_FRAC_BFLY(%12, %17, "[2,3,0,1]") ME_FRAC_BFLY(%13, %17, "[2,3,0,1]") ME_FRAC_BFLY(%14, %17, "[2,3,0,1]") ME_FRAC_BFLY(%15, %17, "[2,3,0,1]")
+          : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(z[4]), "+v"(z[5]), "+v"(z[6]), "+v"(z[7]), "+v"(z[8]), "+v"(z[9]),
+            "+v"(z[10]), "+v"(z[11]), "+v"(z[12]), "+v"(z[13]), "+v"(z[14]), "+v"(z[15])
+          : "v"(s1), "v"(s2));
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sum += __builtin_fabsf(z[i]);
+      sum += me_dpp_f(sum, 1);
+      sum += me_dpp_f(sum, 0);
+      contrib = ((uint32_t)sum + 2) >> 2;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sum += __builtin_fabsf(z[i]);
+      contrib = ((uint32_t)sum + 1) >> 1;
+    }
+  }
+  return contrib;
+}
+
 // STAGE 0: half-pel points (step 2 quarter units around the integer MV); STAGE 1: quarter-pel points around the
 // slot's half-pel winner (cqx, cqy).  P: 12 patch rows x 12 samples (3 * BPS dwords), patch (0,0) = block (-4,-4);
 // 8-bit samples arrive XORed with 0x80 (signed bytes p - 128: the 128 * 64 this removes IS the -8192 offset of the
@@ -1005,57 +1063,7 @@ __device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3 * BPS], c
           const float y = __builtin_amdgcn_fmed3f(a, clip_lo, maxv);   // clip, then round (the bounds are integers)
           d[4 * r + c] = orgM[4 * r + c] - (y + kRoundMagic);
         }
-      uint32_t contrib;
-      if (!HAD) {
-        float sad = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sad += __builtin_fabsf(d[i]);
-        if (KIND8) {   // the quad's four 4x4 SADs belong to the same slots: hand out their sum
-          sad += me_dpp_f(sad, 1);
-          sad += me_dpp_f(sad, 0);
-        }
-        contrib = (uint32_t)sad;
-      } else {
-        float m[16];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {   // 4x4 Walsh-Hadamard: rows, then columns (xCalcHADs4x4)
-          const float a = d[4 * r] + d[4 * r + 3], b = d[4 * r + 1] + d[4 * r + 2], e = d[4 * r + 1] - d[4 * r + 2], f = d[4 * r] - d[4 * r + 3];
-          m[4 * r] = a + b; m[4 * r + 1] = a - b; m[4 * r + 2] = f + e; m[4 * r + 3] = f - e;
-        }
-        float z[16];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float a = m[k] + m[12 + k], b = m[4 + k] + m[8 + k], e = m[4 + k] - m[8 + k], f = m[k] - m[12 + k];
-          z[k] = a + b; z[4 + k] = a - b; z[8 + k] = f + e; z[12 + k] = f - e;
-        }
-        float sum = 0.f;
-        if (KIND8) {   // combine the quad's four 4x4 transforms into the 8x8 transform (xCalcHADs8x8)
-          // two butterflies across the quad, each one v_fmac_f32 with a DPP source: z += t * z[neighbour], t = +-1 by
-          // role.  Odd roles hold the negated difference, which the absolute sum does not see.  One asm block keeps
-          // 16 instructions between a register's write and its DPP read (the hazard the assembler does not pad for).
-          asm("s_nop 1\n\t"
-              ME_FRAC_BFLY(%0, %16, "[1,0,3,2]") ME_FRAC_BFLY(%1, %16, "[1,0,3,2]") ME_FRAC_BFLY(%2, %16, "[1,0,3,2]") ME_FRAC_BFLY(%3, %16, "[1,0,3,2]")
-              ME_FRAC_BFLY(%4, %16, "[1,0,3,2]") ME_FRAC_BFLY(%5, %16, "[1,0,3,2]") ME_FRAC_BFLY(%6, %16, "[1,0,3,2]") ME_FRAC_BFLY(%7, %16, "[1,0,3,2]")
-              ME_FRAC_BFLY(%8, %16, "[1,0,3,2]") ME_FRAC_BFLY(%9, %16, "[1,0,3,2]") ME_FRAC_BFLY(%10, %16, "[1,0,3,2]") ME_FRAC_BFLY(%11, %16, "[1,0,3,2]")
-              ME_FRAC_BFLY(%12, %16, "[1,0,3,2]") ME_FRAC_BFLY(%13, %16, "[1,0,3,2]") ME_FRAC_BFLY(%14, %16, "[1,0,3,2]") ME_FRAC_BFLY(%15, %16, "[1,0,3,2]")
-              ME_FRAC_BFLY(%0, %17, "[2,3,0,1]") ME_FRAC_BFLY(%1, %17, "[2,3,0,1]") ME_FRAC_BFLY(%2, %17, "[2,3,0,1]") ME_FRAC_BFLY(%3, %17, "[2,3,0,1]")
-              ME_FRAC_BFLY(%4, %17, "[2,3,0,1]") ME_FRAC_BFLY(%5, %17, "[2,3,0,1]") ME_FRAC_BFLY(%6, %17, "[2,3,0,1]") ME_FRAC_BFLY(%7, %17, "[2,3,0,1]")
-              ME_FRAC_BFLY(%8, %17, "[2,3,0,1]") ME_FRAC_BFLY(%9, %17, "[2,3,0,1]") ME_FRAC_BFLY(%10, %17, "[2,3,0,1]") ME_FRAC_BFLY(%11, %17, "[2,3,0,1]")
-              ME_FRAC_BFLY(%12, %17, "[2,3,0,1]") ME_FRAC_BFLY(%13, %17, "[2,3,0,1]") ME_FRAC_BFLY(%14, %17, "[2,3,0,1]") ME_FRAC_BFLY(%15, %17, "[2,3,0,1]")
-              : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(z[4]), "+v"(z[5]), "+v"(z[6]), "+v"(z[7]), "+v"(z[8]), "+v"(z[9]),
-                "+v"(z[10]), "+v"(z[11]), "+v"(z[12]), "+v"(z[13]), "+v"(z[14]), "+v"(z[15])
-              : "v"(s1), "v"(s2));
-#pragma unroll
-          for (int i = 0; i < 16; ++i) sum += __builtin_fabsf(z[i]);
-          sum += me_dpp_f(sum, 1);
-          sum += me_dpp_f(sum, 0);
-          contrib = ((uint32_t)sum + 2) >> 2;
-        } else {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) sum += __builtin_fabsf(z[i]);
-          contrib = ((uint32_t)sum + 1) >> 1;
-        }
-      }
+      const uint32_t contrib = me_frac_dist<HAD, KIND8>(d, s1, s2);
       out[STAGE == 0 ? idxH[dyi][dxi] : idxQ[dyi][dxi]] = contrib;
     }
   }
@@ -1075,6 +1083,101 @@ constexpr uint32_t kFracKey0 = 0x3ffffu, kFracKey1 = 0x3fffffu;
 // `src`: window sample (-4,-4) of this CTU in the reference plane, `gpitch` bytes per row.  The 12x12 patch comes straight
 // from global memory: the windows of neighbouring CTUs overlap and stay in L2, and an LDS copy of the window (tried first)
 // was no faster while it capped the search range at 64 and the occupancy at one 16-bit workgroup per CU.
+// STAGE 0 (the nine half-pel points) with the filters SHARED between the points that use them.  The half-pel sample to the right of
+// integer column x is the half-pel sample to the left of x + 1, and likewise for rows: the horizontal half-pel pass is computed for five
+// columns (HH[r][k], k = 0..4: the samples left of columns 0..3 and right of column 3) instead of 2 x 4, the vertical half-pel pass for
+// five rows of each column (rows above 0..3 and below 3) instead of 2 x 4, and every filtered value is rounded and clipped once, not once
+// per point that reads it: 396 second-pass FMAs instead of 816, 165 first-pass dot products instead of 264.  Same values as
+// me_frac_eval<0, ...> bit for bit: every intermediate is exact in fp32 (me_frac_eval's header), so the order of summation is free.
+template <int HAD, int BPS, int KIND8>
+__device__ __forceinline__ void me_frac_eval0(const uint32_t (&P)[12][3 * BPS], const float (&orgM)[16], int role, int bd, float clip_lo,
+                                              uint32_t (&out)[9]) {
+  constexpr int PW = 3 * BPS;
+  constexpr int idxH[3][3] = {{5, 1, 6}, {3, 0, 4}, {7, 2, 8}};   // [dy+1][dx+1], s_acMvRefineH order (TEncSearch.cpp:51-75)
+  const float s1 = (role & 1) ? -1.f : 1.f, s2 = (role & 2) ? -1.f : 1.f;
+  const int sh1 = BPS == 1 ? 0 : bd - 8;
+  const int off1 = BPS == 1 ? 0 : -(8192 << sh1);
+  const float sc2 = BPS == 1 ? 1.f / 4096.f : __int_as_float((127 - (20 - bd)) << 23);
+  const float maxv = clip_lo + (BPS == 1 ? 255.f : (float)((1 << bd) - 1));
+  const float init = 524288.5f * sc2;
+  float cv[8];                                  // half-pel taps * 2^-sh2
+#pragma unroll
+  for (int t = 0; t < 8; ++t) cv[t] = (float)me_luma_tap(2, t) * sc2;
+  const float c64 = 64.f * sc2;
+  // first pass of patch row r with the tap window of (quarter offset q, output column c)
+  auto first = [&](int r, int q, int c) -> float {
+    int a = off1;
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      if (me_htap_dw<BPS>(q, c, k) == 0) continue;
+      if constexpr (BPS == 1) {
+        a = __builtin_amdgcn_sdot4((int)P[r][k], (int)me_htap_dw<BPS>(q, c, k), a, false);
+      } else {
+        typedef short v2s __attribute__((ext_vector_type(2)));
+        a = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, P[r][k]), __builtin_bit_cast(v2s, me_htap_dw<BPS>(q, c, k)), a, false);
+      }
+    }
+    return (float)(BPS == 1 ? a : a >> sh1);
+  };
+  auto clipround = [&](float a) -> float { return __builtin_amdgcn_fmed3f(a, clip_lo, maxv) + kRoundMagic; };
+  // one point: d = org - pred over the 4x4 block, pred(r, c) = y[r0 + r][c0 + c]
+#define ME_FRAC_POINT(Y, R0, C0, DYI, DXI)                                                   \
+  {                                                                                          \
+    float d[16];                                                                             \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r)                                            \
+      _Pragma("unroll") for (int c = 0; c < 4; ++c) d[4 * r + c] = orgM[4 * r + c] - Y[(R0) + r][(C0) + c]; \
+    out[idxH[DYI][DXI]] = me_frac_dist<HAD, KIND8>(d, s1, s2);                               \
+  }
+  // ---- half-pel columns: HH[r][k] = horizontal half-pel sample left of column k (k = 0..3) / right of column 3 (k = 4)
+  {
+    float HH[12][5];
+#pragma unroll
+    for (int r = 0; r < 12; ++r) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) HH[r][k] = first(r, -2, k);
+      HH[r][4] = first(r, 2, 3);
+    }
+    float yG[5][5], yZ[4][5];                     // vertical half-pel rows above 0..3 and below 3 / the integer rows
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        float a = init;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) a = __builtin_fmaf(cv[t], HH[j + t][k], a);
+        yG[j][k] = clipround(a);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) yZ[r][k] = clipround(__builtin_fmaf(c64, HH[r + 4][k], init));
+    }
+    ME_FRAC_POINT(yG, 0, 0, 0, 0) ME_FRAC_POINT(yG, 0, 1, 0, 2) ME_FRAC_POINT(yG, 1, 0, 2, 0) ME_FRAC_POINT(yG, 1, 1, 2, 2)
+    ME_FRAC_POINT(yZ, 0, 0, 1, 0) ME_FRAC_POINT(yZ, 0, 1, 1, 2)
+  }
+  // ---- integer columns
+  {
+    float V0[12][4];
+#pragma unroll
+    for (int r = 0; r < 12; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) V0[r][c] = first(r, 0, c);
+    float yG[5][4], yZ[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        float a = init;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) a = __builtin_fmaf(cv[t], V0[j + t][c], a);
+        yG[j][c] = clipround(a);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) yZ[r][c] = clipround(__builtin_fmaf(c64, V0[r + 4][c], init));
+    }
+    ME_FRAC_POINT(yG, 0, 0, 0, 1) ME_FRAC_POINT(yG, 1, 0, 2, 1) ME_FRAC_POINT(yZ, 0, 0, 1, 1)
+  }
+#undef ME_FRAC_POINT
+}
+
 template <int STAGE, int HAD, int BPS, int KIND8>
 __device__ __forceinline__ void me_frac_item(const uint8_t* __restrict__ src, int gpitch, const uint32_t* curl, const uint32_t* st,
                                              const uint16_t* __restrict__ cover, int pair, int role, int bd, float clip_lo, const uint32_t* tab_h,
@@ -1118,7 +1221,11 @@ __device__ __forceinline__ void me_frac_item(const uint8_t* __restrict__ src, in
   }
   uint32_t dist[9];
   const int cqx = STAGE ? 2 * ((int)((sv >> 18) & 3) - 1) : 0, cqy = STAGE ? 2 * ((int)((sv >> 20) & 3) - 1) : 0;
-  me_frac_eval<STAGE, HAD, BPS, KIND8>(P, orgM, cqx, cqy, role, bd, clip_lo, tab_h, tab_v, dist);
+#ifndef ME_FRAC_STAGE0_PLAIN
+  if constexpr (STAGE == 0) me_frac_eval0<HAD, BPS, KIND8>(P, orgM, role, bd, clip_lo, dist);
+  else
+#endif
+    me_frac_eval<STAGE, HAD, BPS, KIND8>(P, orgM, cqx, cqy, role, bd, clip_lo, tab_h, tab_v, dist);
   // Every slot of this position with the same key takes the distortions; the quad's lanes split the slot list.
   // (Round 3 tried to relieve these adds -- the large slots cover many positions, so lanes of one wave often add to the same address:
   // each quad starting its walk at another list position and two points per ds_add_u64 cut the kernel's LDS conflict cycles by 27 %
