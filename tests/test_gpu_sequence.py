@@ -189,6 +189,36 @@ def test_cpp_sequence_driver_streams_a_yuv_file_equal_to_the_oracle(tmp_path, or
             assert np.array_equal(qmv[i], oq) and np.array_equal(cost[i], oc), (i, cur, ref)
 
 
+@pytest.mark.parametrize("w,h,n,sr,bd", [(480, 320, 12, 16, 8), (1920, 1080, 8, 64, 8), (384, 256, 9, 24, 10)])
+def test_fuzz_streaming_configurations_equal_the_resident_run(engine, w, h, n, sr, bd):
+    """the streaming pipeline under many shapes -- plane rings from the bare minimum (every refill evicts a plane that was just read) to
+    roomy, 1..4 pairs per launch, 1..4 host buffers, refinement / download on and off -- must give the tables of the resident run, bit
+    for bit: a refill that overtook a search, a host buffer reused too early or a launch that read a plane before its fill would show"""
+    import torch
+    from hmme import sequence, shard, synth
+    engine.set_lambda(57.9)
+    seq = synth.Sequence(w, h, n, seed=99, bit_depth=bd)
+    pairs = shard.gop_pairs(n, "randomaccess")
+    dev = torch.device("cuda", 0)
+    base = sequence.run_rank(engine, seq, pairs, w, h, bd, sr, refine=True, device=dev)
+    want = {k: base[k].cpu() for k in ("mv", "sad", "qmv", "cost")}
+    rng = np.random.default_rng(w + n)
+    n_cfg = int(os.environ.get("HMME_STREAM_FUZZ_CASES", "10" if w < 1000 else "4"))
+    for it in range(n_cfg):
+        k = int(rng.integers(1, 5))
+        need = max(len({p for i in b for p in pairs[i]}) for b in sequence.plan_batches(pairs, k))
+        slots = int(rng.integers(need, need + 4)) if it % 3 else need            # every third run on the smallest possible ring
+        refine, download, hb = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), int(rng.integers(1, 5))
+        got = sequence.run_rank(engine, seq, pairs, w, h, bd, sr, stream_mode=True, pairs_per_launch=k, refine=refine, download=download,
+                                n_slots=slots, device=dev, host_buffers=hb)
+        tag = dict(k=k, slots=slots, refine=refine, download=download, host_buffers=hb)
+        for name in ("mv", "sad") + (("qmv", "cost") if refine else ()):
+            assert torch.equal(got[name].cpu(), want[name]), (tag, name)
+            if download:
+                assert torch.equal(got["host_" + name], want[name]), (tag, "host_" + name)
+        assert got["plane_slots"] <= slots and got["uploads"] >= len({p for pr in pairs for p in pr})
+
+
 def _planes(engine, w, h, bd, imgs):
     pls = []
     for img in imgs:
