@@ -17,8 +17,11 @@
  *   hmme_search_frame*     <- the same search batched over every CTU of a picture (the
  *                             reference has no batched form: it launches 2*(2SR+1)^2 kernels per
  *                             CTU from the host, TEncOpenCL.cpp:312-333)
+ *   hmme_search_pairs_device, <- the same for up to 16 (current, reference) picture pairs of a GOP in one launch
+ *   hmme_refine_pairs_device     (cfg/encoder_randomaccess_main.cfg:28-31, cfg/encoder_lowdelay_P_main.cfg:24-27)
  *   hmme_plane_*           <- the padded reference plane calcMotionVectors reads
- *                             (TComPicYuv, TLibCommon/TComPicYuv.cpp:91-92, 214-262)
+ *                             (TComPicYuv, TLibCommon/TComPicYuv.cpp:91-92, 214-262); hmme_plane_upload_* take what
+ *                             TVideoIOYuv::read delivers (TVideoIOYuv.cpp:247, :680: 8-bit or 16-bit little-endian samples)
  *   hmme_last_error        <- TEncOpenCL::checkError (TEncOpenCL.h:93-101)
  *   hmme_destroy           <- TEncOpenCL::~TEncOpenCL (TEncOpenCL.cpp:38-66)
  *
