@@ -1,6 +1,10 @@
 // CPU test of the C++ sequence driver's planning (hm-opencl_amd/host/SequenceME.h): launches cover the pairs in order, every launch
 // finds its pictures in the slots the plan says, no launch's own picture is evicted for it.  Exit code 0 = all invariants hold.
+#include <unistd.h>
+
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <map>
 #include <set>
 #include <string>
@@ -64,6 +68,32 @@ int main() {
   for (size_t c = 0; c < sizeof cases / sizeof cases[0]; ++c) {
     const int r = check(ra, cases[c][0], cases[c][1], cases[c][2] != 0);
     if (r) { printf("FAIL: k=%d slots=%d -> %d\n", cases[c][0], cases[c][1], r); rc = 1; }
+  }
+  // run() without a context fails with a message, no crash; the planning error (too few slots) surfaces through run() as well
+  {
+    SequenceConfig cfg = {128, 64, 8, 16, 4, 3, 0, false};
+    SequenceSearch s(0, cfg);
+    if (s.run(ra, LumaReader(), 0) != HMME_ERR_ARG || s.error().empty()) { printf("FAIL: run() without a context\n"); rc = 1; }
+  }
+  // the YUV file reader: 8-bit 4:2:0 and 16-bit 4:0:0, pictures out of order, beyond the end of the file
+  for (int bd = 8; bd <= 10; bd += 2) {
+    const int w = 48, h = 32, n = 3, bps = bd == 8 ? 1 : 2, chroma = bd == 8 ? 1 : 0;
+    const size_t luma = (size_t)w * h * bps, frame = luma + (chroma ? luma / 2 : 0);
+    std::vector<unsigned char> file(frame * n);
+    for (size_t i = 0; i < file.size(); ++i) file[i] = (unsigned char)(i * 7 + i / frame);
+    char path[] = "/tmp/hmme_seq_test_XXXXXX";
+    const int fd = mkstemp(path);
+    if (fd < 0 || write(fd, &file[0], file.size()) != (ssize_t)file.size()) { printf("FAIL: temp file\n"); return 1; }
+    close(fd);
+    std::string err;
+    LumaReader rd = yuv_file_reader(path, w, h, bd, chroma, &err);
+    std::vector<unsigned char> buf(luma);
+    const int order[3] = {2, 0, 1};
+    for (int i = 0; i < 3; ++i)
+      if (!rd || !rd(order[i], &buf[0]) || memcmp(&buf[0], &file[frame * order[i]], luma) != 0) { printf("FAIL: reader bd %d picture %d\n", bd, order[i]); rc = 1; }
+    if (rd && rd(n, &buf[0])) { printf("FAIL: read beyond the end of the file\n"); rc = 1; }
+    unlink(path);
+    if (yuv_file_reader("/nonexistent/file.yuv", w, h, bd, chroma, &err) || err.empty()) { printf("FAIL: missing file\n"); rc = 1; }
   }
   printf("%s\n", rc ? "FAIL" : "PASS");
   return rc;

@@ -154,3 +154,29 @@ def test_cpu_side_code_is_clean_under_asan_and_ubsan(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-4000:]
     assert "asan_driver: PASS" in r.stdout
+
+
+def test_cpp_sequence_driver_is_clean_under_asan_and_ubsan(tmp_path):
+    """hm-opencl_amd/host/SequenceME.cpp (launch / plane-slot planning, and -- without a GPU -- the failure path of run()) compiled with
+    -fsanitize=address,undefined together with tests/cpp/test_sequence_plan.cpp"""
+    import shutil
+    import subprocess
+    import torch
+    from hmme import api
+    if not shutil.which("hipcc"):
+        pytest.skip("ROCm headers / libamdhip64 not available")
+    api.build()
+    if torch.cuda.is_available():
+        pytest.skip("CPU-build check; on the GPU box the class is covered by tests/test_gpu_sequence.py")
+    exe = str(tmp_path / "seq_plan_asan")
+    csrc = os.path.join(ROOT, "hm-opencl_amd", "csrc")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++11", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
+                    "-I/opt/rocm/include", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_sequence_plan.cpp"),
+                    os.path.join(ROOT, "hm-opencl_amd", "host", "SequenceME.cpp"), "-L" + csrc, "-lhmme", "-Wl,-rpath," + csrc,
+                    "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    supp = tmp_path / "lsan.supp"
+    supp.write_text("leak:libamdhip64\nleak:libhsa-runtime64\nleak:libamd_comgr\n")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", LSAN_OPTIONS=f"suppressions={supp}:print_suppressions=0",
+               UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-1500:] + r.stderr[-4000:]
