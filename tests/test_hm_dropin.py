@@ -23,12 +23,14 @@ CFG_P4 = os.path.join(ROOT, "tests", "hm", "lowdelay_P4_small.cfg")      # four 
 CFG_RA = os.path.join(ROOT, "tests", "hm", "randomaccess_small.cfg")     # hierarchical B, GOP 8, references on both sides
 
 
-def _encode(tmp_path, opencl, frames=3, w=192, h=128, extra=(), exe=None, cfg=None, env_extra=None):
+def _encode(tmp_path, opencl, frames=3, w=192, h=128, extra=(), exe=None, cfg=None, env_extra=None, fade=0.0):
     from hmme import synth, yuv
     src = str(tmp_path / "in.yuv")
     pics = []
     for t in range(frames):
         cur, _, _ = synth.make_pair(w, h, seed=5, max_mv=0, noise_sigma=1.0, shift=(2 * t, t), margin=0)
+        if fade:   # a fade to black: what explicit weighted prediction is for
+            cur = np.clip(np.rint(cur * (1.0 - fade * t)), 0, 255)
         pics.append(cur.astype(np.uint8))
     yuv.write_luma_420(src, pics)
     env = dict(os.environ, HMME_TRACE="1", **(env_extra or {}))
@@ -150,6 +152,28 @@ def test_patched_encoder_gpu_refinement_of_the_biprediction_pass(tmp_path, cfg, 
     bits, bits_cpu_frac = sum(b for _, b, _ in p[1:]), sum(b for _, b, _ in p1[1:])
     assert abs(bits - bits_cpu_frac) < 0.05 * bits_cpu_frac + 300, (bits, bits_cpu_frac)
     print("bi-prediction refinement from the tables:", p, "\nCPU xPatternSearchFracDIF:", p1, "\n", m.group(0))
+
+
+@pytest.mark.gpu
+def test_patched_encoder_leaves_weighted_prediction_slices_to_the_cpu_search(tmp_path):
+    """--WeightedPredP=1 on a fade: HM estimates explicit weights, and its CPU search then prices weighted SADs (xGetSADw,
+    setWpScalingDistParam at TEncSearch.cpp:3740) -- not what the engine (or the reference's kernel) computes.  The patch routes
+    such slices to the CPU search: the bitstream must equal the CPU encoder's bit for bit when every slice is weighted, and
+    HMME_VERIFY must never see a difference."""
+    _build()
+    common = dict(frames=4, w=208, h=120, cfg=CFG, extra=("--SearchRange=24", "--WeightedPredP=1"), fade=0.12)
+    r, p = _encode(tmp_path, 1, exe=EXE_HM, env_extra={"HMME_VERIFY": "1"}, **common)
+    m = _TRACE.search(r.stderr)
+    calls, failed, edge, bi, verified, differ = (int(v) for v in m.groups()) if m else (0, 0, 0, 0, 0, 0)
+    assert failed == 0 and differ == 0
+    r0, p0 = _encode(tmp_path, 0, exe=EXE_HM, **common)
+    rn, pn = _encode(tmp_path, 1, exe=EXE_HM, **dict(common, extra=("--SearchRange=24",)))          # the same clip without WP: engine in use
+    mn = _TRACE.search(rn.stderr)
+    assert mn and int(mn.group(1)) > calls, "the weighted run should have sent fewer (or no) CTUs to the engine"
+    weighted_everywhere = calls == 0
+    if weighted_everywhere:      # every P slice carried weights: the patched encoder IS the CPU encoder
+        assert p == p0, (p, p0)
+    print("WP fade:", p, "CPU:", p0, "engine calls with / without WP:", calls, int(mn.group(1)))
 
 
 @pytest.mark.gpu
