@@ -86,7 +86,10 @@ class _Reader(threading.Thread):
     def run(self):
         try:
             for poc in self.order:
-                i, ev = self.free.get()        # handed back by the consumer only after it has ISSUED the buffer's upload
+                item = self.free.get()         # handed back by the consumer only after it has ISSUED the buffer's upload
+                if item is None:               # the consumer gave up (an error on its side)
+                    return
+                i, ev = item
                 if ev is not None:
                     ev.synchronize()           # ... and that upload has run
                 t0 = time.perf_counter()
@@ -157,6 +160,7 @@ def run_rank(eng, source, pairs, width, height, bit_depth, search_range, *, stre
             e.record(dl)
 
     planes = []
+    reader = None
     try:
         if not stream_mode:
             # ---- resident: one plane per picture, uploaded before the clock starts
@@ -219,6 +223,8 @@ def run_rank(eng, source, pairs, width, height, bit_depth, search_range, *, stre
         out["plane_slots"] = len(planes)
         out["uploads"] = len(ev_pairs["upload"]) if stream_mode else len(pocs)
     finally:
+        if reader is not None and reader.is_alive():
+            reader.free.put(None)              # unblocks a reader that waits for a buffer after an error on this side
         torch.cuda.synchronize(dev)
         for pl in planes:
             pl.close()
