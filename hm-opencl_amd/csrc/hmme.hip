@@ -943,7 +943,7 @@ static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_para
   else {
     if (head)
       hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, grid(head), block, 0, s, (MeJob*)ctx->d_jobs, (const int16_t*)d_pred_q, first, count,
-                         n_refs, cur->width, cur->height, fp->search_range, 0, head);
+                         n_refs, cur->width, cur->height, fp->search_range, 0, head, 1);
     if (n_tail)
       hipLaunchKernelGGL(hmme::me_prep_jobs_split_kernel, grid(n_tail), block, 0, s, (MeJob16*)((uint8_t*)ctx->d_jobs + pl->tail_jobs_off), ctx->d_first_strip,
                          (const int16_t*)d_pred_q, first, count, n_refs, cur->width, cur->height, fp->search_range, pl->tail_parts, head, n_tail);
@@ -1124,7 +1124,7 @@ int hmme_refine_pairs_device(hmme_ctx* ctx, const hmme_plane* const* curs, const
   }
   if (rc == HMME_OK) {
     hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, dim3((jobs + 255) / 256), dim3(256), 0, s, (MeJob*)ctx->d_jobs, (const int16_t*)d_pred_q,
-                       pl.first, pl.count, n_pairs, curs[0]->width, curs[0]->height, fp->search_range, 0, jobs);
+                       pl.first, pl.count, n_pairs, curs[0]->width, curs[0]->height, fp->search_range, 0, jobs, 0);
     const int had = use_hadamard ? 1 : 0, wide = curs[0]->bps == 2 ? 1 : 0;
     using frac_fn = void (*)(const RefSet, int, const RefSet, int, const MeJob*, const uint16_t*, const int16_t*, uint32_t, int, int16_t*, uint32_t*);
     static const frac_fn fns[2][2] = {{hmme::me_frac_kernel<0, 1>, hmme::me_frac_kernel<1, 1>}, {hmme::me_frac_kernel<0, 2>, hmme::me_frac_kernel<1, 2>}};

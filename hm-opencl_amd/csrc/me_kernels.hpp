@@ -175,6 +175,22 @@ struct MeJob16 {
   int32_t job;         // index into the result arrays
 };
 
+// XCD-aware order of a launch's workgroups.  The dispatcher deals workgroup p of a grid to XCD p % 8, and each of the 8 XCDs has its own
+// 4 MB L2.  The windows of neighbouring CTUs overlap by two thirds (192 of 192 + 64 columns, likewise rows): if neighbours run on the
+// same XCD at about the same time their windows come out of that L2 instead of HBM.  So the N units of work of a launch (CTU searches
+// in raster order, or their strips) are cut into 8 contiguous bands, and the p-th workgroup takes unit number (p >> 3) of band (p & 7):
+// unit q <-> position p are a bijection on [0, N).  Results do not depend on it (every unit carries / derives its own output index).
+__host__ __device__ inline int me_xcd_unit(int p, int n) {          // position -> unit
+  const int x = p & 7, base = n >> 3, rem = n & 7;
+  return x * base + (x < rem ? x : rem) + (p >> 3);
+}
+__host__ __device__ inline int me_xcd_position(int q, int n) {      // unit -> position
+  const int base = n >> 3, rem = n & 7, big = rem * (base + 1);
+  if (q < big) return (q % (base + 1)) * 8 + q / (base + 1);
+  const int r = q - big;                                             // base >= 1 here: q >= big means some band has `base` units
+  return (r % base) * 8 + rem + r / base;
+}
+
 // number of tasks me_search_kernel makes out of a wx x wy window (same arithmetic on host and device; the default is the split
 // kernel's task size: host code and the prep kernels only count tasks for split launches)
 // "fold": with 33 quads per row (the 129-wide window) and an odd number of rows, the 32-quad part's last iteration has an
@@ -311,6 +327,7 @@ me_search_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pi
     tile_off = (unsigned long long)(((jb.job >> 29) & 1) * kTileStep) << 16 | (unsigned long long)(((jb.job >> 30) & 1) * kTileStep);
   } else {
     job = ((const MeJob*)jobs_v)[blockIdx.x];
+    out_job = me_xcd_unit(blockIdx.x, gridDim.x);   // the job table of a whole-job launch is in XCD order (me_prep_jobs_kernel)
   }
   const uint8_t* __restrict__ ref_base = refs.base[job.ctu_x & 63];
   const uint8_t* __restrict__ cur_base = curs.base[job.ctu_x & 63];
@@ -466,7 +483,7 @@ me_search_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pi
     const unsigned long long v = best64[s];
     const int mvx = job.lt_x + (int)(v & 0xffff), mvy = job.lt_y + (int)((v >> 16) & 0xffff);
     const uint32_t cost = (uint32_t)(v >> 32);
-    const long o = (long)blockIdx.x * kParts + s;
+    const long o = (long)out_job * kParts + s;
     out_mv[2 * o] = (int16_t)mvx;
     out_mv[2 * o + 1] = (int16_t)mvy;
     out_sad[o] = cost - me_mv_cost(lambda_q16, mvx, mvy, job.pred_x, job.pred_y);
@@ -497,11 +514,13 @@ __host__ __device__ inline void set_search_range(int pred_x, int pred_y, int sr,
 // one job per CTU of the picture from the per-CTU predictors
 // job i = reference (i / ctu_count), CTU ctu_first + (i % ctu_count); pred_q is [n_refs][n_ctu][2]
 // jobs [job0, job0 + n_jobs) of the ctu_count * n_refs (CTU, reference) searches of a launch; jobs[] is indexed from job0
+// xcd_order: jobs[] is written in the XCD-aware order of me_search_kernel<FEN, 0> (position li holds job job0 + me_xcd_unit(li, n_jobs));
+// 0 for the refinement kernel, which takes job blockIdx.x
 __global__ void me_prep_jobs_kernel(MeJob* jobs, const int16_t* __restrict__ pred_q, int ctu_first, int ctu_count,
-                                    int n_refs, int pic_w, int pic_h, int sr, int job0, int n_jobs) {
+                                    int n_refs, int pic_w, int pic_h, int sr, int job0, int n_jobs, int xcd_order) {
   const int li = blockIdx.x * blockDim.x + threadIdx.x;
   if (li >= n_jobs) return;
-  const int i = job0 + li;
+  const int i = job0 + (xcd_order ? me_xcd_unit(li, n_jobs) : li);
   const int r = i / ctu_count;
   const int ctus_x = (pic_w + 63) >> 6, n_ctu = ctus_x * ((pic_h + 63) >> 6);
   const int ctu = ctu_first + (i - r * ctu_count);
@@ -762,24 +781,23 @@ __global__ void me_prep_jobs16_kernel(MeJob16* jobs, int* first_strip_of_job, co
   const int wy = rby - lty + 1;
   const int n_strips = i < tail_first ? n_strips_head : tail_strips;
   const int base = i < tail_first ? i * n_strips_head : tail_first * n_strips_head + (i - tail_first) * tail_strips;
-  first_strip_of_job[i] = base;
+  const int n_units = tail_first * n_strips_head + (ctu_count * n_refs - tail_first) * tail_strips;   // workgroups of the launch
+  first_strip_of_job[i] = me_xcd_position(base, n_units);
   // strips of the height me_strip_rows16 picks for this window, the last one takes the rest; strips beyond the window (clipped
   // windows need fewer) are empty: y0 == y1
   // head jobs: the planner's choice within n_strips; tail jobs: exactly tail_strips equal pieces (the host chose that number for
   // the sake of the launch's last round, not for this window)
   const int h = i < tail_first ? me_strip_rows16(rbx - ltx + 1, wy, rows_max, n_strips) : max(1, (wy + n_strips - 1) / n_strips);
-  const int xcd_period = (n_strips & 1) ? 8 : (n_strips & 2) ? 4 : (n_strips & 4) ? 2 : 1;
   for (int s = 0; s < n_strips; ++s) {
     MeJob16 js;
     js.j = j;
     js.y0 = (int16_t)min(wy, s * h);
     js.y1 = (int16_t)min(wy, (s + 1) * h);
     js.job = i;
-    // Workgroup g runs on XCD g % 8 and each XCD works through its eighth of the grid on its own: strips of unequal height must
-    // not land on a fixed XCD (with two strips per CTU every tall strip sat on an even XCD and the launch took as long as if all
-    // strips were tall).  The XCD of a job's first workgroup repeats every 8 / gcd(n_strips, 8) jobs: the strip order rotates by
-    // one each time it does, which deals every height to every XCD.
-    jobs[base + (s + i / xcd_period) % n_strips] = js;
+    // XCD-aware order (me_xcd_position): the strips of a CTU, whose window rows overlap by 63, and the CTUs next to it run on ONE
+    // XCD, one after the other; every XCD gets all strips of its CTUs, so strips of unequal height cannot pile up on one XCD (round 2
+    // rotated the strip order per job for that)
+    jobs[me_xcd_position(base + s, n_units)] = js;
   }
 }
 
