@@ -89,9 +89,18 @@ class TEncOpenCL {
   Bool fracStored(Int list, Int refIdx, Int poc, Int ctuAddr) const {
     return tablesValidFor(list, refIdx, poc, ctuAddr) && m_fracTag[list][refIdx];
   }
-  const TComMv& getFracMv(Int list, Int refIdx, Int slot) const { return m_fracMvTab[list][refIdx][slot]; }
-  Distortion getFracDist(Int list, Int refIdx, Int slot) const { return m_fracDistTab[list][refIdx][slot]; }
-  Distortion getFracCostStored(Int list, Int refIdx, Int slot) const { return m_fracCostTab[list][refIdx][slot]; }
+  /// stored tables of [list][refIdx]; where none are stored (fracStored() false: the refinement failed, was never requested, or
+  /// the indices are out of range) these return what xPoison writes -- MV (0,0) and the largest Distortion -- never stale or
+  /// unallocated memory: a host must stay up on exactly the path where the engine reported an error
+  const TComMv& getFracMv(Int list, Int refIdx, Int slot) const {
+    return xFracReadable(list, refIdx, slot) ? m_fracMvTab[list][refIdx][slot] : m_zeroMv;
+  }
+  Distortion getFracDist(Int list, Int refIdx, Int slot) const {
+    return xFracReadable(list, refIdx, slot) ? m_fracDistTab[list][refIdx][slot] : (Distortion)~(Distortion)0;
+  }
+  Distortion getFracCostStored(Int list, Int refIdx, Int slot) const {
+    return xFracReadable(list, refIdx, slot) ? m_fracCostTab[list][refIdx][slot] : (Distortion)~(Distortion)0;
+  }
   /// HMME_GPU_FRAC=1: the patched encoder serves xPatternSearchFracDIF (TEncSearch.cpp:3798) from these tables
   static Bool gpuFracEnabled();
 
@@ -134,6 +143,9 @@ class TEncOpenCL {
     TComMv mv[NUM_CTU_PARTS];
   };
   Void xPoison(Tables& t);
+  Bool xFracReadable(Int list, Int refIdx, Int slot) const {
+    return m_fracMvTab && list >= 0 && list < 2 && refIdx >= 0 && refIdx < 33 && slot >= 0 && slot < NUM_CTU_PARTS && m_fracTag[list][refIdx];
+  }
 
   hmme_ctx* m_ctx;
   Int m_deviceId;
@@ -155,6 +167,7 @@ class TEncOpenCL {
   Distortion m_fracCost[NUM_CTU_PARTS];
   TComMv m_fracPred;                   // predictor the refinement of the last call priced its MVs against
   Bool m_fracTag[2][33];
+  TComMv m_zeroMv;                     // what the stored-table getters hand out when nothing is stored
   TComMv (*m_fracMvTab)[33][NUM_CTU_PARTS];          // [2][33][593], allocated on first use (313 KB + 2 x 157 KB)
   Distortion (*m_fracDistTab)[33][NUM_CTU_PARTS];
   Distortion (*m_fracCostTab)[33][NUM_CTU_PARTS];

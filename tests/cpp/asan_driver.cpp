@@ -98,6 +98,53 @@ int main() {
     for (int i = 0; i < NUM_CTU_PARTS; ++i) CHECK(me.getX()[i] == 0 && me.getY()[i] == 0 && me.getRuiCost()[i] == 0xFFFFFFFFu);
   me.calcMotionVectorsEdge(&c8[M * stride + M + 128], stride, 8, 8, &r8[M * stride + M + 128], stride, SR, TComMv(3, -2), 128, 0, W, H);
   CHECK(me.lastCallOk() == have_gpu && me.numCalls() == 2);
+  // ---- the refinement tables on the path where the engine reported an error (gpurun_out/r03p: the class's stored-table getters
+  // indexed tables that storeFrac never allocated).  A TEncOpenCL whose createBuffers FAILED (device -1 never exists, with or
+  // without a GPU in the box): calcMotionVectors -> storeFrac -> every getter must hand out the poison values, in range or not
+  {
+    TEncOpenCL bad;
+    bad.setDeviceId(-1);
+    CHECK(!bad.findDevice(-1));
+    CHECK(!bad.createBuffers(64, 64, SR));
+    bad.setCostMode(TEncOpenCL::ME_MODE_HM);
+    bad.setFastEnc(true);
+    bad.setRefine(true, true);
+    bad.setPredictor(TComMv(1, -1));
+    bad.setSearchRangeRB(TComMv((Short)SR, (Short)SR));
+    bad.calcMotionVectors(&c8[M * stride + M], &r8[M * stride + M], stride, stride, SR, &lt);
+    CHECK(!bad.lastCallOk() && !bad.fracOk() && bad.numFailed() == 1);
+    bad.markTables(1, 2, 40, 9);
+    bad.storeFrac(1, 2);
+    bad.storeFrac(-1, 99);                                       // out-of-range indices are ignored
+    CHECK(bad.tablesValidFor(1, 2, 40, 9) && !bad.fracStored(1, 2, 40, 9) && !bad.fracStored(-1, 99, 40, 9));
+    const int lists[] = {-1, 0, 1, 2}, refs[] = {-1, 0, 2, 32, 33}, slots[] = {-1, 0, 592, 593};
+    for (int l : lists)
+      for (int r : refs)
+        for (int s2 : slots) {
+          CHECK(bad.getFracMv(l, r, s2).getHor() == 0 && bad.getFracMv(l, r, s2).getVer() == 0);
+          CHECK(bad.getFracDist(l, r, s2) == 0xFFFFFFFFu && bad.getFracCostStored(l, r, s2) == 0xFFFFFFFFu);
+        }
+    for (int i = 0; i < NUM_CTU_PARTS; ++i)
+      CHECK(bad.getMvs()[i].getHor() == 0 && bad.getRuiCost()[i] == 0xFFFFFFFFu && bad.getMvs(true)[i].getVer() == 0);
+  }
+  if (have_gpu) {   // a successful store, then a failed call for the same [list][refIdx]: the stored tables are invalidated, not kept
+    me.setCostMode(TEncOpenCL::ME_MODE_HM);
+    me.setFastEnc(true);
+    me.setRefine(true, true);
+    me.setPredictor(TComMv(0, 0));
+    me.setSearchRangeRB(TComMv((Short)SR, (Short)SR));
+    me.calcMotionVectors(&c8[M * stride + M], &r8[M * stride + M], stride, stride, SR, &lt);
+    CHECK(me.lastCallOk() && me.fracOk());
+    me.markTables(0, 0, 1, 0);
+    me.storeFrac(0, 0);
+    CHECK(me.fracStored(0, 0, 1, 0) && me.getFracCostStored(0, 0, 592) == me.getFracCost()[592]);
+    c8[M * stride + M] = 9999;                                   // out of any range: the next call fails
+    me.calcMotionVectors(&c8[M * stride + M], &r8[M * stride + M], stride, stride, SR, &lt);
+    CHECK(!me.lastCallOk() && !me.fracOk());
+    me.markTables(0, 0, 1, 1);
+    me.storeFrac(0, 0);
+    CHECK(!me.fracStored(0, 0, 1, 1) && me.getFracCostStored(0, 0, 592) == 0xFFFFFFFFu && me.getFracMv(0, 0, 592).getHor() == 0);
+  }
   printf("asan_driver: PASS (%s)\n", have_gpu ? "with GPU" : "no GPU: failure paths");
   return 0;
 }

@@ -161,9 +161,15 @@ int main() {
     if (!me.lastCallOk() || !me.fracOk()) { fprintf(stderr, "search + refine call failed\n"); ++failures; }
     me.markTables(1, 2, 40, 9);
     me.storeFrac(1, 2);
-    if (!me.fracStored(1, 2, 40, 9) || me.fracStored(1, 2, 40, 8) || me.fracStored(0, 2, 40, 9)) { fprintf(stderr, "frac table tags\n"); ++failures; }
+    const bool stored = me.fracStored(1, 2, 40, 9);
+    if (!stored || me.fracStored(1, 2, 40, 8) || me.fracStored(0, 2, 40, 9)) { fprintf(stderr, "frac table tags\n"); ++failures; }
+    // tables nobody stored read as poison (never as unallocated memory): [0][2] was not stored, and neither is anything out of range
+    if (me.getFracCostStored(0, 2, 5) != 0xFFFFFFFFu || me.getFracDist(0, 2, 5) != 0xFFFFFFFFu || me.getFracMv(0, 2, 5).getHor() != 0 ||
+        me.getFracCostStored(1, 2, 593) != 0xFFFFFFFFu || me.getFracCostStored(2, 2, 0) != 0xFFFFFFFFu) {
+      fprintf(stderr, "unstored refinement tables do not read as poison\n"); ++failures;
+    }
     const uint32_t lq = hmo_lambda_q16(lambda);
-    for (int slot = 0; slot < NUM_CTU_PARTS; slot += 16) {
+    for (int slot = 0; stored && slot < NUM_CTU_PARTS; slot += 16) {   // the stored tables are read only when fracStored() says so
       hmo_rect r;
       hmo_slot_rect(slot, &r);
       const TComMv imv = me.getMvs()[slot];
@@ -279,6 +285,31 @@ int main() {
     if (me.getX()[i] != 0 || me.getY()[i] != 0 || me.getRuiCost()[i] != 0xFFFFFFFFu || me.getMvs()[i].getHor() != 0) {
       fprintf(stderr, "slot %d not poisoned after a failed call\n", i); ++failures; break;
     }
+  // ... and neither are refinement tables: a failed search + refine call, stored for a [list][refIdx] that held good tables before
+  // (stored above for [1][2]), leaves that entry unreadable -- the getters hand out poison (gpurun_out/r03p: they used to index
+  // tables that were never allocated when the very first call failed)
+  me.setCostMode(TEncOpenCL::ME_MODE_HM);
+  me.setRefine(true, true);
+  me.setSearchRangeRB(TComMv(8, 8));
+  me.calcMotionVectors(&cur[M * stride + M], &ref[M * stride + M], stride, stride, SR, &lt0);
+  if (me.lastCallOk() || me.fracOk()) { fprintf(stderr, "failed search + refine call reported ok\n"); ++failures; }
+  me.markTables(1, 2, 41, 0);
+  me.storeFrac(1, 2);
+  if (me.fracStored(1, 2, 41, 0) || me.getFracCostStored(1, 2, 592) != 0xFFFFFFFFu || me.getFracDist(1, 2, 0) != 0xFFFFFFFFu ||
+      me.getFracMv(1, 2, 100).getHor() != 0) { fprintf(stderr, "refinement tables of a failed call are readable\n"); ++failures; }
+  {
+    TEncOpenCL fresh;   // the very first call of an object fails: nothing was ever allocated
+    if (!fresh.findDevice(0) || !fresh.createBuffers(64, 64, SR)) return 2;
+    fresh.setCostMode(TEncOpenCL::ME_MODE_HM);
+    fresh.setRefine(true, true);
+    fresh.setSearchRangeRB(TComMv(8, 8));
+    fresh.calcMotionVectors(&cur[M * stride + M], &ref[M * stride + M], stride, stride, SR, &lt0);
+    fresh.markTables(0, 0, 1, 0);
+    fresh.storeFrac(0, 0);
+    if (fresh.lastCallOk() || fresh.fracStored(0, 0, 1, 0) || fresh.getFracCostStored(0, 0, 592) != 0xFFFFFFFFu || fresh.getFracMv(0, 0, 0).getVer() != 0) {
+      fprintf(stderr, "fresh object, failed first call: refinement getters\n"); ++failures;
+    }
+  }
   printf("%s (%d mismatches)\n", failures ? "FAIL" : "PASS", failures);
   return failures ? 1 : 0;
 }
