@@ -7,11 +7,26 @@ FEN 1 (encoder_lowdelay_P_main.cfg), all 593 PU shapes per CTU.
 
 A *step* = one whole-picture search (2040 CTUs at 2160p) on every rank; ranks hold different
 frames of the sequence (frame sharding, no data-path collective) and the per-step results are
-gathered with RCCL (torch.distributed "nccl") when N > 1.  Inputs are resident in HBM before the
-timed region; the timed region is K steps between barrier + synchronize, max over ranks.
-Rank 0 prints ONE JSON line: metric GSAD/s (4x4-block SAD evaluations per second, whole job),
-plus `roofline` (algorithmic bytes / measured kernel time against 8 TB/s) and `cpu_baseline`
-(the CPU oracle's exhaustive search and HM's xTZSearch restatement timed on this node's cores).
+gathered to rank 0 with RCCL (torch.distributed "nccl": grouped ncclSend / ncclRecv) when N > 1.
+Inputs are resident in HBM before the timed region; the timed region is K steps between
+barrier + synchronize, max over ranks.  Rank 0 prints ONE JSON line: metric GSAD/s (4x4-block SAD
+evaluations per second, whole job), plus `roofline` (algorithmic bytes / measured kernel time
+against 8 TB/s) and `cpu_baseline` (the CPU oracle's exhaustive search and HM's xTZSearch
+restatement timed on this node's cores).
+
+N > 1: under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process is one rank.
+Invoked plainly as `python bench.py --gpus N` it starts the N ranks itself -- a child
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` launched BEFORE anything in this
+process touches the GPU -- and relays rank 0's line and the exit code.  The line then carries the
+evidence that N devices took part: `ranks_seen`, every rank's device (PCI bus id; N distinct),
+per-rank kernel and step times, the gather's time and bytes, and a cross-rank check (CRC of every
+rank's tables before the gather == CRC of the block rank 0 received; CTUs of the last rank against
+the CPU oracle).
+
+At N = 1 the line also times and verifies, after the headline and never inside `value`, the other
+single-GPU BASELINE configurations (`configs`: 1080p SR 64; 2160p 10-bit SR 128; the 64-picture
+random-access sequence streamed through one GPU) and the refinement kernel on coherent, mixed and
+unrelated content (`refine`).
 """
 import argparse
 import ctypes
@@ -68,7 +83,7 @@ def pmc_profile(size, sr, bd):
         d = json.load(open(os.path.join(ROOT, "profiles", f"latest_pmc_{profile_label(size, sr, bd)}.json")))
     except (OSError, ValueError):
         return {}
-    if d.get("library_build_id") != library_build_id():
+    if d.get("library_build_id") != library_build_id() or library_build_id() in ("", "unknown"):   # a library without an id proves nothing
         return {"stale": True}
     return d
 
@@ -92,9 +107,9 @@ def usable_cores():
     return n
 
 
-def verify_against_oracle(res, cur, ref, w, h, sr, lq, bd):
+def verify_against_oracle(res, cur, ref, w, h, sr, lq, bd, what="tables of the timed step"):
     """res: int32 [2, n_refs, n_ctu, 593] (TComMv words, SADs) of the last timed step; reference 0 is checked bit-exactly
-    against the oracle's exhaustive search on four CTUs.  Raises SystemExit on a mismatch."""
+    against the oracle's exhaustive search on four CTUs (corner, interior, partial bottom row).  Raises SystemExit on a mismatch."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
     from hmme import synth
@@ -107,7 +122,7 @@ def verify_against_oracle(res, cur, ref, w, h, sr, lq, bd):
     for ctu in sample:
         ox, oy, osad = O.search_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, bd, ctu, 1, 1)
         if not (np.array_equal(mv[ctu, :, 0], ox[0]) and np.array_equal(mv[ctu, :, 1], oy[0]) and np.array_equal(sad[ctu], osad[0])):
-            raise SystemExit(f"bench.py: tables of the timed step differ from the CPU oracle at CTU {ctu}: nothing reported")
+            raise SystemExit(f"bench.py: {what} differ from the CPU oracle at CTU {ctu}: nothing reported")
     return {"ctus": sample, "slots": 593 * len(sample), "against": "oracle exhaustive search (bit-exact)", "seconds": round(time.time() - t0, 2)}
 
 
@@ -181,7 +196,7 @@ def cpu_baseline(cur, ref, w, h, sr, lq, bd=8, budget_s=14.0):
     }
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -192,12 +207,204 @@ def main():
     ap.add_argument("--refs", type=int, default=1, help="reference pictures searched per step in one launch (lowdelay_P uses 4)")
     ap.add_argument("--pairs", type=int, default=1, help="DIFFERENT (current, reference) picture pairs searched per step in one launch "
                     "(hmme_search_pairs_device: what an open-loop pass over a sequence of small pictures does); excludes --refs")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="headline only: no CPU legs, no oracle check, no extra configurations "
+                    "(tools/profile_bench.sh profiles this command)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE configurations and the refinement contents")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-gpu: rehearse the N > 1 code path on a one-GPU box (not a measurement)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.size not in SIZES:
+        try:
+            w, h = (int(v) for v in args.size.lower().split("x"))
+        except ValueError:
+            ap.error("--size: %s, or WIDTHxHEIGHT" % ", ".join(sorted(SIZES)))
+        if w < 64 or h < 64 or w % 8 or h % 8:
+            ap.error("--size: width and height must be multiples of 8, at least 64")
+    if max(1, args.pairs) > 1 and args.refs > 1:
+        ap.error("--pairs and --refs exclude each other")
+    return args
 
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as a child torch.distributed.run (one
+    process per GPU, rendezvous on 127.0.0.1) and relay rank 0's JSON line and the exit code.  Nothing in THIS process has touched
+    the GPU (torch is not even imported yet): a process that has initialised the GPU must not be replaced or forked on this pool."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), HMME_BENCH_SELF_LAUNCHED="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in child.stdout:                      # rank 0's line goes to stdout as the only line; everything else is diagnostics
+        if ln.startswith('{"metric"'):
+            line = ln
+        else:
+            sys.stderr.write(ln)
+    rc = child.wait()
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks exited without a result line\n")
+        rc = 1
+    if line is not None and rc == 0:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return rc
+
+
+def device_identity(torch, local_rank):
+    """what proves that a rank ran on a device of its own: name, PCI bus id (hipDeviceGetPCIBusId) and uuid of its GPU"""
+    props = torch.cuda.get_device_properties(local_rank)
+    ident = {"name": props.name, "uuid": str(getattr(props, "uuid", "")), "cus": int(getattr(props, "multi_processor_count", 0))}
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, ctypes.c_int(local_rank)) == 0:
+            ident["pci_bus_id"] = buf.value.decode()
+    except OSError:
+        pass
+    if "pci_bus_id" not in ident:
+        ident["pci_bus_id"] = "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0))
+    return ident
+
+
+def size_of(args_size):
+    return SIZES[args_size] if args_size in SIZES else tuple(int(v) for v in args_size.lower().split("x"))
+
+
+def time_search_config(torch, api, synth, eng, dev, w, h, bd, sr, steps, seed, label):
+    """one other BASELINE configuration on this GPU, timed with HIP events on the launch stream and checked against the oracle;
+    reported beside the headline, never part of `value`"""
+    cur, ref, _ = synth.make_pair(w, h, seed=seed, bit_depth=bd)
+    m = synth.MARGIN
+    pc, pr = eng.plane(w, h, bd), eng.plane(w, h, bd)
+    pc.upload_pel(cur, (m, m)); pr.upload_pel(ref, (m, m))
+    n_ctu = api.load().hmme_num_ctus(w, h)
+    fp = api.FrameParams(sr, 1, bd, 0, n_ctu)
+    buf = torch.zeros((2, 1, n_ctu, api.NUM_PARTS), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    for i in range(steps + 2):
+        if i == 2:
+            ev[0].record()
+        eng.search_pairs_device([pc], [pr], fp, None, buf[0].data_ptr(), buf[1].data_ptr(), stream)
+    ev[1].record()
+    torch.cuda.synchronize()
+    ms = ev[0].elapsed_time(ev[1]) / steps
+    sads = work_4x4_sads(api, w, h, sr)
+    algo = algo_bytes_per_ctu(sr, bd) * n_ctu
+    out = {"workload": label, "steps": steps, "ms_per_step": round(ms, 4), "gsad_per_s": round(sads / (ms * 1e-3) / 1e9, 1),
+           "ctus_per_s": round(n_ctu / (ms * 1e-3), 1), "dtype": "u8" if bd == 8 else "u16",
+           "roofline": {"bound": "hbm", "achieved": round(algo / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": algo},
+           "verified": verify_against_oracle(buf.cpu().numpy(), cur, ref, w, h, sr, eng.lambda_q16, bd, what=f"tables of {label}")}
+    pc.close(); pr.close()
+    return out
+
+
+def time_sequence_config(torch, api, synth, eng, dev):
+    """BASELINE config 4 on THIS one GPU: 3840x2160, 64 pictures, the (current, reference) pairs of encoder_randomaccess_main.cfg
+    (124 pairs), pictures streamed through a ring of plane slots while the GPU searches (hmme/sequence.py); wall clock around the
+    whole pass, uploads included.  One CTU row of the first and the last pair is checked against the oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    from hmme import sequence, shard
+    w, h, n_frames, sr = 3840, 2160, 64, 64
+    src = synth.Sequence(w, h, n_frames, seed=777, bit_depth=8)
+    pairs = shard.gop_pairs(n_frames, "randomaccess")
+    res = None
+    for _ in range(2):   # the first pass includes allocations
+        res = None
+        res = sequence.run_rank(eng, src, pairs, w, h, 8, sr, stream_mode=True, pairs_per_launch=1, device=dev)
+    dt = res["seconds"]
+    n_ctu = api.load().hmme_num_ctus(w, h)
+    ctus_x = (w + 63) // 64
+    t0 = time.time()
+    checked = []
+    for pi in (0, len(pairs) - 1):
+        c, r = pairs[pi]
+        first = ctus_x * 17
+        ox, oy, osad = O.search_frame(src.padded(c), src.padded(r), (synth.MARGIN, synth.MARGIN), w, h, sr, None, eng.lambda_q16, 1, 8,
+                                      first, 8, min(8, usable_cores()))
+        mv = res["mv"][pi, first:first + 8].cpu().numpy()
+        sad = res["sad"][pi, first:first + 8].cpu().numpy().view(np.uint32)
+        if not (np.array_equal(mv[:, :, 0], ox) and np.array_equal(mv[:, :, 1], oy) and np.array_equal(sad, osad)):
+            raise SystemExit(f"bench.py: config 4 tables of pair {pairs[pi]} differ from the CPU oracle: nothing reported")
+        checked.append(list(pairs[pi]))
+    sads = work_4x4_sads(api, w, h, sr)
+    return {"workload": "3840x2160 8-bit, 64 pictures, encoder_randomaccess_main GOP: 124 (current, reference) pairs, SearchRange=64, "
+                        "streamed through ONE GPU (reader thread -> copy stream || compute stream)",
+            "pairs": len(pairs), "seconds": round(dt, 4), "pairs_per_s": round(len(pairs) / dt, 1),
+            "gsad_per_s": round(len(pairs) * sads / dt / 1e9, 1), "ctus_per_s": round(len(pairs) * n_ctu / dt, 1),
+            "plane_slots": res["plane_slots"], "uploads": res["uploads"], "stages": res["stages"],
+            "verified": {"pairs": checked, "ctus": [ctus_x * 17, 8], "slots": 2 * 8 * 593, "against": "oracle exhaustive search (bit-exact)",
+                         "seconds": round(time.time() - t0, 2)}}
+
+
+def time_refine_contents(torch, api, synth, eng, dev, w, h, bd, sr):
+    """the refinement kernel's time depends on how much the 593 slots of a CTU share: one motion per 128x128 region (the bench
+    content: the BEST case), 24-sample regions of their own motion under stronger noise, and unrelated pictures where nearly every
+    slot has its own integer MV (the worst case).  Each is checked against the oracle on a sample of slots."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    m = synth.MARGIN
+    n_ctu = api.load().hmme_num_ctus(w, h)
+    fp = api.FrameParams(sr, 1, bd, 0, n_ctu)
+    stream = torch.cuda.current_stream().cuda_stream
+    d_mv = torch.zeros((n_ctu, api.NUM_PARTS, 2), dtype=torch.int16, device=dev)
+    d_sad = torch.zeros((n_ctu, api.NUM_PARTS), dtype=torch.int32, device=dev)
+    d_q, d_c = torch.zeros_like(d_mv), torch.zeros_like(d_sad)
+    table = O.slot_table()
+    ctus_x = (w + 63) // 64
+    out = {}
+    for content in ("coherent", "mixed", "noise"):
+        if content == "coherent":
+            cur, ref, _ = synth.make_pair(w, h, seed=1234, bit_depth=bd)
+        elif content == "mixed":
+            cur, ref, _ = synth.make_pair(w, h, seed=1234, bit_depth=bd, max_mv=10, region=24, noise_sigma=6.0)
+        else:
+            rng = np.random.default_rng(5)
+            cur = synth.pad_plane(rng.integers(0, 1 << bd, size=(h, w)))
+            ref = synth.pad_plane(rng.integers(0, 1 << bd, size=(h, w)))
+        pc, pr = eng.plane(w, h, bd), eng.plane(w, h, bd)
+        pc.upload_pel(cur, (m, m)); pr.upload_pel(ref, (m, m))
+        eng.search_frame_device(pc, pr, fp, None, d_mv.data_ptr(), d_sad.data_ptr(), stream)
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        for i in range(5):
+            if i == 2:
+                ev[0].record()
+            eng.refine_frame_multi_device(pc, [pr], fp, None, d_mv.data_ptr(), 1, d_q.data_ptr(), d_c.data_ptr(), stream)
+        ev[1].record()
+        torch.cuda.synchronize()
+        ms = ev[0].elapsed_time(ev[1]) / 3
+        mv, qmv, cost = d_mv.cpu().numpy(), d_q.cpu().numpy(), d_c.cpu().numpy().view(np.uint32)
+        rs = np.random.default_rng(11)
+        n_checked = 0
+        for ctu in (0, ctus_x * 16 + 29, n_ctu - 1):
+            cx, cy = (ctu % ctus_x) * 64, (ctu // ctus_x) * 64
+            for s in list(rs.choice(593, size=20, replace=False)) + [592, 588, 0]:
+                x, y, bw, bh = (int(v) for v in table[s])
+                if cx + x + bw > w or cy + y + bh > h:
+                    continue   # slots beyond the picture edge: defined on the padding, not looked up by HM
+                imv = (int(mv[ctu, s, 0]), int(mv[ctu, s, 1]))
+                hx, hy, qx, qy, c = O.frac_refine(cur, (m + cx + x, m + cy + y), ref, (m + cx + x, m + cy + y), bw, bh, imv, (0, 0), eng.lambda_q16, 1, bd)
+                if (int(qmv[ctu, s, 0]), int(qmv[ctu, s, 1]), int(cost[ctu, s])) != (4 * imv[0] + 2 * hx + qx, 4 * imv[1] + 2 * hy + qy, c):
+                    raise SystemExit(f"bench.py: refinement of CTU {ctu} slot {s} ({content} content) differs from the CPU oracle: nothing reported")
+                n_checked += 1
+        out[content] = {"ms_per_step": round(ms, 4), "slots_per_s": round(n_ctu * api.NUM_PARTS / (ms * 1e-3)), "slots_verified": n_checked}
+        pc.close(); pr.close()
+    return out
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))          # before torch is imported: this process never touches the GPU
+
+    import zlib
     import torch
     import torch.distributed as dist
     from hmme import api, shard, synth
@@ -205,14 +412,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
-        args.gpus = world
+    args.gpus = world                        # under a launcher the world it made is what runs
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
     if args.share_gpu:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} (local rank {local_rank}) has no GPU of its own: {torch.cuda.device_count()} visible "
+                         f"(--share-gpu --backend gloo rehearses the N > 1 path on one GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # HMME_BENCH_FORCE_DIST=1: run the collective path with world size 1 too (rehearses the RCCL calls on a 1-GPU box)
@@ -224,15 +431,7 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    if args.size in SIZES:
-        w, h = SIZES[args.size]
-    else:
-        try:
-            w, h = (int(v) for v in args.size.lower().split("x"))
-        except ValueError:
-            ap.error("--size: %s, or WIDTHxHEIGHT" % ", ".join(sorted(SIZES)))
-        if w < 64 or h < 64 or w % 8 or h % 8:
-            ap.error("--size: width and height must be multiples of 8, at least 64")
+    w, h = size_of(args.size)
     sr = args.search_range
     bd = args.bit_depth
     eng = api.Engine(local_rank, 128)
@@ -244,8 +443,6 @@ def main():
     pc.upload_pel(cur, (synth.MARGIN, synth.MARGIN))
     pr.upload_pel(ref, (synth.MARGIN, synth.MARGIN))
     n_pairs = max(1, args.pairs)
-    if n_pairs > 1 and args.refs > 1:
-        raise SystemExit("bench.py: --pairs and --refs exclude each other")
     n_refs = max(1, args.refs) if n_pairs == 1 else n_pairs      # searches per CTU position and launch
     ref_planes = [pr] + [eng.plane(w, h, bd) for _ in range(n_refs - 1)]
     cur_planes = [pc] * n_refs
@@ -258,7 +455,7 @@ def main():
     n_ctu = api.load().hmme_num_ctus(w, h)
     fp = api.FrameParams(sr, 1, bd, 0, n_ctu)
     # one picture pair per rank and step.  Results of step k land in buffer k % 2 ([2, n_refs, n_ctu, 593] int32: TComMv
-    # words and SADs) and are all-gathered asynchronously on RCCL's stream while step k+1 searches into the other
+    # words and SADs) and travel to rank 0 asynchronously on RCCL's stream while step k+1 searches into the other
     # buffer (hmme/shard.py PipelinedGather; the same class runs under gloo in tests/test_shard_gloo.py)
     stream = torch.cuda.current_stream().cuda_stream
     pipe = shard.PipelinedGather(lambda: torch.zeros((2, n_refs, n_ctu, api.NUM_PARTS), dtype=torch.int32, device=dev),
@@ -287,11 +484,13 @@ def main():
         dist.barrier()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     torch.cuda.synchronize()
+    received0 = pipe.bytes_received
     t0 = time.perf_counter()
     for k in range(args.steps):
         pipe.step(launch)
     pipe.drain()
     torch.cuda.synchronize()
+    local_elapsed = time.perf_counter() - t0          # this rank's own K steps (before the closing barrier)
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -300,6 +499,53 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))   # HIP events on the launch stream
+
+    # ---- evidence of the N-rank run (every rank contributes; rank 0 reports) ----------------------------------------------------
+    multi = None
+    if use_dist:
+        last = pipe.last_local
+        mine = {"rank": rank, "local_rank": local_rank, "device": device_identity(torch, local_rank), "kernel_ms": round(kernel_ms, 4),
+                "step_ms": round(local_elapsed / args.steps * 1e3, 4), "pid": os.getpid(),
+                "crc32_local_tables": zlib.crc32(last.cpu().numpy().tobytes())}    # this rank's tables of the last step, BEFORE any transfer
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        # the exchange step alone: three blocking gathers of one step's tables
+        gt = []
+        out_flat = (pipe.last_gathered.view((world * last.shape[0],) + tuple(last.shape[1:])) if rank == 0 and pipe.last_gathered is not None else None)
+        keep = pipe.last_gathered.clone() if rank == 0 and pipe.last_gathered is not None else None
+        got = 0
+        for _ in range(3):
+            torch.cuda.synchronize()
+            dist.barrier()
+            tg = time.perf_counter()
+            _, _, got = shard.gather_to_root(last, None, 0, out_flat)
+            torch.cuda.synchronize()
+            gt.append((time.perf_counter() - tg) * 1e3)
+        if rank == 0:
+            distinct = sorted({e["device"]["pci_bus_id"] + "/" + e["device"]["uuid"] for e in everyone})
+            if not args.share_gpu and len(distinct) != world:
+                raise SystemExit(f"bench.py: {world} ranks ran on {len(distinct)} distinct devices ({distinct}): nothing reported")
+            crc_ok = []
+            for r in range(world):      # what rank 0 RECEIVED during the timed steps == what rank r computed
+                blk = keep[r] if keep is not None else last
+                crc_ok.append(zlib.crc32(blk.cpu().numpy().tobytes()) == everyone[r]["crc32_local_tables"])
+            if not all(crc_ok):
+                raise SystemExit(f"bench.py: gathered tables differ from what the ranks computed (per-rank CRC match: {crc_ok}): nothing reported")
+            multi = {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(), "self_launched": os.environ.get("HMME_BENCH_SELF_LAUNCHED") == "1",
+                     "devices": [dict(e["device"], rank=e["rank"], local_rank=e["local_rank"], pid=e["pid"]) for e in everyone],
+                     "distinct_devices": len(distinct), "shared_gpu_rehearsal": bool(args.share_gpu),
+                     "per_rank_kernel_ms": [e["kernel_ms"] for e in everyone], "per_rank_step_ms": [e["step_ms"] for e in everyone],
+                     "kernel_ms_min_max": [min(e["kernel_ms"] for e in everyone), max(e["kernel_ms"] for e in everyone)],
+                     "step_ms_min_max": [min(e["step_ms"] for e in everyone), max(e["step_ms"] for e in everyone)],
+                     "pairs_per_rank_per_step": [n_pairs] * world,
+                     "gather": {"what": "every rank's tables of a step to rank 0 only (grouped point-to-point send / receive)",
+                                "ms_blocking": round(float(np.median(gt)), 4), "bytes_received_by_rank0_per_step": int(got),
+                                "bytes_received_in_timed_steps": int(pipe.bytes_received - received0), "overlapped_with_next_search": args.backend == "nccl"},
+                     "crc32_tables_match_per_rank": crc_ok}
+            if world > 1 and not args.no_cpu_baseline:   # one non-zero rank's tables against the oracle (its frame pair is regenerated here)
+                r = world - 1
+                c_r, r_r, _ = synth.make_pair(w, h, seed=1234 + r, bit_depth=bd)
+                multi["verified_rank"] = dict(verify_against_oracle(keep[r].cpu().numpy(), c_r, r_r, w, h, sr, lq, bd, what=f"tables gathered from rank {r}"), rank=r)
 
     if rank == 0:
         sads = work_4x4_sads(api, w, h, sr) * n_refs
@@ -319,17 +565,23 @@ def main():
             "config": {"workload": f"{w}x{h} {bd}-bit luma, lowdelay_P_main{'' if bd == 8 else '10'} (FEN=1), SearchRange={sr}, CTU=64, exhaustive "
                                    f"integer search of all 593 PU shapes, " + (f"{n_pairs} picture pairs" if n_pairs > 1 else f"{n_refs} reference picture{'s' if n_refs > 1 else ''}") + f" per launch, {n_ctu} CTUs per frame",
                        "frames_per_step": world * n_pairs, "parallelism": f"frame-shard x{world}", "lambda": LAMBDA,
-                       "collective": f"all_gather_into_tensor ({args.backend}), world {world}" if use_dist else "none (one rank)",
+                       "collective": f"gather to rank 0: grouped send/recv ({args.backend}), world {world}" if use_dist else "none (one rank)",
                        "sads_4x4_per_frame": sads},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": int(traffic) if traffic is not None else None,
                          "traffic_same_run": False if traffic is not None else None,   # counters: separate rocprofv3 --pmc passes of this command
+                         "achieved_is": "ALGORITHMIC bytes per launch (SURVEY 8d: CTU + window + results per CTU-search) / kernel time; "
+                                        "`traffic` is the MEASURED HBM bytes per launch (neighbouring windows hit the XCD's L2), "
+                                        "`traffic_gbs` = traffic / kernel time",
+                         "traffic_gbs": round(traffic / (kernel_ms * 1e-3) / 1e9, 2) if traffic is not None else None,
                          "kernel": "me_search_kernel<1, 0>" if bd == 8 else "me_search16_kernel<1,*> (+ merge-table preset and finalize)",
                          "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "kernel is VALU-bound (1664 abs-diff ops per unique input byte at SR 64, SURVEY 8d); "
                                  "see valu_roofline and DESIGN.md 5 for the instruction-issue roofline"},
         }
+        if multi is not None:
+            out["multi_gpu"] = multi
         if prof.get("stale"):
             out["roofline"]["traffic_note"] = "profiles/latest_pmc_* was taken on a library with another build id than the one loaded: counters withheld"
         if kprof.get("valu_busy_frac") is not None:   # what actually binds: integer VALU issue
@@ -367,12 +619,15 @@ def main():
         r_ms = ev[0].elapsed_time(ev[1]) / 3
         out["refine"] = {"what": "xPatternSearchFracDIF (half + quarter-pel, Hadamard) for all 593 slots of every CTU, on the integer winners",
                          "kernel": "me_frac_kernel<1, %d>" % (1 if bd == 8 else 2), "ms_per_step": round(r_ms, 4),
-                         "slots_per_s": round(n_ctu * n_refs * api.NUM_PARTS / (r_ms * 1e-3))}
+                         "slots_per_s": round(n_ctu * n_refs * api.NUM_PARTS / (r_ms * 1e-3)),
+                         "content": "the bench pictures: one motion per 128x128 region, i.e. the refinement kernel's BEST case "
+                                    "(slots of a CTU share their patches); see by_content for the others"}
+        extras = n_refs == 1 and n_pairs == 1 and world == 1 and not args.no_cpu_baseline
         # beside the headline, never `value`: the same picture against the FOUR reference pictures a lowdelay_P_main picture searches
         # (cfg/encoder_lowdelay_P_main.cfg:24-27) in one launch -- what the encoder configuration the metric is quoted on asks of a step
         # (not under --no-cpu-baseline: tools/profile_bench.sh profiles that command, and launches of another size would enter the
         # per-kernel averages of its rocprofv3 summaries)
-        if n_refs == 1 and n_pairs == 1 and world == 1 and not args.no_cpu_baseline:
+        if extras:
             refs4 = [pr] + [eng.plane(w, h, bd) for _ in range(3)]
             for i, pl in enumerate(refs4[1:]):
                 _, r2, _ = synth.make_pair(w, h, seed=7000 + 13 * i, bit_depth=bd)
@@ -400,6 +655,20 @@ def main():
             # (corner, interior, partial bottom row); a mismatch fails the run
             res = last.cpu().numpy()
             out["verified"] = verify_against_oracle(res, cur, ref, w, h, sr, lq, bd)
+        if extras and not args.no_extras and (w, h, bd, sr) == (3840, 2160, 8, 64):
+            # the other single-GPU BASELINE configurations and the refinement kernel's content dependence, each timed with HIP events
+            # and checked against the oracle in this same process (BASELINE.json configs 2, 5 and 4-on-one-GPU)
+            t_x = time.time()
+            out["refine"]["by_content"] = time_refine_contents(torch, api, synth, eng, dev, w, h, bd, sr)
+            out["configs"] = {
+                "config2_1080p_sr64": time_search_config(torch, api, synth, eng, dev, 1920, 1080, 8, 64, 20, 1234,
+                                                         "1920x1080 8-bit, SearchRange=64 (BASELINE config 2), one reference per launch"),
+                "config5_2160p_10bit_sr128": time_search_config(torch, api, synth, eng, dev, 3840, 2160, 10, 128, 5, 1234,
+                                                                "3840x2160 10-bit, SearchRange=128, packed-u16 SAD path (BASELINE config 5)"),
+                "config4_2160p_randomaccess_64_pictures_one_gpu": time_sequence_config(torch, api, synth, eng, dev),
+            }
+            out["configs"]["seconds"] = round(time.time() - t_x, 1)
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cur, ref, w, h, sr, lq, bd)
         print(json.dumps(out), flush=True)
     for pl in set(cur_planes) | set(ref_planes):

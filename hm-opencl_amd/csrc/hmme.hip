@@ -113,6 +113,8 @@ struct hmme_ctx {
   int out_cap = 0;
   int* d_flag = nullptr;
   bool lds_optin[8] = {false, false, false, false, false, false, false, false};
+  int num_cus = 0;
+  int frac_wg_per_cu[2][2] = {{0, 0}, {0, 0}};   // [wide][hadamard] workgroups of me_frac_kernel a CU holds (runtime occupancy query, first use)
   uint16_t* d_frac_cover = nullptr;   // fractional refinement: slots covering each 8x8 / 4x4 position, same for every CTU
   int16_t* d_imv = nullptr;           // host-facing refine call: integer MVs / quarter-pel MVs / costs on the device
   int16_t* d_qmv = nullptr;
@@ -413,6 +415,7 @@ int hmme_create(int device, int sr_max, unsigned flags, hmme_ctx** out) {
            (double)prop.totalGlobalMem / (1 << 30));
   ctx->info = info;
   ctx->wg_slots = 2 * prop.multiProcessorCount;
+  ctx->num_cus = prop.multiProcessorCount;
   const size_t win_bytes = (size_t)kWinRows * kWinPitch + 64;
 #define CREATE_TRY(call)                                                                                           \
   do {                                                                                                             \
@@ -539,6 +542,29 @@ int hmme_slot_rect(int slot, int* x, int* y, int* w, int* h) {
 // ---- per-CTU drop-in ---------------------------------------------------------------------------------
 namespace {
 int build_frac_cover(hmme_ctx* ctx);
+using frac_fn = void (*)(const RefSet, int, const RefSet, int, const MeJob*, int, const uint16_t*, const int16_t*, uint32_t, int, int16_t*, uint32_t*);
+inline frac_fn frac_kernel(int wide, int had) {
+  static const frac_fn fns[2][2] = {{hmme::me_frac_kernel<0, 1>, hmme::me_frac_kernel<1, 1>}, {hmme::me_frac_kernel<0, 2>, hmme::me_frac_kernel<1, 2>}};
+  return fns[wide ? 1 : 0][had ? 1 : 0];
+}
+// workgroups of a refinement launch: as many as the chip holds at a time (the runtime's occupancy figure for this kernel with its
+// LDS block x the CUs), each walking every grid-th job; HMME_FRAC_GRID=<n> forces a grid (0 = one workgroup per job, as before round 4)
+int frac_grid(hmme_ctx* ctx, int wide, int had, int jobs) {
+  int& per_cu = ctx->frac_wg_per_cu[wide ? 1 : 0][had ? 1 : 0];
+  if (per_cu == 0) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)frac_kernel(wide, had), hmme::frac_threads(wide ? 2 : 1),
+                                                     hmme::frac_lds_bytes(wide ? 2 : 1)) != hipSuccess || n < 1) {
+      (void)hipGetLastError();
+      n = 2;
+    }
+    per_cu = n;
+    if (std::getenv("HMME_TRACE")) fprintf(stderr, "hmme: me_frac_kernel<%d, %d>: %d workgroups per CU, %d CUs\n", had ? 1 : 0, wide ? 2 : 1, n, ctx->num_cus);
+  }
+  static const int forced = std::getenv("HMME_FRAC_GRID") ? std::atoi(std::getenv("HMME_FRAC_GRID")) : -1;
+  int grid = forced == 0 ? jobs : (forced > 0 ? forced : per_cu * ctx->num_cus);
+  return grid < jobs ? (grid < 1 ? 1 : grid) : jobs;
+}
 
 // host-side packing of the call block, one picture row at a time; separate reduction and narrowing loops so that the compiler
 // vectorises both (the reference copies the same window sample by sample, TEncOpenCL.cpp:275-277)
@@ -694,11 +720,9 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
     // its input the integer tables the finalize kernel just wrote (or the caller's), its output in the same pinned block
     rc = build_frac_cover(ctx);
     if (rc) return rc;
-    using frac_fn = void (*)(const RefSet, int, const RefSet, int, const MeJob*, const uint16_t*, const int16_t*, uint32_t, int, int16_t*, uint32_t*);
-    static const frac_fn fns[2][2] = {{hmme::me_frac_kernel<0, 1>, hmme::me_frac_kernel<1, 1>}, {hmme::me_frac_kernel<0, 2>, hmme::me_frac_kernel<1, 2>}};
     const int16_t* d_imv = do_search ? d_mv1 : (const int16_t*)(ctx->d_call + kCallImv);
-    hipLaunchKernelGGL(fns[wide ? 1 : 0][refine_had ? 1 : 0], dim3(1), dim3(hmme::frac_threads(bps)), hmme::frac_lds_bytes(bps), s, one_ref(ctx->d_call + kCallCtu),
-                       64 * bps, one_ref(ref_base), kWinPitch, (const MeJob*)(ctx->d_call + kCallFracJob), ctx->d_frac_cover, d_imv, ctx->lambda_q16,
+    hipLaunchKernelGGL(frac_kernel(wide ? 1 : 0, refine_had ? 1 : 0), dim3(1), dim3(hmme::frac_threads(bps)), hmme::frac_lds_bytes(bps), s, one_ref(ctx->d_call + kCallCtu),
+                       64 * bps, one_ref(ref_base), kWinPitch, (const MeJob*)(ctx->d_call + kCallFracJob), 1, ctx->d_frac_cover, d_imv, ctx->lambda_q16,
                        p->bit_depth | (bipred_origin ? 0x100 : 0), (int16_t*)(ctx->d_res + kResQmv), (uint32_t*)(ctx->d_res + kResCost));
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(hmme::me_publish_kernel, dim3(1), dim3(1), 0, s, (volatile uint32_t*)(ctx->d_res + kResDone2), seq);
@@ -1126,10 +1150,8 @@ int hmme_refine_pairs_device(hmme_ctx* ctx, const hmme_plane* const* curs, const
     hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, dim3((jobs + 255) / 256), dim3(256), 0, s, (MeJob*)ctx->d_jobs, (const int16_t*)d_pred_q,
                        pl.first, pl.count, n_pairs, curs[0]->width, curs[0]->height, fp->search_range, 0, jobs, 0);
     const int had = use_hadamard ? 1 : 0, wide = curs[0]->bps == 2 ? 1 : 0;
-    using frac_fn = void (*)(const RefSet, int, const RefSet, int, const MeJob*, const uint16_t*, const int16_t*, uint32_t, int, int16_t*, uint32_t*);
-    static const frac_fn fns[2][2] = {{hmme::me_frac_kernel<0, 1>, hmme::me_frac_kernel<1, 1>}, {hmme::me_frac_kernel<0, 2>, hmme::me_frac_kernel<1, 2>}};
-    hipLaunchKernelGGL(fns[wide][had], dim3(jobs), dim3(hmme::frac_threads(wide ? 2 : 1)), hmme::frac_lds_bytes(wide ? 2 : 1), s, pl.curs,
-                       curs[0]->pitch, pl.refs, refs[0]->pitch, (const MeJob*)ctx->d_jobs, ctx->d_frac_cover, (const int16_t*)d_int_mv, ctx->lambda_q16,
+    hipLaunchKernelGGL(frac_kernel(wide, had), dim3(frac_grid(ctx, wide, had, jobs)), dim3(hmme::frac_threads(wide ? 2 : 1)), hmme::frac_lds_bytes(wide ? 2 : 1), s, pl.curs,
+                       curs[0]->pitch, pl.refs, refs[0]->pitch, (const MeJob*)ctx->d_jobs, jobs, ctx->d_frac_cover, (const int16_t*)d_int_mv, ctx->lambda_q16,
                        fp->bit_depth, (int16_t*)d_out_qmv, (uint32_t*)d_out_cost);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) rc = fail(ctx, HMME_ERR_DEVICE, "refinement launch -> %s", hipGetErrorString(e));

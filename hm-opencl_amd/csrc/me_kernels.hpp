@@ -876,7 +876,8 @@ __global__ void me_prep_jobs_tile_kernel(MeJob16* jobs, int* first_strip_of_job,
 constexpr int kFracAccRow = 9, kFracAcc = 593 * kFracAccRow, kFracAccDw = (kFracAcc + 15) & ~15;
 // BPS = bytes per sample of the planes (1: 8-bit video, 2: 9..12 bit)
 constexpr int frac_threads(int bps) { return 256; }
-constexpr size_t frac_lds_bytes(int bps) { return (size_t)(kFracAccDw + 600 + 160 + (64 * 18 + 256 * 6) / 2 + 1024 * bps + 600) * 4; }
+// sums [593][9] | slot states | tap tables, counters | the two work lists | current block | cover table (uint16 [64][18] + [256][6])
+constexpr size_t frac_lds_bytes(int bps) { return (size_t)(kFracAccDw + 600 + 160 + (64 * 18 + 256 * 6) / 2 + 1024 * bps + (64 * 18 + 256 * 6) / 2) * 4; }
 
 __device__ __forceinline__ uint32_t me_mv_cost_q(uint32_t lambda_q16, int vx_q, int vy_q, int pred_x, int pred_y) {
   return (lambda_q16 * (me_component_bits(vx_q - pred_x) + me_component_bits(vy_q - pred_y))) >> 16;
@@ -1196,34 +1197,56 @@ __device__ __forceinline__ void me_frac_eval0(const uint32_t (&P)[12][3 * BPS], 
 #undef ME_FRAC_POINT
 }
 
+// One work item = one 4x4 block of one (position, MV) pair; `pair` indexes the cover table (kind-8 pairs first), `role` is the lane's
+// quadrant of an 8x8 Hadamard block.  An item is handled in three steps so that the patch of a lane's NEXT item can be in flight while
+// the current one is evaluated (round 4; until then a lane loaded its 12 patch rows, waited for them, and computed, with nothing
+// outstanding -- the kernel was VALU-busy half of its time on coherent content, profiles/latest_pmc_2160p_sr64.json of round 3):
+//   me_frac_fetch    slot state + address -> 12 raw rows of PW + 1 aligned dwords each (global_load_dwordx4 / x3), nothing waited for
+//   me_frac_compute  byte-align the rows (first use = the wait), evaluate the 9 / 8 points, add to the slots that share the key
+template <int BPS>
+struct FracRaw {
+  uint32_t w[12][3 * BPS + 1];
+  uint32_t sv;      // state word of the item's first slot (the sharing key of the stage)
+  uint32_t o;       // byte offset of the patch inside its first dword
+};
+
+template <int BPS, int KIND8>
+__device__ __forceinline__ void me_frac_fetch(const uint8_t* __restrict__ src, int gpitch, const uint32_t* st, const uint16_t* cover, int pair, int role,
+                                              FracRaw<BPS>& R) {
+  constexpr int PW = 3 * BPS, NCOV = KIND8 ? kFracCover8 : kFracCover4;
+  const int q = KIND8 ? pair : pair - kFracPairs8;
+  const int pos = q / NCOV;
+  const uint32_t sv = st[cover[pair]];
+  const int bx = KIND8 ? 2 * (pos & 7) + (role & 1) : (pos & 15), by = KIND8 ? 2 * (pos >> 3) + (role >> 1) : (pos >> 4);
+  // patch (0,0) = block sample (-4,-4) = window row (by*4 + my - lt_y), sample (bx*4 + mx - lt_x) (halo offsets cancel)
+  const int prow = by * 4 + (int)((sv >> 9) & 0x1ff), pcol = (bx * 4 + (int)(sv & 0x1ff)) * BPS;   // pcol in bytes
+  const uint8_t* a = src + (long)prow * gpitch + pcol;
+  const uint32_t o = (uint32_t)(uintptr_t)a & 3u;
+  const uint32_t* __restrict__ rowp = (const uint32_t*)(a - o);
+  const int gp = gpitch >> 2;
+#pragma unroll
+  for (int r = 0; r < 12; ++r)
+#pragma unroll
+    for (int k = 0; k <= PW; ++k) R.w[r][k] = rowp[r * gp + k];
+  R.sv = sv;
+  R.o = o;
+}
+
 template <int STAGE, int HAD, int BPS, int KIND8>
-__device__ __forceinline__ void me_frac_item(const uint8_t* __restrict__ src, int gpitch, const uint32_t* curl, const uint32_t* st,
-                                             const uint16_t* __restrict__ cover, int pair, int role, int bd, float clip_lo, const uint32_t* tab_h,
-                                             const float* tab_v, uint32_t* acc) {
+__device__ __forceinline__ void me_frac_compute(const FracRaw<BPS>& R, const uint32_t* curl, const uint32_t* st, const uint16_t* cover, int pair, int role,
+                                                int bd, float clip_lo, const uint32_t* tab_h, const float* tab_v, uint32_t* acc) {
   constexpr int PW = 3 * BPS, NCOV = KIND8 ? kFracCover8 : kFracCover4;
   constexpr uint32_t keymask = STAGE ? kFracKey1 : kFracKey0;
   const int q = KIND8 ? pair : pair - kFracPairs8;
   const int pos = q / NCOV, j = q - pos * NCOV;
   const uint16_t* cov = cover + (KIND8 ? 0 : kFracPairs8) + pos * NCOV;
-  const uint32_t sv = st[cov[j]];
+  const uint32_t sv = R.sv;
   const int bx = KIND8 ? 2 * (pos & 7) + (role & 1) : (pos & 15), by = KIND8 ? 2 * (pos >> 3) + (role >> 1) : (pos >> 4);
-  // patch (0,0) = block sample (-4,-4) = window row (by*4 + my - lt_y), sample (bx*4 + mx - lt_x) (halo offsets cancel)
-  const int prow = by * 4 + (int)((sv >> 9) & 0x1ff), pcol = (bx * 4 + (int)(sv & 0x1ff)) * BPS;   // pcol in bytes
   uint32_t P[12][PW];
-  {
-    const uint8_t* a = src + (long)prow * gpitch + pcol;
-    const uint32_t o = (uint32_t)(uintptr_t)a & 3u;
-    const uint32_t* __restrict__ rowp = (const uint32_t*)(a - o);
-    const int gp = gpitch >> 2;
 #pragma unroll
-    for (int r = 0; r < 12; ++r) {
-      uint32_t w[PW + 1];
+  for (int r = 0; r < 12; ++r)
 #pragma unroll
-      for (int k = 0; k <= PW; ++k) w[k] = rowp[r * gp + k];
-#pragma unroll
-      for (int k = 0; k < PW; ++k) P[r][k] = __builtin_amdgcn_alignbyte(w[k + 1], w[k], o) ^ (BPS == 1 ? 0x80808080u : 0u);
-    }
-  }
+    for (int k = 0; k < PW; ++k) P[r][k] = __builtin_amdgcn_alignbyte(R.w[r][k + 1], R.w[r][k], R.o) ^ (BPS == 1 ? 0x80808080u : 0u);
   float orgM[16];   // current samples + kRoundMagic (exact: integers below 2^24)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -1247,8 +1270,7 @@ __device__ __forceinline__ void me_frac_item(const uint8_t* __restrict__ src, in
   // Every slot of this position with the same key takes the distortions; the quad's lanes split the slot list.
   // (Round 3 tried to relieve these adds -- the large slots cover many positions, so lanes of one wave often add to the same address:
   // each quad starting its walk at another list position and two points per ds_add_u64 cut the kernel's LDS conflict cycles by 27 %
-  // and its LDS waits by 90 %, and changed its time by -2 % .. +3 %: LDS is busy 10 % of the CU cycles here, the kernel waits on its
-  // VALU chains and loads, not on these atomics.  profiles/r03d_frac_ab.txt)
+  // and its LDS waits by 90 %, and changed its time by -2 % .. +3 %: LDS is busy 10 % of the CU cycles here.  profiles/r03d_frac_ab.txt)
   for (int j2 = j + (KIND8 ? role : 0); j2 < NCOV; j2 += KIND8 ? 4 : 1) {
     const int s2 = cov[j2];
     if (j2 == j || ((st[s2] ^ sv) & keymask) == 0) {
@@ -1258,16 +1280,68 @@ __device__ __forceinline__ void me_frac_item(const uint8_t* __restrict__ src, in
   }
 }
 
-// distinct (position, key) pairs of one stage -> work lists.  Thread t < 64 owns 8x8 position t, the next 256 own the 4x4
-// positions; the first slot (lowest index in the cover list) with a given key is the one evaluated.
-template <int NCOV>
-__device__ __forceinline__ void me_frac_dedupe(const uint32_t* st, const uint16_t* __restrict__ cov, uint32_t keymask, int pair0,
+// software-pipelined walk over a lane's items of one stage: kind-8 items (whole quads), then kind-4 items; the patch rows of the next
+// item -- of either kind -- are requested before the current item is evaluated.  ME_FRAC_PIPE 0 = request, wait, evaluate (round 3).
+#ifndef ME_FRAC_PIPE
+#define ME_FRAC_PIPE 0
+#endif
+template <int STAGE, int HAD, int BPS>
+__device__ __forceinline__ void me_frac_stage_items(const uint8_t* __restrict__ src, int gpitch, const uint32_t* curl, const uint32_t* st, const uint16_t* cover,
+                                                    const uint16_t* list8, int n8, const uint16_t* list4, int n4, int tid, int bd, float clip_lo,
+                                                    const uint32_t* tab_h, const float* tab_v, uint32_t* acc) {
+  constexpr int NT = frac_threads(BPS);
+  const int role = tid & 3;
+  FracRaw<BPS> R;
+  int i8 = tid, i4 = tid;
+  int pair = 0;
+#if ME_FRAC_PIPE
+  if (i8 < n8) { pair = list8[i8 >> 2]; me_frac_fetch<BPS, 1>(src, gpitch, st, cover, pair, role, R); }
+  else if (i4 < n4) { pair = list4[i4]; me_frac_fetch<BPS, 0>(src, gpitch, st, cover, pair, 0, R); }
+#pragma unroll 1
+  while (i8 < n8) {   // whole quads: n8 and NT are multiples of 4
+    const FracRaw<BPS> C = R;
+    const int cpair = pair;
+    i8 += NT;
+    if (i8 < n8) { pair = list8[i8 >> 2]; me_frac_fetch<BPS, 1>(src, gpitch, st, cover, pair, role, R); }
+    else if (i4 < n4) { pair = list4[i4]; me_frac_fetch<BPS, 0>(src, gpitch, st, cover, pair, 0, R); }
+    me_frac_compute<STAGE, HAD, BPS, 1>(C, curl, st, cover, cpair, role, bd, clip_lo, tab_h, tab_v, acc);
+  }
+#pragma unroll 1
+  while (i4 < n4) {
+    const FracRaw<BPS> C = R;
+    const int cpair = pair;
+    i4 += NT;
+    if (i4 < n4) { pair = list4[i4]; me_frac_fetch<BPS, 0>(src, gpitch, st, cover, pair, 0, R); }
+    me_frac_compute<STAGE, HAD, BPS, 0>(C, curl, st, cover, cpair, 0, bd, clip_lo, tab_h, tab_v, acc);
+  }
+#else
+#pragma unroll 1
+  for (; i8 < n8; i8 += NT) {
+    pair = list8[i8 >> 2];
+    me_frac_fetch<BPS, 1>(src, gpitch, st, cover, pair, role, R);
+    me_frac_compute<STAGE, HAD, BPS, 1>(R, curl, st, cover, pair, role, bd, clip_lo, tab_h, tab_v, acc);
+  }
+#pragma unroll 1
+  for (; i4 < n4; i4 += NT) {
+    pair = list4[i4];
+    me_frac_fetch<BPS, 0>(src, gpitch, st, cover, pair, 0, R);
+    me_frac_compute<STAGE, HAD, BPS, 0>(R, curl, st, cover, pair, 0, bd, clip_lo, tab_h, tab_v, acc);
+  }
+#endif
+}
+
+// distinct (position, key) pairs of one stage -> work lists; the first slot (lowest index in the cover list) with a given key is the one
+// evaluated.  PARTS waves share a position's list: part PART decides entries PART, PART + PARTS, ... (an 8x8 position's 18 entries are
+// 153 compares: one wave per part -- the part is wave-uniform, so each wave runs only its own 32..45 compares -- keeps the four
+// waves of the workgroup equally busy; with one thread per position wave 0 did all 64 positions while the others waited at the barrier)
+template <int NCOV, int PARTS, int PART>
+__device__ __forceinline__ void me_frac_dedupe(const uint32_t* st, const uint16_t* cov, uint32_t keymask, int pair0,
                                                uint32_t* counter, uint16_t* list) {
   uint32_t key[NCOV];
 #pragma unroll
   for (int j = 0; j < NCOV; ++j) key[j] = st[cov[j]] & keymask;
 #pragma unroll
-  for (int j = 0; j < NCOV; ++j) {
+  for (int j = PART; j < NCOV; j += PARTS) {
     bool first = true;
 #pragma unroll
     for (int k = 0; k < j; ++k) first = first && key[k] != key[j];
@@ -1278,7 +1352,7 @@ __device__ __forceinline__ void me_frac_dedupe(const uint32_t* st, const uint16_
 template <int HAD, int BPS>
 __global__ void __launch_bounds__(frac_threads(BPS), BPS == 1 ? ME_FRAC_WAVES8 : 2)
 me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitch,
-               const MeJob* __restrict__ jobs, const uint16_t* __restrict__ cover, const int16_t* __restrict__ int_mv,
+               const MeJob* __restrict__ jobs, int n_jobs, const uint16_t* __restrict__ cover_g, const int16_t* __restrict__ int_mv,
                uint32_t lambda_q16, int bit_depth_bias, int16_t* __restrict__ out_qmv, uint32_t* __restrict__ out_cost) {
   // bit_depth_bias: bit depth in the low 8 bits; bit 8 set = block and window carry the bias 2^bitDepth of a bi-prediction origin
   // (2*org - pred, TEncSearch.cpp:3702-3712: current samples in [-maxv, 2*maxv]; per-CTU calls only, u16 staging)
@@ -1294,27 +1368,34 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
   uint16_t* list8 = (uint16_t*)(tab_h + 160);                  // distinct (8x8 position, key) pairs
   uint16_t* list4 = (uint16_t*)(tab_h + 160 + kFracPairs8 / 2);   // distinct (4x4 position, key) pairs
   uint32_t* curl = tab_h + 160 + (kFracPairs8 + kFracPairs4) / 2;   // 64 x 64 current block
-  uint32_t* carry = curl + 1024 * BPS;  // [593] stage 0: each slot's distortion sum at its winning half-pel point
+  uint16_t* cover = (uint16_t*)(curl + 1024 * BPS);   // the cover table (uint16 [64][18] then [256][6]): read per item and per dedupe, so it lives here
 
   const int tid = threadIdx.x;
-  MeJob job = jobs[blockIdx.x];
+  const int bd = BPS == 1 ? 8 : bit_depth;
+  // tables that do not depend on the job
+  if (tid < 7 * kFracTabH) tab_h[tid] = (tid & 7) < 3 * BPS ? me_htap_dw<BPS>((tid >> 3) - 3, 0, tid & 7) : 0u;
+  if (tid >= 64 && tid < 64 + 7 * kFracTabV) {
+    const int i = tid - 64, row = i / kFracTabV, j = i - row * kFracTabV;
+    tab_v[i] = j < 9 ? (float)me_tap9(row - 3, j) * (BPS == 1 ? 1.f / 4096.f : __int_as_float((127 - (20 - bd)) << 23)) : 0.f;
+  }
+  for (int i = tid; i < (kFracPairs8 + kFracPairs4) / 8; i += NT) ((uint4*)cover)[i] = ((const uint4*)cover_g)[i];
+
+  // A workgroup walks the jobs blockIdx.x, blockIdx.x + gridDim.x, ...: the host launches as many workgroups as the chip holds at a
+  // time (a job lives ~60 us; launched one workgroup per job, the slots stood empty between a workgroup's end and its successor's
+  // first instruction for a good part of that)
+#pragma unroll 1
+  for (int jb = blockIdx.x; jb < n_jobs; jb += gridDim.x) {
+  MeJob job = jobs[jb];
   const uint8_t* __restrict__ ref_base = refs.base[job.ctu_x & 63];
   const uint8_t* __restrict__ cur_base = curs.base[job.ctu_x & 63];
   job.ctu_x &= ~63;
-  const int wy = job.rb_y - job.lt_y + 1;
-  const int bd = BPS == 1 ? 8 : bit_depth;
-  const int16_t* mvs = int_mv + (long)blockIdx.x * kParts * 2;
+  const int16_t* mvs = int_mv + (long)jb * kParts * 2;
 
   for (int i = tid; i < kFracAcc; i += NT) acc[i] = 0;
   // integer MVs outside the CTU's window (not produced by the search) are clamped to it: the patch stays inside the LDS window
   for (int s = tid; s < kParts; s += NT) {
     const int mx = min(max((int)mvs[2 * s], job.lt_x), job.rb_x), my = min(max((int)mvs[2 * s + 1], job.lt_y), job.rb_y);
     st[s] = (uint32_t)(mx - job.lt_x) | (uint32_t)(my - job.lt_y) << 9 | 1u << 18 | 1u << 20;
-  }
-  if (tid < 7 * kFracTabH) tab_h[tid] = (tid & 7) < 3 * BPS ? me_htap_dw<BPS>((tid >> 3) - 3, 0, tid & 7) : 0u;
-  if (tid >= 64 && tid < 64 + 7 * kFracTabV) {
-    const int i = tid - 64, row = i / kFracTabV, j = i - row * kFracTabV;
-    tab_v[i] = j < 9 ? (float)me_tap9(row - 3, j) * (BPS == 1 ? 1.f / 4096.f : __int_as_float((127 - (20 - bd)) << 23)) : 0.f;
   }
   if (tid < 2) counter[tid] = 0;
   for (int i = tid; i < 256 * BPS; i += NT) {
@@ -1327,23 +1408,24 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
 #pragma unroll 1
   for (int stage = 0; stage < 2; ++stage) {
     const uint32_t keymask = stage ? kFracKey1 : kFracKey0;
-    for (int t = tid; t < 64 + 256; t += NT) {
-      if (t < 64) me_frac_dedupe<kFracCover8>(st, cover + t * kFracCover8, keymask, t * kFracCover8, &counter[0], list8);
-      else me_frac_dedupe<kFracCover4>(st, cover + kFracPairs8 + (t - 64) * kFracCover4, keymask, kFracPairs8 + (t - 64) * kFracCover4, &counter[1], list4);
+    {   // 64 8x8 positions x 4 waves (NT = 256: wave w decides entries w, w + 4, ... of each position's list), then 256 4x4 positions
+      static_assert(NT == 256, "me_frac_kernel: the work-list pass assumes 4 waves");
+      const int p8 = tid & 63;
+      const uint16_t* c8 = cover + p8 * kFracCover8;
+      switch (__builtin_amdgcn_readfirstlane(tid >> 6)) {
+        case 0: me_frac_dedupe<kFracCover8, 4, 0>(st, c8, keymask, p8 * kFracCover8, &counter[0], list8); break;
+        case 1: me_frac_dedupe<kFracCover8, 4, 1>(st, c8, keymask, p8 * kFracCover8, &counter[0], list8); break;
+        case 2: me_frac_dedupe<kFracCover8, 4, 2>(st, c8, keymask, p8 * kFracCover8, &counter[0], list8); break;
+        default: me_frac_dedupe<kFracCover8, 4, 3>(st, c8, keymask, p8 * kFracCover8, &counter[0], list8); break;
+      }
+      me_frac_dedupe<kFracCover4, 1, 0>(st, cover + kFracPairs8 + tid * kFracCover4, keymask, kFracPairs8 + tid * kFracCover4, &counter[1], list4);
     }
     __syncthreads();
     const int n8 = 4 * (int)counter[0], n4 = (int)counter[1];
-#pragma unroll 1
-    for (int i = tid; i < n8; i += NT) {   // whole quads: n8 and NT are multiples of 4
-      if (stage == 0) me_frac_item<0, HAD, BPS, 1>(src, ref_pitch, curl, st, cover, list8[i >> 2], tid & 3, bd, clip_lo, tab_h, tab_v, acc);
-      else me_frac_item<1, HAD, BPS, 1>(src, ref_pitch, curl, st, cover, list8[i >> 2], tid & 3, bd, clip_lo, tab_h, tab_v, acc);
-    }
-#pragma unroll 1
-    for (int i = tid; i < n4; i += NT) {
-      if (stage == 0) me_frac_item<0, HAD, BPS, 0>(src, ref_pitch, curl, st, cover, list4[i], 0, bd, clip_lo, tab_h, tab_v, acc);
-      else me_frac_item<1, HAD, BPS, 0>(src, ref_pitch, curl, st, cover, list4[i], 0, bd, clip_lo, tab_h, tab_v, acc);
-    }
+    if (stage == 0) me_frac_stage_items<0, HAD, BPS>(src, ref_pitch, curl, st, cover, list8, n8, list4, n4, tid, bd, clip_lo, tab_h, tab_v, acc);
+    else me_frac_stage_items<1, HAD, BPS>(src, ref_pitch, curl, st, cover, list8, n8, list4, n4, tid, bd, clip_lo, tab_h, tab_v, acc);
     __syncthreads();
+    if (tid < 2) counter[tid] = 0;
     for (int s = tid; s < kParts; s += NT) {
       const uint32_t sv = st[s];
       const int mx = (int)(sv & 0x1ff) + job.lt_x, my = (int)((sv >> 9) & 0x1ff) + job.lt_y;
@@ -1351,34 +1433,33 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
       const int bxq = 4 * mx + 2 * hx, byq = 4 * my + 2 * hy;   // centre of this stage in quarter units
       constexpr int ph[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};
       constexpr int pq[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {1, 1}};
-      uint32_t best = 0xffffffffu;
+      uint32_t best = 0xffffffffu, best_acc = 0;
       int bi = 0;
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
         const int ox = stage ? pq[i][0] : 2 * ph[i][0], oy = stage ? pq[i][1] : 2 * ph[i][1];
         // whole-PU distortion >> (bitDepth - 8) (TComRdCost.cpp:520-521, :1604), then the MV cost
-        const uint32_t d = (acc[s * kFracAccRow + i] >> (bd - 8)) + me_mv_cost_q(lambda_q16, bxq + ox, byq + oy, job.pred_x, job.pred_y);
-        if (d < best) { best = d; bi = i; }
+        const uint32_t a = acc[s * kFracAccRow + i];
+        const uint32_t d = (a >> (bd - 8)) + me_mv_cost_q(lambda_q16, bxq + ox, byq + oy, job.pred_x, job.pred_y);
+        if (d < best) { best = d; bi = i; best_acc = a; }
       }
       if (stage == 0) {
         st[s] = (sv & kFracKey0) | (uint32_t)(ph[bi][0] + 1) << 18 | (uint32_t)(ph[bi][1] + 1) << 20;
-        carry[s] = acc[s * kFracAccRow + bi];
+        // this thread owns row s of acc between the two barriers around this loop: it leaves the row as stage 1 needs it -- point 0 (the
+        // centre of the quarter-pel stage IS the half-pel winner: nothing adds to it in stage 1) carried over, the other eight cleared
+        acc[s * kFracAccRow] = best_acc;
+#pragma unroll
+        for (int i = 1; i < 9; ++i) acc[s * kFracAccRow + i] = 0;
       } else {
-        const long o = (long)blockIdx.x * kParts + s;
+        const long o = (long)jb * kParts + s;
         out_qmv[2 * o] = (int16_t)(bxq + pq[bi][0]);
         out_qmv[2 * o + 1] = (int16_t)(byq + pq[bi][1]);
         out_cost[o] = best;
       }
     }
-    if (stage == 0) {
-      if (tid < 2) counter[tid] = 0;
-      __syncthreads();   // every thread has read its acc entries
-      for (int i = tid; i < kFracAcc; i += NT) acc[i] = 0;
-      __syncthreads();
-      // centre of the quarter-pel stage (point 0): nothing adds to it in stage 1, its owner thread reads it back after the barrier
-      for (int s = tid; s < kParts; s += NT) acc[s * kFracAccRow] = carry[s];
-    }
+    __syncthreads();   // slot states, cleared sums and list counters are in place before the quarter-pel stage lists its work / the next job starts
   }
+  }   // jobs of this workgroup
 }
 
 }  // namespace hmme

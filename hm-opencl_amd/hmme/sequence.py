@@ -13,7 +13,8 @@ tools/me_sequence.py).  Two ways to feed the GPU:
 Batches: up to `pairs_per_launch` consecutive pairs of the rank's list go into ONE launch (hmme_search_pairs_device): a single
 1080p pair is 510 workgroups -- less than one round of the chip's 512 workgroup slots.
 
-The planning functions (plan_batches, plan_plane_loads) are pure Python and covered by the CPU tests.
+The planning functions (plan_batches, plan_plane_loads) are the C++ planner of hm-opencl_amd/host/SequenceME.cpp bound with
+ctypes -- one implementation for this driver and the C++ ones -- and covered by the CPU tests.
 """
 import queue
 import threading
@@ -24,49 +25,69 @@ import numpy as np
 NUM_PARTS = 593
 
 
+_HOST = None
+
+
+def _host_lib():
+    """libhmme_host.so (hm-opencl_amd/host): the C++ host module.  The launch / plane-slot planner lives THERE
+    (SequenceME.cpp plan_batches / plan_plane_loads, the C++ sequence drivers use it directly); this module binds it."""
+    global _HOST
+    if _HOST is None:
+        import ctypes as C
+        import os
+        import subprocess
+        here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        path = os.path.join(here, "host", "libhmme_host.so")
+        if not os.path.exists(path):
+            subprocess.run(["make", "-C", os.path.join(here, "host")], check=True, stdout=subprocess.DEVNULL)
+        L = C.CDLL(path)
+        L.hmme_host_plan.restype = C.c_int
+        L.hmme_host_plan.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.c_void_p,
+                                     C.c_char_p, C.c_int]
+        _HOST = L
+    return _HOST
+
+
+def _plan(pairs, pairs_per_launch, n_slots):
+    import ctypes as C
+    n = len(pairs)
+    pr = np.ascontiguousarray(np.array(pairs, np.int32).reshape(n, 2))
+    first = np.zeros(n + 1, np.int32)
+    loads = np.zeros((2 * n + 2, 3), np.int32)      # a launch uploads at most the 2k pictures it reads
+    where = np.zeros((n, 2), np.int32)
+    nb = C.c_int(0)
+    err = C.create_string_buffer(256)
+    k = _host_lib().hmme_host_plan(pr.ctypes.data, n, int(pairs_per_launch), int(n_slots), first.ctypes.data, C.byref(nb), loads.ctypes.data,
+                                   loads.shape[0], where.ctypes.data, err, 256)
+    if k < 0:
+        raise ValueError(err.value.decode())
+    return first[:nb.value + 1], loads[:k], where
+
+
 def plan_batches(pairs, pairs_per_launch):
     """consecutive pairs of the rank's list, at most `pairs_per_launch` (<= 16) per launch -> list of lists of indices"""
-    k = max(1, min(16, int(pairs_per_launch)))
-    return [list(range(i, min(i + k, len(pairs)))) for i in range(0, len(pairs), k)]
+    first, _, _ = _plan(pairs, pairs_per_launch, 1 << 20)
+    return [list(range(int(first[b]), int(first[b + 1]))) for b in range(len(first) - 1)]
 
 
 def plan_plane_loads(pairs, batches, n_slots):
-    """Which picture is uploaded into which plane slot before which batch.
+    """Which picture is uploaded into which plane slot before which batch (the C++ planner, SequenceME.cpp plan_plane_loads).
 
     pairs: [(cur_poc, ref_poc)] of the rank, batches: plan_batches(...).  Returns (loads, where): loads[b] = [(poc, slot)] to
     upload before batch b runs (in this order), where[b] = {poc: slot} for the pictures batch b reads.  Replacement: a slot
     whose picture is not needed by batch b is reused; among those prefer one that batch b - 1 does not read either (its refill
     then overlaps batch b - 1's search instead of waiting for it), then the one whose next use lies farthest ahead (Belady)."""
-    need = [sorted({p for i in b for p in pairs[i]}) for b in batches]
-    if any(len(n) > n_slots for n in need):
-        raise ValueError(f"a launch needs {max(len(n) for n in need)} pictures resident, only {n_slots} plane slots")
-    # next use of every picture after batch b
-    uses = {}
-    for b, n in enumerate(need):
-        for p in n:
-            uses.setdefault(p, []).append(b)
-    resident = {}           # poc -> slot
-    free = list(range(n_slots))
-    loads, where = [], []
-    for b, n in enumerate(need):
-        cur_loads = []
-        prev = set(need[b - 1]) if b else set()
-        for p in n:
-            if p in resident:
-                continue
-            if free:
-                slot = free.pop(0)
-            else:
-                def next_use(q):
-                    later = [u for u in uses[q] if u >= b]
-                    return later[0] if later else 1 << 30
-                cands = [q for q in resident if q not in n]
-                victim = max(cands, key=lambda q: (q not in prev, next_use(q)))
-                slot = resident.pop(victim)
-            resident[p] = slot
-            cur_loads.append((p, slot))
-        loads.append(cur_loads)
-        where.append({p: resident[p] for p in n})
+    k = max(len(b) for b in batches) if batches else 1
+    first, ld, wh = _plan(pairs, k, n_slots)
+    assert [list(range(int(first[b]), int(first[b + 1]))) for b in range(len(first) - 1)] == [list(b) for b in batches], "batches are not plan_batches(pairs, k)"
+    loads = [[] for _ in batches]
+    for b, poc, slot in ld:
+        loads[int(b)].append((int(poc), int(slot)))
+    where = [{} for _ in batches]
+    for b, idx in enumerate(batches):
+        for i in idx:
+            where[b][pairs[i][0]] = int(wh[i, 0])
+            where[b][pairs[i][1]] = int(wh[i, 1])
     return loads, where
 
 

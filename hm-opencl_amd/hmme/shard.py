@@ -42,101 +42,133 @@ def pairs_for_rank(n_pairs, rank, world):
 
 
 def pairs_per_rank(n_pairs, world):
-    """every rank contributes the same number of blocks to the gather (short ranks pad)"""
+    """the largest number of pairs any rank searches (rank r searches len(pairs_for_rank(n_pairs, r, world)) of them)"""
     return (n_pairs + world - 1) // world
 
 
-def gather_pair_results(local_mv, local_sad, n_pairs):
-    """local_mv: [k, n_ctu, 593, 2] int16, local_sad: [k, n_ctu, 593] int32 with k = pairs_per_rank
-    (rows beyond the rank's real pairs are padding).  Returns (mv, sad) in pair order on every rank."""
+def pair_counts(n_pairs, world):
+    """pairs per rank, rank by rank -- the load balance of the job (124 pairs on 8 ranks: four ranks search 16, four 15)"""
+    return [len(range(r, n_pairs, world)) for r in range(world)]
+
+
+def _staged(t):
+    """gloo moves host tensors: a device tensor of the one-GPU rehearsal (bench.py --share-gpu --backend gloo) travels through the host"""
+    return t.cpu() if (dist.get_backend() == "gloo" and t.device.type != "cpu") else t
+
+
+def gather_to_root(local, counts=None, root=0, out=None, async_op=False):
+    """The one exchange step of the path: every rank's result block to rank `root` -- and only there; nothing is sent to ranks that
+    do not read it (round 3 all-gathered: 8 x the bytes, plus zero tables that padded short ranks).
+
+    local   this rank's [k_r, ...] block (k_r may differ between ranks and may be 0)
+    counts  k_r of every rank (default: all equal to local.shape[0])
+    out     root only, optional: preallocated [sum(counts), ...] tensor on local's device
+    Returns (blocks, works, bytes_received): on root `blocks` is the list of per-rank views into `out` (rank order) and
+    bytes_received what the other ranks sent; elsewhere (None, works, 0).  Point-to-point sends and receives issued as one batch
+    (dist.batch_isend_irecv = ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on RCCL); with async_op the caller waits on
+    `works` (a stream-side dependency under RCCL) before it reads `blocks` or rewrites `local`."""
+    if not dist.is_initialized():
+        return [local], [], 0
+    world, rank = dist.get_world_size(), dist.get_rank()
+    counts = list(counts) if counts is not None else [int(local.shape[0])] * world
+    assert len(counts) == world and int(local.shape[0]) == counts[rank], (counts, rank, tuple(local.shape))
+    host_staged = dist.get_backend() == "gloo" and local.device.type != "cpu"
+    src = _staged(local.contiguous())
+    ops, blocks, received, recv_bufs = [], None, 0, []
+    if rank == root:
+        if out is None:
+            out = torch.empty((sum(counts),) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        offs = [sum(counts[:r]) for r in range(world)]
+        blocks = [out[offs[r]:offs[r] + counts[r]] for r in range(world)]
+        blocks[root].copy_(local)
+        for r in range(world):
+            if r == root or counts[r] == 0:
+                continue
+            buf = torch.empty(blocks[r].shape, dtype=local.dtype) if host_staged else blocks[r]
+            recv_bufs.append((buf, blocks[r]))
+            ops.append(dist.P2POp(dist.irecv, buf, r))
+            received += buf.numel() * buf.element_size()
+    elif counts[rank] > 0:
+        ops.append(dist.P2POp(dist.isend, src, root))
+    works = dist.batch_isend_irecv(ops) if ops else []
+    if not async_op or host_staged:
+        for w in works:
+            w.wait()
+        works = []
+        if host_staged:
+            for buf, dst in recv_bufs:
+                dst.copy_(buf)
+    return blocks, works, received
+
+
+def gather_pair_results(local_mv, local_sad, n_pairs, root=0):
+    """local_mv: [k_r, n_ctu, 593, 2] int16, local_sad: [k_r, n_ctu, 593] int32: the tables of this rank's pairs (pairs_for_rank order;
+    rows beyond them, if any, are ignored).  Returns (mv, sad) in pair order on rank `root`, (None, None) on the others."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     if world == 1:
         return local_mv[:n_pairs], local_sad[:n_pairs]
-    k = pairs_per_rank(n_pairs, world)
-    assert local_mv.shape[0] == k and local_sad.shape[0] == k
-    # an (mvx, mvy) int16 pair travels as one int32 word (TComMv is 4 bytes; gloo has no int16 collectives)
-    mv_shape = tuple(local_mv.shape)
-    local_mv = local_mv.contiguous().view(torch.int32)
-    # concatenated layout (world * k, ...): accepted by both the RCCL and the gloo implementation
-    dev = local_mv.device
-    if dist.get_backend() == "gloo" and dev.type != "cpu":   # rehearsal of the N > 1 path without RCCL: stage on host
-        local_mv, local_sad = local_mv.cpu(), local_sad.cpu()
-    g_mv = torch.empty((world * k,) + tuple(local_mv.shape[1:]), dtype=local_mv.dtype, device=local_mv.device)
-    g_sad = torch.empty((world * k,) + tuple(local_sad.shape[1:]), dtype=local_sad.dtype, device=local_sad.device)
-    dist.all_gather_into_tensor(g_mv, local_mv.contiguous())
-    dist.all_gather_into_tensor(g_sad, local_sad.contiguous())
-    g_mv, g_sad = g_mv.to(dev), g_sad.to(dev)
-    g_mv = g_mv.view((world, k) + tuple(local_mv.shape[1:]))
-    g_sad = g_sad.view((world, k) + tuple(local_sad.shape[1:]))
-    # block [r, i] holds pair i * world + r
-    mv = g_mv.transpose(0, 1).reshape((k * world,) + tuple(local_mv.shape[1:])).view(torch.int16)
-    mv = mv.reshape((k * world,) + mv_shape[1:])[:n_pairs]
-    sad = g_sad.transpose(0, 1).reshape((k * world,) + tuple(local_sad.shape[1:]))[:n_pairs]
-    return mv, sad
-
-
-def gather_packed(buf, out=None, async_op=False):
-    """one collective for both result tables.  buf: int32 [2, k, n_ctu, 593] (plane 0 = TComMv words,
-    plane 1 = SADs) of this rank; returns (out int32 [world, 2, k, n_ctu, 593], work-or-None).
-    With async_op=True the gather runs on RCCL's stream while the caller launches the next search
-    (the handle's wait() is a stream-side dependency, not a host block)."""
-    if not dist.is_initialized():
-        return buf.unsqueeze(0), None
-    world = dist.get_world_size()   # a world of 1 still goes through the collective (bench.py's one-GPU rehearsal of the RCCL calls)
-    if out is None:
-        out = torch.empty((world,) + tuple(buf.shape), dtype=buf.dtype, device=buf.device)
-    flat_out = out.view((world * buf.shape[0],) + tuple(buf.shape[1:]))
-    if dist.get_backend() == "gloo" and buf.device.type != "cpu":   # rehearsal path: stage on the host
-        tmp = torch.empty(flat_out.shape, dtype=buf.dtype)
-        dist.all_gather_into_tensor(tmp, buf.cpu())
-        flat_out.copy_(tmp)
-        return out, None
-    work = dist.all_gather_into_tensor(flat_out, buf, async_op=async_op)
-    return out, work
+    rank = dist.get_rank()
+    counts = pair_counts(n_pairs, world)
+    # an (mvx, mvy) int16 pair travels as one int32 word (TComMv is 4 bytes; gloo has no int16 point-to-point either)
+    mv_words = local_mv[:counts[rank]].contiguous().view(torch.int32).squeeze(-1)
+    b_mv, _, _ = gather_to_root(mv_words, counts, root)
+    b_sad, _, _ = gather_to_root(local_sad[:counts[rank]].contiguous(), counts, root)
+    if rank != root:
+        return None, None
+    mv = torch.empty((n_pairs,) + tuple(mv_words.shape[1:]), dtype=torch.int32, device=local_mv.device)
+    sad = torch.empty((n_pairs,) + tuple(local_sad.shape[1:]), dtype=local_sad.dtype, device=local_sad.device)
+    for r in range(world):   # block r, row i holds pair i * world + r
+        mv[r::world] = b_mv[r]
+        sad[r::world] = b_sad[r]
+    return mv.unsqueeze(-1).view(torch.int16), sad
 
 
 class PipelinedGather:
     """Double-buffered result exchange of a stream of search steps (bench.py --gpus N, an open-loop ME pass).
 
-    Step k writes its tables into local buffer k % 2 and starts their all-gather; the gather runs on the collective
-    backend's own stream / thread while step k+1 searches into the other buffer, so the 9.7 MB per rank and 2160p
-    pair never stall the search kernel.  Before buffer b is written again (step k+2) the gather that read it (step k)
-    is waited for -- with RCCL a stream-side dependency, not a host block -- and only then is its gathered block
-    handed to `consume` and recycled.
+    Step k writes its tables into local buffer k % 2 and starts their gather to rank 0 (gather_to_root); the transfer runs on the
+    collective backend's own stream / thread while step k+1 searches into the other buffer, so the 9.7 MB per rank and 2160p pair
+    never stall the search kernel.  Before buffer b is written again (step k+2) the transfer that read it (step k) is waited for --
+    with RCCL a stream-side dependency, not a host block -- and only then is its gathered block handed to `consume` and recycled.
 
     make_local() -> tensor            this rank's [2, k, n_ctu, 593] int32 block (plane 0 TComMv words, plane 1 SADs)
     launch(buf, step)                 enqueue the search of step `step` writing into buf (engine call; tests: a stand-in)
-    consume(step, gathered) or None   gathered = [world, ...] block of `step`, valid only during the call
+    consume(step, gathered) or None   rank 0: gathered = [world, ...] block of `step`, valid only during the call; other ranks: None
     """
 
-    def __init__(self, make_local, distributed, async_op=True):
-        self.world = dist.get_world_size() if (distributed and dist.is_initialized()) else 1
-        self.distributed = bool(distributed)
+    def __init__(self, make_local, distributed, async_op=True, root=0):
+        self.distributed = bool(distributed) and dist.is_initialized()
+        self.world = dist.get_world_size() if self.distributed else 1
+        self.rank = dist.get_rank() if self.distributed else 0
+        self.root = root
         self.async_op = async_op
         self.bufs = [make_local(), make_local()]
-        self.gathered = [torch.empty((self.world,) + tuple(b.shape), dtype=b.dtype, device=b.device) if self.distributed else None
-                         for b in self.bufs]
-        self.pending = [None, None]     # (step, work-or-None) of the gather that last used buffer b
+        self.gathered = [torch.empty((self.world,) + tuple(b.shape), dtype=b.dtype, device=b.device)
+                         if (self.distributed and self.rank == root) else None for b in self.bufs]
+        self.pending = [None, None]     # (step, works) of the transfer that last used buffer b
+        self.bytes_received = 0         # root: what the other ranks have sent so far
         self.k = 0
 
     def _retire(self, b, consume):
         if self.pending[b] is None:
             return
-        step, work = self.pending[b]
-        if work is not None:
-            work.wait()
+        step, works = self.pending[b]
+        for w in works:
+            w.wait()
         self.pending[b] = None
         if consume is not None:
-            consume(step, self.gathered[b] if self.distributed else self.bufs[b].unsqueeze(0))
+            consume(step, (self.gathered[b] if self.rank == self.root else None) if self.distributed else self.bufs[b].unsqueeze(0))
 
     def step(self, launch, consume=None):
         b = self.k & 1
-        self._retire(b, consume)        # the gather that read bufs[b] (two steps ago) is done before bufs[b] is overwritten
+        self._retire(b, consume)        # the transfer that read bufs[b] (two steps ago) is done before bufs[b] is overwritten
         launch(self.bufs[b], self.k)
-        work = None
-        if self.distributed:   # the one exchange step of the path: tables of all `world` pairs to every rank
-            _, work = gather_packed(self.bufs[b], self.gathered[b], async_op=self.async_op)
-        self.pending[b] = (self.k, work)
+        works = []
+        if self.distributed:   # the one exchange step of the path: this step's tables of all `world` pairs to rank 0
+            out = self.gathered[b].view((self.world * self.bufs[b].shape[0],) + tuple(self.bufs[b].shape[1:])) if self.rank == self.root else None
+            _, works, got = gather_to_root(self.bufs[b], None, self.root, out, async_op=self.async_op)
+            self.bytes_received += got
+        self.pending[b] = (self.k, works)
         self.k += 1
         return b
 
@@ -149,15 +181,20 @@ class PipelinedGather:
         """this rank's buffer of the most recent step"""
         return self.bufs[(self.k - 1) & 1]
 
+    @property
+    def last_gathered(self):
+        """rank 0, after drain(): the [world, ...] block of the most recent step (None elsewhere / without a process group)"""
+        return self.gathered[(self.k - 1) & 1]
+
 
 def search_sequence(search_pair, n_pairs, n_ctu, device):
     """run `search_pair(p, out_mv, out_sad)` (fills device tensors [n_ctu,593,2] / [n_ctu,593]) for the
-    rank's pairs and gather.  `search_pair` is the engine call on GPUs; tests substitute a CPU stand-in."""
+    rank's pairs and gather to rank 0 (the other ranks get (None, None)).  `search_pair` is the engine call on GPUs; tests substitute a CPU stand-in."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
-    k = pairs_per_rank(n_pairs, world)
-    mv = torch.zeros((k, n_ctu, 593, 2), dtype=torch.int16, device=device)
-    sad = torch.zeros((k, n_ctu, 593), dtype=torch.int32, device=device)
-    for i, p in enumerate(pairs_for_rank(n_pairs, rank, world)):
+    mine = pairs_for_rank(n_pairs, rank, world)
+    mv = torch.zeros((len(mine), n_ctu, 593, 2), dtype=torch.int16, device=device)
+    sad = torch.zeros((len(mine), n_ctu, 593), dtype=torch.int32, device=device)
+    for i, p in enumerate(mine):
         search_pair(p, mv[i], sad[i])
     return gather_pair_results(mv, sad, n_pairs)

@@ -109,7 +109,7 @@ struct Free { int buf; hipEvent_t ev; };  // buf < 0: stop
 
 SequenceSearch::SequenceSearch(hmme_ctx* ctx, const SequenceConfig& cfg)
     : ctx_(ctx), cfg_(cfg), n_ctu_(hmme_num_ctus(cfg.width, cfg.height)), s_copy_(0), s_compute_(0), s_download_(0), d_mv_(0), d_sad_(0),
-      d_qmv_(0), d_cost_(0), h_mv_(0), h_qmv_(0), h_sad_(0), h_cost_(0), cap_pairs_(0) {
+      d_qmv_(0), d_cost_(0), h_mv_(0), h_qmv_(0), h_sad_(0), h_cost_(0), cap_pairs_(0), x_mv_(0), x_qmv_(0), x_sad_(0), x_cost_(0) {
   if (cfg_.pairs_per_launch < 1) cfg_.pairs_per_launch = 1;
   if (cfg_.pairs_per_launch > 16) cfg_.pairs_per_launch = 16;
   if (cfg_.plane_slots <= 0) cfg_.plane_slots = std::max(8, 2 * cfg_.pairs_per_launch + 2);
@@ -117,6 +117,11 @@ SequenceSearch::SequenceSearch(hmme_ctx* ctx, const SequenceConfig& cfg)
 }
 
 SequenceSearch::~SequenceSearch() { release(); }
+
+void SequenceSearch::set_host_output(int16_t* mv, uint32_t* sad, int16_t* qmv, uint32_t* cost, const std::vector<int>& dest_index) {
+  x_mv_ = mv; x_sad_ = sad; x_qmv_ = qmv; x_cost_ = cost;
+  x_index_ = dest_index;
+}
 
 void SequenceSearch::release() {
   for (size_t i = 0; i < planes_.size(); ++i) hmme_plane_destroy(planes_[i]);
@@ -156,6 +161,7 @@ int SequenceSearch::fail(int code, const std::string& what) {
 
 int SequenceSearch::run(const std::vector<std::pair<int, int> >& pairs, const LumaReader& read_luma, SequenceStats* stats) {
   if (!ctx_) return fail(HMME_ERR_ARG, "no context");
+  if (!read_luma) return fail(HMME_ERR_ARG, "no picture source");
   const int device = hmme_device_index(ctx_);
   SEQ_HIP(hipSetDevice(device));              // this object makes HIP calls of its own beside the library's
   const int n_pairs = (int)pairs.size();
@@ -188,6 +194,8 @@ int SequenceSearch::run(const std::vector<std::pair<int, int> >& pairs, const Lu
     host_bufs_.push_back(p);
   }
   const size_t per_pair = (size_t)n_ctu_ * HMME_NUM_CTU_PARTS;   // slots of one pair's tables
+  if (x_mv_ && ((int)x_index_.size() < n_pairs || !x_sad_ || (cfg_.refine && (!x_qmv_ || !x_cost_))))
+    return fail(HMME_ERR_ARG, "set_host_output: arrays / destination indices do not cover the pairs of this run");
   if ((size_t)n_pairs > cap_pairs_) {
     hipFree(d_mv_); hipFree(d_sad_); hipFree(d_qmv_); hipFree(d_cost_);
     if (h_mv_) hipHostFree(h_mv_);
@@ -195,21 +203,32 @@ int SequenceSearch::run(const std::vector<std::pair<int, int> >& pairs, const Lu
     if (h_qmv_) hipHostFree(h_qmv_);
     if (h_cost_) hipHostFree(h_cost_);
     d_mv_ = d_sad_ = d_qmv_ = d_cost_ = 0; h_mv_ = h_qmv_ = 0; h_sad_ = h_cost_ = 0; cap_pairs_ = 0;
+    const bool own_host = !cfg_.no_download && !x_mv_;   // otherwise the tables stay on the device or go to the caller's arrays
     SEQ_HIP(hipMalloc(&d_mv_, 4 * per_pair * n_pairs));
     SEQ_HIP(hipMalloc(&d_sad_, 4 * per_pair * n_pairs));
-    SEQ_HIP(hipHostMalloc((void**)&h_mv_, 4 * per_pair * n_pairs, hipHostMallocDefault));
-    SEQ_HIP(hipHostMalloc((void**)&h_sad_, 4 * per_pair * n_pairs, hipHostMallocDefault));
+    if (own_host) SEQ_HIP(hipHostMalloc((void**)&h_mv_, 4 * per_pair * n_pairs, hipHostMallocDefault));
+    if (own_host) SEQ_HIP(hipHostMalloc((void**)&h_sad_, 4 * per_pair * n_pairs, hipHostMallocDefault));
     if (cfg_.refine) {
       SEQ_HIP(hipMalloc(&d_qmv_, 4 * per_pair * n_pairs));
       SEQ_HIP(hipMalloc(&d_cost_, 4 * per_pair * n_pairs));
-      SEQ_HIP(hipHostMalloc((void**)&h_qmv_, 4 * per_pair * n_pairs, hipHostMallocDefault));
-      SEQ_HIP(hipHostMalloc((void**)&h_cost_, 4 * per_pair * n_pairs, hipHostMallocDefault));
+      if (own_host) SEQ_HIP(hipHostMalloc((void**)&h_qmv_, 4 * per_pair * n_pairs, hipHostMallocDefault));
+      if (own_host) SEQ_HIP(hipHostMalloc((void**)&h_cost_, 4 * per_pair * n_pairs, hipHostMallocDefault));
     }
     cap_pairs_ = n_pairs;
   }
-  std::vector<hipEvent_t> buf_events(cfg_.host_buffers), batch_events(batches.size());
-  for (size_t i = 0; i < buf_events.size(); ++i) SEQ_HIP(hipEventCreateWithFlags(&buf_events[i], hipEventDisableTiming));
-  for (size_t i = 0; i < batch_events.size(); ++i) SEQ_HIP(hipEventCreateWithFlags(&batch_events[i], hipEventDisableTiming));
+  // events of this run: destroyed on every way out of run(), the early error returns included
+  struct Events {
+    std::vector<hipEvent_t> v;
+    ~Events() { for (size_t i = 0; i < v.size(); ++i) if (v[i]) hipEventDestroy(v[i]); }
+    hipError_t create(size_t n) {
+      v.assign(n, (hipEvent_t)0);
+      for (size_t i = 0; i < n; ++i) { const hipError_t e = hipEventCreateWithFlags(&v[i], hipEventDisableTiming); if (e != hipSuccess) return e; }
+      return hipSuccess;
+    }
+    hipEvent_t operator[](size_t i) const { return v[i]; }
+  } buf_events, batch_events;
+  SEQ_HIP(buf_events.create(cfg_.host_buffers));
+  SEQ_HIP(batch_events.create(batches.size()));
 
   const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   // ---- reader thread: pictures in upload order into the page-locked buffers
@@ -226,9 +245,11 @@ int SequenceSearch::run(const std::vector<std::pair<int, int> >& pairs, const Lu
     for (size_t n = 0; n < order.size(); ++n) {
       const Free f = free_bufs.get();        // handed back only after the buffer's upload has been ISSUED
       if (f.buf < 0 || stop.load()) break;
-      if (f.ev) hipEventSynchronize(f.ev);   // ... and that upload has run
+      bool ok = !f.ev || hipEventSynchronize(f.ev) == hipSuccess;   // ... and that upload has run (a failed copy must not be overwritten silently)
       const std::chrono::steady_clock::time_point r0 = std::chrono::steady_clock::now();
-      const bool ok = read_luma(order[n], host_bufs_[f.buf]);
+      if (ok) {
+        try { ok = read_luma(order[n], host_bufs_[f.buf]); } catch (...) { ok = false; }   // a throwing source is a failed picture, not std::terminate
+      }
       read_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - r0).count();
       Ready r = {ok ? order[n] : -1, f.buf};
       ready.put(r);
@@ -263,12 +284,24 @@ int SequenceSearch::run(const std::vector<std::pair<int, int> >& pairs, const Lu
       lrc = hmme_refine_pairs_device(ctx_, curs, refs, k, &fp, 0, mv, 1, (char*)d_qmv_ + 4 * per_pair * i0, (char*)d_cost_ + 4 * per_pair * i0, s_compute);
     if (lrc != HMME_OK) { what = std::string("launch: ") + hmme_last_error(ctx_); return lrc; }
     hipError_t e = hipEventRecord(batch_events[b], s_compute);
+    if (cfg_.no_download) return e == hipSuccess ? HMME_OK : HMME_ERR_DEVICE;
     if (e == hipSuccess) e = hipStreamWaitEvent(s_dl, batch_events[b], 0);
-    const size_t bytes = 4 * per_pair * k, off = 4 * per_pair * i0;
-    if (e == hipSuccess) e = hipMemcpyAsync((char*)h_mv_ + off, mv, bytes, hipMemcpyDeviceToHost, s_dl);
-    if (e == hipSuccess) e = hipMemcpyAsync((char*)h_sad_ + off, sad, bytes, hipMemcpyDeviceToHost, s_dl);
-    if (e == hipSuccess && cfg_.refine) e = hipMemcpyAsync((char*)h_qmv_ + off, (char*)d_qmv_ + off, bytes, hipMemcpyDeviceToHost, s_dl);
-    if (e == hipSuccess && cfg_.refine) e = hipMemcpyAsync((char*)h_cost_ + off, (char*)d_cost_ + off, bytes, hipMemcpyDeviceToHost, s_dl);
+    const size_t pair_bytes = 4 * per_pair;
+    if (x_mv_) {   // the caller's arrays: every pair has its own place
+      for (int i = 0; i < k && e == hipSuccess; ++i) {
+        const size_t src = pair_bytes * (i0 + i), dst = pair_bytes * (size_t)x_index_[i0 + i];
+        e = hipMemcpyAsync((char*)x_mv_ + dst, (char*)d_mv_ + src, pair_bytes, hipMemcpyDeviceToHost, s_dl);
+        if (e == hipSuccess) e = hipMemcpyAsync((char*)x_sad_ + dst, (char*)d_sad_ + src, pair_bytes, hipMemcpyDeviceToHost, s_dl);
+        if (e == hipSuccess && cfg_.refine) e = hipMemcpyAsync((char*)x_qmv_ + dst, (char*)d_qmv_ + src, pair_bytes, hipMemcpyDeviceToHost, s_dl);
+        if (e == hipSuccess && cfg_.refine) e = hipMemcpyAsync((char*)x_cost_ + dst, (char*)d_cost_ + src, pair_bytes, hipMemcpyDeviceToHost, s_dl);
+      }
+    } else {
+      const size_t bytes = pair_bytes * k, off = pair_bytes * i0;
+      if (e == hipSuccess) e = hipMemcpyAsync((char*)h_mv_ + off, mv, bytes, hipMemcpyDeviceToHost, s_dl);
+      if (e == hipSuccess) e = hipMemcpyAsync((char*)h_sad_ + off, sad, bytes, hipMemcpyDeviceToHost, s_dl);
+      if (e == hipSuccess && cfg_.refine) e = hipMemcpyAsync((char*)h_qmv_ + off, (char*)d_qmv_ + off, bytes, hipMemcpyDeviceToHost, s_dl);
+      if (e == hipSuccess && cfg_.refine) e = hipMemcpyAsync((char*)h_cost_ + off, (char*)d_cost_ + off, bytes, hipMemcpyDeviceToHost, s_dl);
+    }
     if (e != hipSuccess) { what = std::string("download: ") + hipGetErrorString(e); return HMME_ERR_DEVICE; }
     return HMME_OK;
   };
@@ -288,8 +321,6 @@ int SequenceSearch::run(const std::vector<std::pair<int, int> >& pairs, const Lu
   hipStreamSynchronize(s_copy);
   hipStreamSynchronize(s_compute);
   hipStreamSynchronize(s_dl);
-  for (size_t i = 0; i < buf_events.size(); ++i) hipEventDestroy(buf_events[i]);
-  for (size_t i = 0; i < batch_events.size(); ++i) hipEventDestroy(batch_events[i]);
   if (stats) {
     stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     stats->read_seconds = read_s;
@@ -320,3 +351,41 @@ LumaReader yuv_file_reader(const std::string& path, int width, int height, int b
 }
 
 }  // namespace hmme_host
+
+// ---- C entry points of the planner: hm-opencl_amd/hmme/sequence.py binds these with ctypes, so the launch / plane-slot plan exists
+// once (round 3 kept a Python twin of plan_plane_loads in step with this one by tests only)
+extern "C" {
+// pairs: n_pairs x (current POC, reference POC).  Outputs: batch_first[n_batches + 1] (launch b = pairs [batch_first[b],
+// batch_first[b + 1])), loads[3 * n_loads] = (launch, POC, slot) in issue order, where[2 * n_pairs] = (slot of the current picture, slot of
+// the reference picture) of every pair when its launch runs.  Capacities: batch_first n_pairs + 1, loads 3 * max_loads, where
+// 2 * n_pairs.  Returns the number of loads, or -1 with a message in err (too few slots, capacity).
+int hmme_host_plan(const int32_t* pairs, int n_pairs, int pairs_per_launch, int n_slots, int32_t* batch_first, int* n_batches,
+                   int32_t* loads, int max_loads, int32_t* where, char* err, int err_len) {
+  std::vector<std::pair<int, int> > pr;
+  for (int i = 0; i < n_pairs; ++i) pr.push_back(std::make_pair((int)pairs[2 * i], (int)pairs[2 * i + 1]));
+  const std::vector<std::pair<int, int> > batches = hmme_host::plan_batches(n_pairs, pairs_per_launch);
+  std::vector<std::vector<hmme_host::PlaneLoad> > ld;
+  std::vector<std::vector<std::pair<int, int> > > wh;
+  std::string e;
+  bool ok = hmme_host::plan_plane_loads(pr, batches, n_slots, &ld, &wh, &e);
+  int n = 0;
+  if (ok) {
+    for (size_t b = 0; b < ld.size(); ++b) n += (int)ld[b].size();
+    if (n > max_loads) { ok = false; e = "load list capacity"; }
+  }
+  if (!ok) {
+    if (err && err_len > 0) snprintf(err, (size_t)err_len, "%s", e.c_str());
+    return -1;
+  }
+  *n_batches = (int)batches.size();
+  for (size_t b = 0; b < batches.size(); ++b) batch_first[b] = batches[b].first;
+  batch_first[batches.size()] = n_pairs;
+  int k = 0;
+  for (size_t b = 0; b < ld.size(); ++b)
+    for (size_t j = 0; j < ld[b].size(); ++j) { loads[3 * k] = (int32_t)b; loads[3 * k + 1] = ld[b][j].poc; loads[3 * k + 2] = ld[b][j].slot; ++k; }
+  for (size_t b = 0; b < wh.size(); ++b)
+    for (size_t i = 0; i < wh[b].size(); ++i) { where[2 * (batches[b].first + i)] = wh[b][i].first; where[2 * (batches[b].first + i) + 1] = wh[b][i].second; }
+  return n;
+}
+}  // extern "C"
+

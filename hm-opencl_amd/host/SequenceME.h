@@ -39,6 +39,7 @@ struct SequenceConfig {
   int plane_slots;       // >= 2 * pairs_per_launch is always enough; 0 = max(8, 2 * pairs_per_launch + 2)
   int host_buffers;      // page-locked picture buffers between reader and copy stream; 0 = 4
   bool refine;           // also run xPatternSearchFracDIF (Hadamard) for every slot
+  bool no_download;      // leave the tables in device memory (d_mv() ...): a multi-device driver gathers them on the device side
 };
 
 struct SequenceStats {
@@ -64,6 +65,15 @@ class SequenceSearch {
   const uint32_t* sad() const { return h_sad_; }
   const int16_t* qmv() const { return h_qmv_; }
   const uint32_t* cost() const { return h_cost_; }
+  // the same tables in device memory, pairs in the order given to run() (valid until the next run() / destruction)
+  const void* d_mv() const { return d_mv_; }
+  const void* d_sad() const { return d_sad_; }
+  const void* d_qmv() const { return d_qmv_; }
+  const void* d_cost() const { return d_cost_; }
+  // Download into the caller's page-locked arrays instead of this object's own: pair i of run() lands at table index dest_index[i]
+  // (a multi-device driver gives every device its places in ONE result in global pair order).  The arrays must stay valid and
+  // page-locked (hipHostMalloc / hmme_host_register) during run(); qmv / cost may be null without refine.
+  void set_host_output(int16_t* mv, uint32_t* sad, int16_t* qmv, uint32_t* cost, const std::vector<int>& dest_index);
   int num_ctus() const { return n_ctu_; }
   const std::string& error() const { return err_; }
 
@@ -83,6 +93,9 @@ class SequenceSearch {
   int16_t *h_mv_, *h_qmv_;
   uint32_t *h_sad_, *h_cost_;
   size_t cap_pairs_;
+  int16_t *x_mv_, *x_qmv_;         // external output (set_host_output), or null
+  uint32_t *x_sad_, *x_cost_;
+  std::vector<int> x_index_;
 };
 
 // planar YUV file reader for SequenceSearch: luma of picture `poc` (4:2:0 / 4:0:0; 8-bit or 16-bit little-endian samples,

@@ -10,7 +10,9 @@
 #include <string>
 #include <vector>
 
-#include "../../hm-opencl_amd/host/SequenceME.h"
+#include <thread>
+
+#include "../../hm-opencl_amd/host/MultiDeviceME.h"
 
 using namespace hmme_host;
 
@@ -71,7 +73,7 @@ int main() {
   }
   // run() without a context fails with a message, no crash; the planning error (too few slots) surfaces through run() as well
   {
-    SequenceConfig cfg = {128, 64, 8, 16, 4, 3, 0, false};
+    SequenceConfig cfg = {128, 64, 8, 16, 4, 3, 0, false, false};
     SequenceSearch s(0, cfg);
     if (s.run(ra, LumaReader(), 0) != HMME_ERR_ARG || s.error().empty()) { printf("FAIL: run() without a context\n"); rc = 1; }
   }
@@ -94,6 +96,43 @@ int main() {
     if (rd && rd(n, &buf[0])) { printf("FAIL: read beyond the end of the file\n"); rc = 1; }
     unlink(path);
     if (yuv_file_reader("/nonexistent/file.yuv", w, h, bd, chroma, &err) || err.empty()) { printf("FAIL: missing file\n"); rc = 1; }
+  }
+  // ---- N devices: the shard rule, the planner called from N host threads at once (one per device, as MultiDeviceSearch does), and the
+  // failure paths of MultiDeviceSearch::run that need no GPU
+  {
+    for (int world = 1; world <= 8; ++world) {
+      std::set<int> seen;
+      size_t most = 0, least = 1 << 30;
+      for (int r = 0; r < world; ++r) {
+        const std::vector<int> mine = pairs_for_device((int)ra.size(), r, world);
+        for (size_t i = 0; i < mine.size(); ++i) { if (mine[i] % world != r || !seen.insert(mine[i]).second) rc = 1; }
+        most = mine.size() > most ? mine.size() : most; least = mine.size() < least ? mine.size() : least;
+      }
+      if (seen.size() != ra.size() || most - least > 1) { printf("FAIL: shard of %d\n", world); rc = 1; }
+    }
+    const int world = 8;
+    std::vector<int> results(world, -1);
+    std::vector<std::thread> th;
+    for (int r = 0; r < world; ++r)
+      th.push_back(std::thread([&, r]() {
+        std::vector<std::pair<int, int> > mine;
+        const std::vector<int> idx = pairs_for_device((int)ra.size(), r, world);
+        for (size_t i = 0; i < idx.size(); ++i) mine.push_back(ra[idx[i]]);
+        int bad = 0;
+        for (int k = 1; k <= 4; ++k) bad += check(mine, k, 2 * k + 6, true) != 0;
+        results[r] = bad;
+      }));
+    for (int r = 0; r < world; ++r) th[r].join();
+    for (int r = 0; r < world; ++r) if (results[r] != 0) { printf("FAIL: planner on thread %d\n", r); rc = 1; }
+    SequenceConfig cfg = {128, 64, 8, 16, 2, 0, 0, false, false};
+    std::vector<int> twice(2, 0), none;
+    MultiDeviceSearch dup(twice, cfg, kGatherRccl, 57.9);
+    if (dup.run(ra, [](int) { return LumaReader(); }, 0) != HMME_ERR_ARG || dup.error().find("distinct") == std::string::npos) { printf("FAIL: RCCL gather with one device twice\n"); rc = 1; }
+    MultiDeviceSearch empty(none, cfg, kGatherPeer, 57.9);
+    if (empty.run(ra, [](int) { return LumaReader(); }, 0) != HMME_ERR_ARG) { printf("FAIL: no devices\n"); rc = 1; }
+    std::vector<int> far(1, 1000);   // a device that does not exist: hmme_create fails, run() reports it, nothing leaks
+    MultiDeviceSearch nodev(far, cfg, kGatherHost, 57.9);
+    if (nodev.run(ra, [](int) { return LumaReader(); }, 0) != HMME_ERR_DEVICE || nodev.error().empty()) { printf("FAIL: missing device\n"); rc = 1; }
   }
   printf("%s\n", rc ? "FAIL" : "PASS");
   return rc;

@@ -148,7 +148,7 @@ def test_cpu_side_code_is_clean_under_asan_and_ubsan(tmp_path):
                     "-x", "c", os.path.join(ROOT, "oracle", "hm_oracle.c"), "-x", "none",
                     "-L" + csrc, "-lhmme", "-Wl,-rpath," + csrc, "-lm", "-lpthread"], check=True)
     supp = tmp_path / "lsan.supp"
-    supp.write_text("leak:libamdhip64\nleak:libhsa-runtime64\nleak:libamd_comgr\n")
+    supp.write_text("leak:libamdhip64\nleak:libhsa-runtime64\nleak:libamd_comgr\nleak:librccl\n")
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", LSAN_OPTIONS=f"suppressions={supp}:print_suppressions=0",
                UBSAN_OPTIONS="print_stacktrace=1")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
@@ -157,7 +157,8 @@ def test_cpu_side_code_is_clean_under_asan_and_ubsan(tmp_path):
 
 
 def test_cpp_sequence_driver_is_clean_under_asan_and_ubsan(tmp_path):
-    """hm-opencl_amd/host/SequenceME.cpp (launch / plane-slot planning, and -- without a GPU -- the failure path of run()) compiled with
+    """hm-opencl_amd/host/SequenceME.cpp + MultiDeviceME.cpp (launch / plane-slot planning, the planner on eight host threads at once as the
+    N-device driver runs it, the pair -> device shard rule, and -- without a GPU -- the failure paths of both run() functions) compiled with
     -fsanitize=address,undefined together with tests/cpp/test_sequence_plan.cpp"""
     import shutil
     import subprocess
@@ -172,10 +173,10 @@ def test_cpp_sequence_driver_is_clean_under_asan_and_ubsan(tmp_path):
     csrc = os.path.join(ROOT, "hm-opencl_amd", "csrc")
     subprocess.run(["g++", "-O1", "-g", "-std=c++11", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
                     "-I/opt/rocm/include", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_sequence_plan.cpp"),
-                    os.path.join(ROOT, "hm-opencl_amd", "host", "SequenceME.cpp"), "-L" + csrc, "-lhmme", "-Wl,-rpath," + csrc,
-                    "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+                    os.path.join(ROOT, "hm-opencl_amd", "host", "SequenceME.cpp"), os.path.join(ROOT, "hm-opencl_amd", "host", "MultiDeviceME.cpp"),
+                    "-L" + csrc, "-lhmme", "-Wl,-rpath," + csrc, "-L/opt/rocm/lib", "-lrccl", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"], check=True)
     supp = tmp_path / "lsan.supp"
-    supp.write_text("leak:libamdhip64\nleak:libhsa-runtime64\nleak:libamd_comgr\n")
+    supp.write_text("leak:libamdhip64\nleak:libhsa-runtime64\nleak:libamd_comgr\nleak:librccl\n")
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", LSAN_OPTIONS=f"suppressions={supp}:print_suppressions=0",
                UBSAN_OPTIONS="print_stacktrace=1")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)

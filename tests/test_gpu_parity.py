@@ -853,7 +853,7 @@ def test_shift_free_and_int16_argument_checks(engine, oracle_lib):
 
 
 def test_bench_collective_path_under_torchrun_one_rank(tmp_path):
-    """bench.py's N > 1 code path (process group, PipelinedGather with RCCL all-gathers, barrier, max-over-ranks) rehearsed
+    """bench.py's N > 1 code path (process group, PipelinedGather, all_gather_object / all_reduce / barrier on RCCL, max-over-ranks) rehearsed
     with ONE rank on this one-GPU box: `torchrun --nproc-per-node 1` + HMME_BENCH_FORCE_DIST=1 (launcher started before any GPU call)"""
     import json
     import socket
@@ -868,7 +868,48 @@ def test_bench_collective_path_under_torchrun_one_rank(tmp_path):
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 100 and d["roofline"]["kernel_ms"] > 0
-    assert d["config"]["collective"] == "all_gather_into_tensor (nccl), world 1"
+    assert d["config"]["collective"] == "gather to rank 0: grouped send/recv (nccl), world 1"
+    m = d["multi_gpu"]
+    assert m["ranks_seen"] == 1 and m["backend"] == "nccl" and m["crc32_tables_match_per_rank"] == [True] and len(m["devices"]) == 1
+    assert m["devices"][0]["pci_bus_id"] and m["per_rank_kernel_ms"][0] > 0
+
+
+def test_bench_starts_its_own_ranks_two_rank_rehearsal_on_one_gpu(tmp_path):
+    """`python bench.py --gpus 2` exactly as a driver without a launcher invokes it: bench.py starts the two ranks itself (a child
+    torch.distributed.run, before anything touches the GPU) and relays rank 0's line.  On this one-GPU box both ranks share cuda:0 and
+    the tables travel over gloo (--share-gpu --backend gloo): a rehearsal of the code path, not a measurement.  The line must carry
+    the evidence of a two-rank run: both ranks' devices and process ids, per-rank times, the gather's bytes, the per-rank CRC
+    comparison (tables each rank computed == block rank 0 received) and rank 1's tables checked against the CPU oracle."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo", "--steps", "3",
+                        "--warmup", "1", "--size", "512x320", "--search-range", "16"], capture_output=True, text=True, timeout=900, env=env,
+                       cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                      # ONE line on stdout, whatever the ranks and the launcher print
+    d = json.loads(lines[0])
+    n_ctu = 8 * 5
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["frames_per_step"] == 2 and d["scaling"] == "weak"
+    m = d["multi_gpu"]
+    assert m["ranks_seen"] == 2 and m["self_launched"] is True and m["shared_gpu_rehearsal"] is True and m["distinct_devices"] == 1
+    assert [e["rank"] for e in m["devices"]] == [0, 1] and m["devices"][0]["pid"] != m["devices"][1]["pid"]
+    assert m["crc32_tables_match_per_rank"] == [True, True]
+    assert len(m["per_rank_kernel_ms"]) == 2 and min(m["per_rank_kernel_ms"]) > 0 and m["step_ms_min_max"][0] <= m["step_ms_min_max"][1]
+    assert m["gather"]["bytes_received_by_rank0_per_step"] == 2 * n_ctu * 593 * 4           # rank 1's block, nothing else
+    assert m["gather"]["bytes_received_in_timed_steps"] == 3 * 2 * n_ctu * 593 * 4
+    assert m["verified_rank"]["rank"] == 1 and m["verified_rank"]["slots"] >= 593
+    # the whole-job value counts both ranks' pictures
+    assert abs(d["ctus_per_s"] - 2 * n_ctu * 3 / (d["ms_per_step"] * 3e-3)) / d["ctus_per_s"] < 0.01
+    # without --share-gpu two ranks on a one-GPU box must refuse, not silently share the device
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0",
+                         "--size", "256x192", "--search-range", "8", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env,
+                        cwd=str(tmp_path))
+    assert r2.returncode != 0 and not [ln for ln in r2.stdout.splitlines() if ln.startswith("{")]
+    assert "no GPU of its own" in r2.stderr
 
 
 def test_sequence_driver_reads_a_yuv_file(tmp_path):

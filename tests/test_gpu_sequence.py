@@ -189,6 +189,62 @@ def test_cpp_sequence_driver_streams_a_yuv_file_equal_to_the_oracle(tmp_path, or
             assert np.array_equal(qmv[i], oq) and np.array_equal(cost[i], oc), (i, cur, ref)
 
 
+def _read_tables(path):
+    raw = np.fromfile(path, np.int32)
+    n_pairs, n_ctu, refined = (int(v) for v in raw[:3])
+    body = raw[4 + 2 * n_pairs:]
+    per = n_pairs * n_ctu * 593
+    t = {"pairs": raw[4:4 + 2 * n_pairs].reshape(n_pairs, 2).tolist(), "mv": body[:per].view(np.int16).reshape(n_pairs, n_ctu, 593, 2),
+         "sad": body[per:2 * per].view(np.uint32).reshape(n_pairs, n_ctu, 593)}
+    if refined:
+        t["qmv"] = body[2 * per:3 * per].view(np.int16).reshape(n_pairs, n_ctu, 593, 2)
+        t["cost"] = body[3 * per:4 * per].view(np.uint32).reshape(n_pairs, n_ctu, 593)
+    return t
+
+
+@pytest.mark.parametrize("devices,gather", [("0,0", "peer"), ("0,0,0", "host"), ("0", "rccl"), ("0,0", "rccl")])
+def test_cpp_multi_device_driver_on_contexts_sharing_the_one_gpu(tmp_path, oracle_lib, devices, gather):
+    """hm-opencl_amd/host/MultiDeviceME (C++, one process, one host thread + hmme context + sequence driver per rank, pair p -> rank
+    p mod N, tables gathered into rank 0's page-locked memory in pair order) rehearsed on this one-GPU box with N contexts on device
+    0: the gathered tables equal the single-context driver's, and the oracle's.  `peer` = hipMemcpyPeerAsync into device 0's gather
+    buffer, `host` = every rank downloads into its places, `rccl` = ncclCommInitAll + grouped ncclSend / ncclRecv -- which exists for
+    N DISTINCT devices (unmeasured here: one GPU), is exercised with world 1, and must REFUSE one GPU twice."""
+    from conftest import ROOT
+    from hmme import shard, synth
+    host = os.path.join(ROOT, "hm-opencl_amd", "host")
+    subprocess.run(["make", "-s", "-C", host], check=True)
+    w, h, n, sr = 448, 256, 9, 24
+    seq = synth.Sequence(w, h, n, seed=777, bit_depth=8)
+    path = os.path.join(tmp_path, "seq.yuv")
+    seq.write_yuv(path)
+    common = ["--yuv", path, "--size", f"{w}x{h}", "--frames", str(n), "--gop", "randomaccess", "--search-range", str(sr), "--pairs-per-launch", "2", "--refine"]
+    out_m, out_1 = os.path.join(tmp_path, "multi.bin"), os.path.join(tmp_path, "single.bin")
+    r = subprocess.run([os.path.join(host, "me_stream")] + common + ["--devices", devices, "--gather", gather, "--out", out_m, "--repeat", "2"],
+                       capture_output=True, text=True, timeout=600)
+    world = len(devices.split(","))
+    if gather == "rccl" and world > 1:
+        assert r.returncode != 0 and "distinct devices" in r.stderr
+        return
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    pairs = shard.gop_pairs(n, "randomaccess")
+    n_ctu = ((w + 63) // 64) * ((h + 63) // 64)
+    assert d["gpus"] == world and d["pairs"] == len(pairs) and d["pairs_per_device"] == shard.pair_counts(len(pairs), world)
+    assert d["gather_bytes"] == sum(shard.pair_counts(len(pairs), world)[1:]) * n_ctu * 593 * 4 * 4   # four tables of the OTHER ranks' pairs
+    r1 = subprocess.run([os.path.join(host, "me_stream")] + common + ["--out", out_1], capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    tm, t1 = _read_tables(out_m), _read_tables(out_1)
+    assert tm["pairs"] == t1["pairs"] == [list(p) for p in pairs]
+    for k in ("mv", "sad", "qmv", "cost"):
+        assert np.array_equal(tm[k], t1[k]), k
+    lq = oracle_lib.oracle().hmo_lambda_q16(57.9)
+    m = synth.MARGIN
+    for i in (0, 1, len(pairs) - 2, len(pairs) - 1):      # pairs of both / all ranks
+        cur, ref = pairs[i]
+        ox, oy, osad = oracle_lib.search_frame(seq.padded(cur), seq.padded(ref), (m, m), w, h, sr, None, lq, 1, 8, n_threads=16)
+        assert np.array_equal(tm["mv"][i, :, :, 0], ox) and np.array_equal(tm["mv"][i, :, :, 1], oy) and np.array_equal(tm["sad"][i], osad), (i, cur, ref)
+
+
 @pytest.mark.parametrize("w,h,n,sr,bd", [(480, 320, 12, 16, 8), (1920, 1080, 8, 64, 8), (384, 256, 9, 24, 10)])
 def test_fuzz_streaming_configurations_equal_the_resident_run(engine, w, h, n, sr, bd):
     """the streaming pipeline under many shapes -- plane rings from the bare minimum (every refill evicts a plane that was just read) to

@@ -85,9 +85,10 @@ def test_yuv_file_reader_8_and_16_bit(tmp_path, bd, chroma):
         assert int(raw[0]) | int(raw[1]) << 8 == int(seq.luma(0)[0, 0])
 
 
-def test_cpp_sequence_driver_plans_like_the_python_one(tmp_path):
-    """hm-opencl_amd/host/SequenceME.{h,cpp} (the C++ twin of hmme/sequence.py, over the C ABI and the HIP runtime): builds, links
-    and its launch / plane-slot plan keeps the same invariants (tests/cpp/test_sequence_plan.cpp).  No GPU call is made."""
+def test_cpp_sequence_drivers_build_and_keep_the_plan_invariants(tmp_path):
+    """hm-opencl_amd/host/SequenceME.{h,cpp} (the sequence driver over the C ABI and the HIP runtime; its planner is the one
+    hmme/sequence.py binds) and MultiDeviceME.{h,cpp} (N devices from one process, links RCCL): build, link, and the launch / plane-slot
+    plan keeps its invariants (tests/cpp/test_sequence_plan.cpp).  No GPU call is made."""
     import shutil
     import subprocess
     from conftest import ROOT
@@ -97,8 +98,9 @@ def test_cpp_sequence_driver_plans_like_the_python_one(tmp_path):
     subprocess.run(["make", "-s", "-C", csrc], check=True)
     subprocess.run(["make", "-s", "-C", host], check=True)
     exe = str(tmp_path / "test_sequence_plan")
-    subprocess.run(["g++", "-O1", "-std=c++11", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_sequence_plan.cpp"), "-L" + host, "-lhmme_host",
-                    "-L" + csrc, "-lhmme", "-Wl,-rpath," + host, "-Wl,-rpath," + csrc], check=True)
+    subprocess.run(["g++", "-O1", "-std=c++11", "-pthread", "-I/opt/rocm/include", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_sequence_plan.cpp"),
+                    "-L" + host, "-lhmme_multi", "-lhmme_host", "-L" + csrc, "-lhmme", "-Wl,-rpath," + host, "-Wl,-rpath," + csrc,
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
     assert os.path.exists(os.path.join(host, "me_stream"))
@@ -109,3 +111,5 @@ def test_cpp_sequence_driver_plans_like_the_python_one(tmp_path):
         f.write_bytes(bytes(64 * 64 * 3 // 2 * 2))
         r = subprocess.run([os.path.join(host, "me_stream"), "--yuv", str(f), "--size", "64x64", "--frames", "2"], capture_output=True, text=True)
         assert r.returncode == 1 and "hmme_create" in r.stderr
+        r = subprocess.run([os.path.join(host, "me_stream"), "--yuv", str(f), "--size", "64x64", "--frames", "2", "--gpus", "2"], capture_output=True, text=True)
+        assert r.returncode == 1 and "hmme_create on device 0" in r.stderr

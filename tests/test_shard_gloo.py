@@ -48,6 +48,8 @@ def _worker(rank, world, port, q):
         mv, sad = shard.search_sequence(_pair_search(oracle_py, synth), N_PAIRS, 2 * 2, torch.device("cpu"))
         if rank == 0:
             q.put((mv.numpy().copy(), sad.numpy().copy()))
+        else:   # the tables go to rank 0 only: nothing is sent to a rank that does not read them
+            assert mv is None and sad is None
         dist.barrier()
     except Exception as e:  # surface the failure instead of letting the parent time out
         if rank == 0:
@@ -61,6 +63,7 @@ def test_pairs_round_robin():
     from hmme import shard
     assert shard.pairs_for_rank(5, 0, 2) == [0, 2, 4] and shard.pairs_for_rank(5, 1, 2) == [1, 3]
     assert shard.pairs_per_rank(5, 2) == 3 and shard.pairs_per_rank(64, 8) == 8
+    assert shard.pair_counts(5, 2) == [3, 2] and shard.pair_counts(124, 8) == [16] * 4 + [15] * 4 and shard.pair_counts(3, 4) == [1, 1, 1, 0]
     assert sorted(sum((shard.pairs_for_rank(64, r, 8) for r in range(8)), [])) == list(range(64))
 
 
@@ -124,7 +127,8 @@ def _pipeline_worker(rank, world, port, q):
                     time.sleep(0.002)
 
         def consume(k, gathered):
-            seen[k] = gathered.clone()
+            assert (gathered is None) == (rank != 0)      # only rank 0 receives
+            seen[k] = gathered.clone() if gathered is not None else None
 
         for _ in range(N_STEPS):
             pipe.step(launch, consume)
@@ -133,9 +137,15 @@ def _pipeline_worker(rank, world, port, q):
         assert pipe.pending == [None, None]
         ok = sorted(seen) == list(range(N_STEPS))
         for k, g in seen.items():
+            if rank != 0:
+                continue
             ok = ok and tuple(g.shape) == (world,) + SHAPE
             for r in range(world):
                 ok = ok and bool(torch.equal(g[r], _expected_block(r, k)))
+        if rank == 0:   # what rank 1 sent: one block per step, nothing more (round 3's all-gather moved world x that, to every rank)
+            ok = ok and pipe.bytes_received == N_STEPS * 4 * int(np.prod(SHAPE))
+        else:
+            ok = ok and pipe.bytes_received == 0
         q.put((rank, ok, sorted(seen)))
         dist.barrier()
     except Exception as e:
@@ -147,8 +157,8 @@ def _pipeline_worker(rank, world, port, q):
 
 def test_pipelined_gather_two_ranks_gloo():
     """the double-buffered step()/drain() logic of bench.py (hmme/shard.py PipelinedGather) under gloo, world size 2, async
-    collectives: every step's gathered block arrives complete and in order on both ranks although each local buffer is
-    rewritten two steps later"""
+    transfers: every step's gathered block arrives complete and in order on rank 0 -- and only there -- although each local buffer
+    is rewritten two steps later"""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -174,3 +184,54 @@ def test_pipelined_gather_single_process_passthrough():
     pipe.drain(lambda kk, g: seen.append((kk, int(g[0, 0, 0, 0, 0]))))
     assert seen == [(k, k + 1) for k in range(5)]
     assert int(pipe.last_local[0, 0, 0, 0]) == 5
+
+
+# ---- gather_to_root with unequal and empty shares: 2 pairs on 3 ranks (rank 2 has nothing to send) -----------------------------
+def _ragged_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "hm-opencl_amd"))
+    from hmme import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_pairs = 2
+        mine = shard.pairs_for_rank(n_pairs, rank, world)
+        mv = torch.zeros((len(mine), 3, 593, 2), dtype=torch.int16)
+        sad = torch.zeros((len(mine), 3, 593), dtype=torch.int32)
+        for i, p in enumerate(mine):
+            mv[i] = 100 * p + 7
+            mv[i, :, :, 1] = -(100 * p + 7)
+            sad[i] = 1000 + p
+        g_mv, g_sad = shard.gather_pair_results(mv, sad, n_pairs)
+        if rank == 0:
+            ok = tuple(g_mv.shape) == (2, 3, 593, 2) and tuple(g_sad.shape) == (2, 3, 593)
+            for p in range(n_pairs):
+                ok = ok and bool((g_mv[p, :, :, 0] == 100 * p + 7).all()) and bool((g_mv[p, :, :, 1] == -(100 * p + 7)).all()) and bool((g_sad[p] == 1000 + p).all())
+            _, _, got = shard.gather_to_root(sad, shard.pair_counts(n_pairs, world))
+            q.put((ok, got))
+        else:
+            assert g_mv is None
+            shard.gather_to_root(sad, shard.pair_counts(n_pairs, world))
+        dist.barrier()
+    except Exception as e:
+        if rank == 0:
+            q.put(repr(e))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_to_root_with_unequal_and_empty_shares_three_ranks_gloo():
+    """124 pairs on 8 ranks are 16 / 15 per rank; the extreme of that: 2 pairs on 3 ranks (1, 1, 0).  Rank 0 receives exactly the
+    tables that exist -- no zero tables pad a short rank, nothing is sent to ranks 1 and 2"""
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == (True, 1 * 3 * 593 * 4), got     # one table from rank 1, none from rank 2

@@ -7,6 +7,10 @@ HERE=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$HERE/hm-opencl_amd/csrc/build/variants
 mkdir -p $OUT
 cd $OUT
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value "$@" -c $HERE/hm-opencl_amd/csrc/hmme.hip -o hmme_$TAG.o
+# the same build id recipe as hm-opencl_amd/csrc/Makefile (sources + arch + the variant's flags): hmme_build_id() of a variant is its own,
+# so that a counter summary taken on a variant can never pass for the default library's (bench.py pmc_profile)
+C=$HERE/hm-opencl_amd/csrc
+ID=$( (cat $C/hmme.hip $C/me_kernels.hpp $C/me_tree_fen0.inc $C/me_tree_fen1.inc $C/me_tree16_fen0.inc $C/me_tree16_fen1.inc $C/me_slotmap.inc; echo "gfx950 $*") | sha256sum | cut -c1-16)
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value "$@" -DHMME_BUILD_ID=\"$ID\" -c $HERE/hm-opencl_amd/csrc/hmme.hip -o hmme_$TAG.o
 hipcc --offload-arch=gfx950 -shared -fPIC -o libhmme_$TAG.so hmme_$TAG.o
 echo $OUT/libhmme_$TAG.so

@@ -6,8 +6,8 @@
         tools/me_sequence.py --frames 64 --gop randomaccess --size 2160p [--yuv file.yuv] [--bit-depth 10]
                              [--stream] [--pairs-per-launch K] [--refine] [--download] [--dump out.npz]
 
-Rank r searches pairs r, r+N, ... (hmme/shard.py); the 593-entry tables of all pairs are gathered with one RCCL all-gather per
-table.  Default: every picture the rank needs is resident in HBM before the clock starts (a 64-picture 2160p sequence is 0.6 GB
+Rank r searches pairs r, r+N, ... (hmme/shard.py); the 593-entry tables of all pairs are gathered to rank 0 over RCCL (grouped
+send / receive, one batch per table).  Default: every picture the rank needs is resident in HBM before the clock starts (a 64-picture 2160p sequence is 0.6 GB
 of the 288 GB).  --stream: pictures come from the file (or the generator) through a ring of plane slots while the GPU searches
 (hmme/sequence.py): reader thread -> page-locked buffers -> copy stream || compute stream || download stream; the clock then
 includes reading and uploading.  --pairs-per-launch K puts K picture pairs into one launch (small pictures do not fill the
@@ -80,24 +80,13 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    # the one exchange step: every rank's tables to every rank, in pair order (ranks with one pair fewer pad)
-    k = shard.pairs_per_rank(len(pairs), world)
-
-    def padded(t):
-        if t.shape[0] == k:
-            return t
-        return torch.cat([t, torch.zeros((k - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)])
-
+    # the one exchange step: every rank's tables to rank 0, which puts them into pair order (hmme/shard.py gather_to_root: grouped
+    # point-to-point transfers; a rank with one pair fewer simply sends one table fewer)
     import time
     t0 = time.perf_counter()
-    if use_dist:
-        mv, sad = shard.gather_pair_results(padded(res["mv"]), padded(res["sad"]), len(pairs))
-        if args.refine:
-            qmv, cost = shard.gather_pair_results(padded(res["qmv"]), padded(res["cost"]), len(pairs))
-    else:
-        mv, sad = res["mv"], res["sad"]
-        if args.refine:
-            qmv, cost = res["qmv"], res["cost"]
+    mv, sad = shard.gather_pair_results(res["mv"], res["sad"], len(pairs))
+    if args.refine:
+        qmv, cost = shard.gather_pair_results(res["qmv"], res["cost"], len(pairs))
     torch.cuda.synchronize()
     gather_s = time.perf_counter() - t0
     if rank == 0:
@@ -114,7 +103,8 @@ def main():
                           "gsad_per_s": round(len(pairs) * sads / total / 1e9, 1),
                           "mode": {"stream": bool(args.stream), "pairs_per_launch": args.pairs_per_launch, "refine": bool(args.refine),
                                    "download": bool(args.download), "bit_depth": bd, "source": args.yuv or "synthetic",
-                                   "collective": "all_gather_into_tensor (nccl), world %d" % world if use_dist else "none (one rank)"},
+                                   "collective": "gather to rank 0: grouped send/recv (nccl), world %d" % world if use_dist else "none (one rank)",
+                                   "pairs_per_rank": shard.pair_counts(len(pairs), world)},
                           "size": [w, h], "search_range": args.search_range,
                           "rank0": {"pairs": len(mine), "launches": res["launches"], "plane_slots": res["plane_slots"], "uploads": res["uploads"],
                                     "stages": res["stages"]},
