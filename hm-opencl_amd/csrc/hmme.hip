@@ -1,6 +1,7 @@
 // hmme.hip -- host side of the C ABI declared in include/hmme.h (see that header for the
 // reference interface each entry point replaces).  Plain HIP runtime; no OpenCL, no fallback path.
 #include "../../include/hmme.h"
+#include "../../include/hmme_test.h"
 
 #include <hip/hip_runtime.h>
 
@@ -542,7 +543,7 @@ int hmme_slot_rect(int slot, int* x, int* y, int* w, int* h) {
 // ---- per-CTU drop-in ---------------------------------------------------------------------------------
 namespace {
 int build_frac_cover(hmme_ctx* ctx);
-using frac_fn = void (*)(const RefSet, int, const RefSet, int, const MeJob*, int, const uint16_t*, const int16_t*, uint32_t, int, int16_t*, uint32_t*);
+using frac_fn = void (*)(const RefSet, int, const RefSet, int, const MeJob*, int, uint32_t*, const uint16_t*, const int16_t*, uint32_t, int, int16_t*, uint32_t*);
 inline frac_fn frac_kernel(int wide, int had) {
   static const frac_fn fns[2][2] = {{hmme::me_frac_kernel<0, 1>, hmme::me_frac_kernel<1, 1>}, {hmme::me_frac_kernel<0, 2>, hmme::me_frac_kernel<1, 2>}};
   return fns[wide ? 1 : 0][had ? 1 : 0];
@@ -583,9 +584,12 @@ inline void row_pack16(const int16_t* __restrict__ s, int n, int bias, uint16_t*
 // One (CTU, reference) call: search (out_mv / out_sad), refinement of the winners or of the caller's integer MVs
 // (refine_had >= 0: out_qmv / out_cost), or both.  With refinement the staged window carries a halo of kRefineHalo samples.
 int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref0, int ref_stride, const hmme_search_params* p,
-             bool do_search, const int16_t* int_mv, int refine_had, int16_t* out_mv, uint32_t* out_sad, int16_t* out_qmv, uint32_t* out_cost) {
+             bool do_search, const int16_t* int_mv, int refine_had, int16_t* out_mv, uint32_t* out_sad, int16_t* out_qmv, uint32_t* out_cost,
+             const hmme_weight* wp = nullptr) {
   if (!ctx) return HMME_ERR_ARG;
   const bool refine = refine_had >= 0;
+  if (wp && (!do_search || refine)) return fail(ctx, HMME_ERR_UNSUPPORTED, "weighted prediction: integer search only (the refinement prices xGetHADsw, not built)");
+  if (wp && (wp->shift < 0 || wp->shift > 15)) return fail(ctx, HMME_ERR_ARG, "weighted prediction: shift %d outside 0..15", wp->shift);
   if (!ctu || !ref0 || !p || (do_search && (!out_mv || !out_sad)) || (refine && (!out_qmv || !out_cost)) || (!do_search && !int_mv))
     return fail(ctx, HMME_ERR_ARG, "hmme_search_ctu: null argument");
   const int halo = refine ? kRefineHalo : 0;
@@ -607,8 +611,8 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
   const bool bipred_origin = lo < 0 || hi > maxv;
   if (lo < -maxv || hi > 2 * maxv)
     return fail(ctx, HMME_ERR_RANGE, "hmme_search_ctu: current-block sample outside [%d, %d] (bit depth %d)", -maxv, 2 * maxv, p->bit_depth);
-  const bool wide = p->bit_depth > 8 || bipred_origin;
-  const int bias = bipred_origin ? (1 << p->bit_depth) : 0;
+  const bool wide = p->bit_depth > 8 || bipred_origin || wp;
+  int bias = bipred_origin ? (1 << p->bit_depth) : 0;
   // xPatternSearchFracDIF on 2*org - pred_other (the bBi pass, TEncSearch.cpp:3798 with bBi): the refinement kernel runs on the same
   // biased u16 staging as the search; the bias passes HM's interpolation exactly and shifts its clip bounds (me_frac_eval)
   const int shift_bd = p->shift_free ? 8 : p->bit_depth;   // the kernels shift by (this - 8)
@@ -624,6 +628,20 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
   const int rows = wy + 63 + 2 * halo, cols = wx + 63 + 2 * halo;
   const int16_t* src = ref0 + (long)(p->lt_y - halo) * ref_stride + (p->lt_x - halo);
   int vlo = 32767, vhi = -32768;
+  if (wp)   // the window goes up as it is and is weighted on the device; block and weighted window share a bias chosen below
+    for (int y = 0; y < rows; ++y) row_minmax(src + (long)y * ref_stride, cols, vlo, vhi);
+  long wlo = 0, whi = 0;   // range of the weighted window
+  if (wp) {
+    if (vlo < 0 || vhi > maxv) return fail(ctx, HMME_ERR_RANGE, "hmme_search_ctu: reference sample outside [0,%d] for bit depth %d", maxv, p->bit_depth);
+    const long a = (((long)wp->w0 * vlo + wp->round) >> wp->shift) + wp->offset, b = (((long)wp->w0 * vhi + wp->round) >> wp->shift) + wp->offset;
+    wlo = std::min(a, b); whi = std::max(a, b);
+    // HM keeps the weighted sample in a Pel (`const Pel pred`, TComRdCostWeightPrediction.cpp:79): beyond int16 its arithmetic wraps,
+    // which nothing here reproduces -- such a call goes back to the caller
+    if (wlo < -32768 || whi > 32767) return fail(ctx, HMME_ERR_UNSUPPORTED, "weighted prediction reaches %ld..%ld, beyond a Pel", wlo, whi);
+    const long low = std::min<long>(wlo, lo);
+    bias = low < 0 ? (int)-low : 0;
+    if (std::max<long>(whi, hi) + bias > 65535) return fail(ctx, HMME_ERR_UNSUPPORTED, "weighted prediction: samples span more than 16 bits");
+  }
   for (int y = 0; y < 64; ++y) {
     if (wide) row_pack16(ctu + (long)y * ctu_stride, 64, bias, (uint16_t*)h_ctu + y * 64);
     else row_pack8(ctu + (long)y * ctu_stride, 64, h_ctu + y * 64);
@@ -631,12 +649,17 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
   for (int y = 0; y < rows; ++y) {
     uint8_t* row = h_win + (size_t)y * kWinPitch;
     const int16_t* srow = src + (long)y * ref_stride;
-    row_minmax(srow, cols, vlo, vhi);
-    if (wide) row_pack16(srow, cols, bias, (uint16_t*)row);
+    if (!wp) row_minmax(srow, cols, vlo, vhi);
+    if (wide) row_pack16(srow, cols, wp ? 0 : bias, (uint16_t*)row);
     else row_pack8(srow, cols, row);
     std::memset(row + cols * bps, 0, 16);   // the kernels stage whole dwords past the last sample
   }
   if (vlo < 0 || vhi > maxv) return fail(ctx, HMME_ERR_RANGE, "hmme_search_ctu: reference sample outside [0,%d] for bit depth %d", maxv, p->bit_depth);
+  if (wp) {   // the sums of a weighted search must fit the cost field like any other (the weighted window may be far from the block)
+    const long span = std::max<long>((long)hi - wlo, whi - (long)lo);
+    if (((4096 * span) >> (shift_bd - 8)) + 65535 >= (long)hmme::kInvCost16)
+      return fail(ctx, HMME_ERR_UNSUPPORTED, "weighted SADs of this block could reach %ld: beyond the cost field", 4096 * span);
+  }
   // unshifted sums must fit the 24-bit cost field of the 16-bit kernel's keys (me_kernels.hpp kInvCost16).  The bound is taken
   // from the samples of THIS call (both scans are made anyway): no |cur - ref| exceeds max(hi - vlo, vhi - lo), so any content whose
   // 64x64 sum cannot reach the marker is searched, whatever the nominal bit depth says (10-bit bi-prediction origins nominally
@@ -693,6 +716,11 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
     const int n16 = (int)((kCallWin + (size_t)rows * kWinPitch + 64 + 15) / 16);
     hipLaunchKernelGGL(hmme::me_stage_call_kernel, dim3((n16 + 255) / 256), dim3(256), 0, s, (const uint4*)ctx->h_call_dev, (uint4*)ctx->d_call, n16);
     HIP_TRY(ctx, hipGetLastError());
+    if (wp) {
+      hipLaunchKernelGGL(hmme::me_weight_window_kernel, dim3((rows * cols + 255) / 256), dim3(256), 0, s, ctx->d_call + kCallWin, (int)kWinPitch, rows, cols,
+                         wp->w0, wp->round, wp->shift, wp->offset + bias);
+      HIP_TRY(ctx, hipGetLastError());
+    }
   }
   // the kernel addresses ref(ctu + lt): bias the base so that (lt_x, lt_y) lands on the window copy's first sample
   const uint8_t* ref_base = ctx->d_call + kCallWin - (long)(p->lt_y - halo) * kWinPitch - (long)(p->lt_x - halo) * bps;
@@ -708,7 +736,7 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
   if (!wide)
     rc = launch_search8_split(ctx, one_ref(ctx->d_call + kCallCtu), 64, one_ref(ref_base), kWinPitch, d_js, d_first, 1, n_wg, p->fen, d_mv1, d_sad1, s, d_best1, false);
   else
-    rc = launch_search16(ctx, one_ref(ctx->d_call + kCallCtu), 128, one_ref(ref_base), kWinPitch, d_js, d_first, 1, n_wg, pdw, smax, p->fen, shift_bd,
+    rc = launch_search16(ctx, one_ref(ctx->d_call + kCallCtu), 128, one_ref(ref_base), kWinPitch, d_js, d_first, 1, n_wg, pdw, smax, wp ? 0 : p->fen, shift_bd,   // xGetSADw reads every row
                          d_mv1, d_sad1, s, d_best1, false);
   if (rc) return rc;
   hipLaunchKernelGGL(hmme::me_finalize1_kernel, dim3(1), dim3(640), 0, s, d_best1, d_js, ctx->lambda_q16, d_mv1, d_sad1,
@@ -722,7 +750,7 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
     if (rc) return rc;
     const int16_t* d_imv = do_search ? d_mv1 : (const int16_t*)(ctx->d_call + kCallImv);
     hipLaunchKernelGGL(frac_kernel(wide ? 1 : 0, refine_had ? 1 : 0), dim3(1), dim3(hmme::frac_threads(bps)), hmme::frac_lds_bytes(bps), s, one_ref(ctx->d_call + kCallCtu),
-                       64 * bps, one_ref(ref_base), kWinPitch, (const MeJob*)(ctx->d_call + kCallFracJob), 1, ctx->d_frac_cover, d_imv, ctx->lambda_q16,
+                       64 * bps, one_ref(ref_base), kWinPitch, (const MeJob*)(ctx->d_call + kCallFracJob), 1, (uint32_t*)nullptr, ctx->d_frac_cover, d_imv, ctx->lambda_q16,
                        p->bit_depth | (bipred_origin ? 0x100 : 0), (int16_t*)(ctx->d_res + kResQmv), (uint32_t*)(ctx->d_res + kResCost));
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(hmme::me_publish_kernel, dim3(1), dim3(1), 0, s, (volatile uint32_t*)(ctx->d_res + kResDone2), seq);
@@ -750,6 +778,12 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
 int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref0, int ref_stride,
                     const hmme_search_params* p, int16_t* out_mv, uint32_t* out_sad) {
   return ctu_call(ctx, ctu, ctu_stride, ref0, ref_stride, p, true, nullptr, -1, out_mv, out_sad, nullptr, nullptr);
+}
+
+int hmme_search_ctu_w(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref0, int ref_stride,
+                      const hmme_search_params* p, const hmme_weight* wp, int16_t* out_mv, uint32_t* out_sad) {
+  if (ctx && !wp) return fail(ctx, HMME_ERR_ARG, "hmme_search_ctu_w: null weight");
+  return ctu_call(ctx, ctu, ctu_stride, ref0, ref_stride, p, true, nullptr, -1, out_mv, out_sad, nullptr, nullptr, wp);
 }
 
 int hmme_search_refine_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref0, int ref_stride, const hmme_search_params* p,
@@ -820,7 +854,7 @@ int hmme_upload_status(hmme_ctx* ctx, void* stream) {
   return fail(ctx, HMME_ERR_RANGE, "an asynchronous plane upload carried a sample outside the range of its plane's bit depth");
 }
 
-uint64_t hmme_debug_device_address(const hmme_ctx* ctx, const hmme_plane* pl) {
+uint64_t hmme_test_device_address(const hmme_ctx* ctx, const hmme_plane* pl) {
   if (pl) return (uint64_t)(uintptr_t)pl->origin();
   return ctx ? (uint64_t)(uintptr_t)(ctx->d_call + kCallCtu) : 0;
 }
@@ -967,7 +1001,7 @@ static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_para
   else {
     if (head)
       hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, grid(head), block, 0, s, (MeJob*)ctx->d_jobs, (const int16_t*)d_pred_q, first, count,
-                         n_refs, cur->width, cur->height, fp->search_range, 0, head, 1);
+                         n_refs, cur->width, cur->height, fp->search_range, 0, head, 1, (uint32_t*)nullptr);
     if (n_tail)
       hipLaunchKernelGGL(hmme::me_prep_jobs_split_kernel, grid(n_tail), block, 0, s, (MeJob16*)((uint8_t*)ctx->d_jobs + pl->tail_jobs_off), ctx->d_first_strip,
                          (const int16_t*)d_pred_q, first, count, n_refs, cur->width, cur->height, fp->search_range, pl->tail_parts, head, n_tail);
@@ -1143,15 +1177,18 @@ int hmme_refine_pairs_device(hmme_ctx* ctx, const hmme_plane* const* curs, const
   rc = build_frac_cover(ctx);
   if (rc == HMME_OK) {
     size_t cap = ctx->jobs_bytes;
-    rc = ensure(ctx, (uint8_t**)&ctx->d_jobs, &cap, sizeof(MeJob) * (size_t)jobs);
+    rc = ensure(ctx, (uint8_t**)&ctx->d_jobs, &cap, sizeof(MeJob) * (size_t)jobs + 64);   // + the launch's job counter behind the table
     ctx->jobs_bytes = cap;
   }
   if (rc == HMME_OK) {
+    uint32_t* counter = (uint32_t*)((uint8_t*)ctx->d_jobs + ((sizeof(MeJob) * (size_t)jobs + 15) & ~(size_t)15));
     hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, dim3((jobs + 255) / 256), dim3(256), 0, s, (MeJob*)ctx->d_jobs, (const int16_t*)d_pred_q,
-                       pl.first, pl.count, n_pairs, curs[0]->width, curs[0]->height, fp->search_range, 0, jobs, 0);
+                       pl.first, pl.count, n_pairs, curs[0]->width, curs[0]->height, fp->search_range, 0, jobs, 0, counter);
     const int had = use_hadamard ? 1 : 0, wide = curs[0]->bps == 2 ? 1 : 0;
-    hipLaunchKernelGGL(frac_kernel(wide, had), dim3(frac_grid(ctx, wide, had, jobs)), dim3(hmme::frac_threads(wide ? 2 : 1)), hmme::frac_lds_bytes(wide ? 2 : 1), s, pl.curs,
-                       curs[0]->pitch, pl.refs, refs[0]->pitch, (const MeJob*)ctx->d_jobs, jobs, ctx->d_frac_cover, (const int16_t*)d_int_mv, ctx->lambda_q16,
+    const int grid = frac_grid(ctx, wide, had, jobs);
+    hipLaunchKernelGGL(frac_kernel(wide, had), dim3(grid), dim3(hmme::frac_threads(wide ? 2 : 1)), hmme::frac_lds_bytes(wide ? 2 : 1), s, pl.curs,
+                       curs[0]->pitch, pl.refs, refs[0]->pitch, (const MeJob*)ctx->d_jobs, jobs, grid < jobs ? counter : (uint32_t*)nullptr, ctx->d_frac_cover,
+                       (const int16_t*)d_int_mv, ctx->lambda_q16,
                        fp->bit_depth, (int16_t*)d_out_qmv, (uint32_t*)d_out_cost);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) rc = fail(ctx, HMME_ERR_DEVICE, "refinement launch -> %s", hipGetErrorString(e));
@@ -1202,12 +1239,12 @@ int hmme_refine_frame(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* re
   return HMME_OK;
 }
 
-int hmme_time_search_kernel(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp,
+int hmme_test_time_search_kernel(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp,
                             const void* d_pred_q, void* d_out_mv, void* d_out_sad, void* stream, int reps, float* avg_ms) {
   int first, count;
   int rc = check_frame_args(ctx, cur, ref, fp, &first, &count);
   if (rc) return rc;
-  if (!avg_ms || reps < 1) return fail(ctx, HMME_ERR_ARG, "hmme_time_search_kernel: bad reps/avg_ms");
+  if (!avg_ms || reps < 1) return fail(ctx, HMME_ERR_ARG, "hmme_test_time_search_kernel: bad reps/avg_ms");
   hipStream_t s = (hipStream_t)stream;
   PairLaunch pl;
   rc = pairs_begin(ctx, &cur, &ref, 1, fp, s, &pl);

@@ -516,9 +516,11 @@ __host__ __device__ inline void set_search_range(int pred_x, int pred_y, int sr,
 // jobs [job0, job0 + n_jobs) of the ctu_count * n_refs (CTU, reference) searches of a launch; jobs[] is indexed from job0
 // xcd_order: jobs[] is written in the XCD-aware order of me_search_kernel<FEN, 0> (position li holds job job0 + me_xcd_unit(li, n_jobs));
 // 0 for the refinement kernel, which takes job blockIdx.x
+// job_counter (may be null): the refinement kernel's work counter, reset here for the launch that follows on the same stream
 __global__ void me_prep_jobs_kernel(MeJob* jobs, const int16_t* __restrict__ pred_q, int ctu_first, int ctu_count,
-                                    int n_refs, int pic_w, int pic_h, int sr, int job0, int n_jobs, int xcd_order) {
+                                    int n_refs, int pic_w, int pic_h, int sr, int job0, int n_jobs, int xcd_order, uint32_t* job_counter) {
   const int li = blockIdx.x * blockDim.x + threadIdx.x;
+  if (li == 0 && job_counter) *job_counter = 0;
   if (li >= n_jobs) return;
   const int i = job0 + (xcd_order ? me_xcd_unit(li, n_jobs) : li);
   const int r = i / ctu_count;
@@ -733,6 +735,19 @@ __global__ void me_stage_call_kernel(const uint4* __restrict__ host_block, uint4
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n16) dev_block[i] = host_block[i];
 }
+// explicit weighted prediction (TEncSearch::setWpScalingDistParam, TEncSearch.cpp:5594-5635): the search of a slice with weighted
+// prediction prices |org - (((w0 * ref + round) >> shift) + offset)| (TComRdCostWeightPrediction::xGetSADw,
+// TComRdCostWeightPrediction.cpp:79-81).  The prediction of a sample does not depend on the candidate, so the staged window of a
+// per-CTU call is weighted ONCE, in place (u16 samples, `bias` added so that block and window stay unsigned), and the 16-bit search
+// kernel runs on it unchanged.
+__global__ void me_weight_window_kernel(uint8_t* __restrict__ win, int pitch, int rows, int cols, int w0, int round, int shift, int offset_bias) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int y = i / cols, x = i - y * cols;
+  uint16_t* p = (uint16_t*)(win + (long)y * pitch) + x;
+  *p = (uint16_t)(((w0 * (int)*p + round) >> shift) + offset_bias);
+}
+
 // single-job finalize (one workgroup) that writes the results straight into mapped pinned host memory and then publishes a
 // sequence number there: the host polls that word instead of sleeping in hipStreamSynchronize
 __global__ void __launch_bounds__(640)
@@ -922,14 +937,17 @@ __device__ __forceinline__ float me_dpp_f(float v, const int ctrl_b1) {
 
 // distortion of one 4x4 difference block d (row-major): SAD, or the Hadamard sum (xCalcHADs4x4; with KIND8 the quad's four 4x4
 // transforms are combined into the 8x8 transform, xCalcHADs8x8, and all four lanes return the block's value)
+// want4 (wave-uniform, KIND8 only): also return in `own4` what this lane's 4x4 block alone contributes to a slot made of 4x4 blocks
+// (the AMP shapes, 8x4, 4x8) -- the same difference block, the same 4x4 transform, only the 8x8 combination left out
 template <int HAD, int KIND8>
-__device__ __forceinline__ uint32_t me_frac_dist(const float (&d)[16], float s1, float s2) {
+__device__ __forceinline__ uint32_t me_frac_dist(const float (&d)[16], float s1, float s2, bool want4, uint32_t& own4) {
   uint32_t contrib;
   if (!HAD) {
     float sad = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) sad += __builtin_fabsf(d[i]);
     if (KIND8) {   // the quad's four 4x4 SADs belong to the same slots: hand out their sum
+      own4 = (uint32_t)sad;
       sad += me_dpp_f(sad, 1);
       sad += me_dpp_f(sad, 0);
     }
@@ -949,6 +967,12 @@ __device__ __forceinline__ uint32_t me_frac_dist(const float (&d)[16], float s1,
     }
     float sum = 0.f;
     if (KIND8) {   // combine the quad's four 4x4 transforms into the 8x8 transform (xCalcHADs8x8)
+      if (want4) {   // xCalcHADs4x4 of this block, as the 4x4 kind computes it
+        float s4 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s4 += __builtin_fabsf(z[i]);
+        own4 = ((uint32_t)s4 + 1) >> 1;
+      }
       // two butterflies across the quad, each one v_fmac_f32 with a DPP source: z += t * z[neighbour], t = +-1 by
       // role.  Odd roles hold the negated difference, which the absolute sum does not see.  One asm block keeps
       // 16 instructions between a register's write and its DPP read (the hazard the assembler does not pad for).
@@ -992,7 +1016,7 @@ constexpr float kRoundMagic = 12582912.0f;   // 1.5 * 2^23: x + magic rounds x t
 // return the block's distortion.  out[point]: distortion of the 9 refinement points in HM's point order.
 template <int STAGE, int HAD, int BPS, int KIND8>
 __device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3 * BPS], const float (&orgM)[16], int cqx, int cqy, int role, int bd, float clip_lo,
-                                             const uint32_t* tab_h, const float* tab_v, uint32_t (&out)[9]) {
+                                             const uint32_t* tab_h, const float* tab_v, bool want4, uint32_t (&out)[9], uint32_t (&out4)[9]) {
   constexpr int step = STAGE == 0 ? 2 : 1, PW = 3 * BPS;
   // point index of (dx, dy) in s_acMvRefineH / s_acMvRefineQ order (reference TEncSearch.cpp:51-75)
   constexpr int idxH[3][3] = {{5, 1, 6}, {3, 0, 4}, {7, 2, 8}}, idxQ[3][3] = {{3, 1, 4}, {5, 0, 6}, {7, 2, 8}};   // [dy+1][dx+1]
@@ -1063,7 +1087,7 @@ __device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3 * BPS], c
     for (int dyi = 0; dyi < 3; ++dyi) {
       // the centre of the quarter-pel stage IS the half-pel stage's winning point: same position, same interpolated samples, same
       // distortion -- HM evaluates it again (TEncSearch.cpp:4324-4331), here the slot's winner thread carries the sum over
-      if (STAGE == 1 && dxi == 1 && dyi == 1) { out[0] = 0; continue; }
+      if (STAGE == 1 && dxi == 1 && dyi == 1) { out[0] = 0; out4[0] = 0; continue; }
       float cv[9];   // taps * 2^-sh2 (exact): the accumulator is the sample value with its fraction
 #pragma unroll
       for (int j = 0; j < 9; ++j)
@@ -1082,8 +1106,10 @@ __device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3 * BPS], c
           const float y = __builtin_amdgcn_fmed3f(a, clip_lo, maxv);   // clip, then round (the bounds are integers)
           d[4 * r + c] = orgM[4 * r + c] - (y + kRoundMagic);
         }
-      const uint32_t contrib = me_frac_dist<HAD, KIND8>(d, s1, s2);
+      uint32_t own4 = 0;
+      const uint32_t contrib = me_frac_dist<HAD, KIND8>(d, s1, s2, want4, own4);
       out[STAGE == 0 ? idxH[dyi][dxi] : idxQ[dyi][dxi]] = contrib;
+      out4[STAGE == 0 ? idxH[dyi][dxi] : idxQ[dyi][dxi]] = own4;
     }
   }
 }
@@ -1110,7 +1136,7 @@ constexpr uint32_t kFracKey0 = 0x3ffffu, kFracKey1 = 0x3fffffu;
 // me_frac_eval<0, ...> bit for bit: every intermediate is exact in fp32 (me_frac_eval's header), so the order of summation is free.
 template <int HAD, int BPS, int KIND8>
 __device__ __forceinline__ void me_frac_eval0(const uint32_t (&P)[12][3 * BPS], const float (&orgM)[16], int role, int bd, float clip_lo,
-                                              uint32_t (&out)[9]) {
+                                              bool want4, uint32_t (&out)[9], uint32_t (&out4)[9]) {
   constexpr int PW = 3 * BPS;
   constexpr int idxH[3][3] = {{5, 1, 6}, {3, 0, 4}, {7, 2, 8}};   // [dy+1][dx+1], s_acMvRefineH order (TEncSearch.cpp:51-75)
   const float s1 = (role & 1) ? -1.f : 1.f, s2 = (role & 2) ? -1.f : 1.f;
@@ -1145,7 +1171,9 @@ __device__ __forceinline__ void me_frac_eval0(const uint32_t (&P)[12][3 * BPS], 
     float d[16];                                                                             \
     _Pragma("unroll") for (int r = 0; r < 4; ++r)                                            \
       _Pragma("unroll") for (int c = 0; c < 4; ++c) d[4 * r + c] = orgM[4 * r + c] - Y[(R0) + r][(C0) + c]; \
-    out[idxH[DYI][DXI]] = me_frac_dist<HAD, KIND8>(d, s1, s2);                               \
+    uint32_t own4 = 0;                                                                       \
+    out[idxH[DYI][DXI]] = me_frac_dist<HAD, KIND8>(d, s1, s2, want4, own4);                  \
+    out4[idxH[DYI][DXI]] = own4;                                                             \
   }
   // ---- half-pel columns: HH[r][k] = horizontal half-pel sample left of column k (k = 0..3) / right of column 3 (k = 4)
   {
@@ -1260,13 +1288,33 @@ __device__ __forceinline__ void me_frac_compute(const FracRaw<BPS>& R, const uin
       orgM[4 * r + 2] = (float)(w.y & 0xffff) + kRoundMagic; orgM[4 * r + 3] = (float)(w.y >> 16) + kRoundMagic;
     }
   }
-  uint32_t dist[9];
+  uint32_t dist[9], dist4[9];
   const int cqx = STAGE ? 2 * ((int)((sv >> 18) & 3) - 1) : 0, cqy = STAGE ? 2 * ((int)((sv >> 20) & 3) - 1) : 0;
+  // Slots made of 4x4 blocks (the AMP shapes at 16, 8x4, 4x8: six per 4x4 position) whose key equals this item's get this lane's 4x4
+  // block for nothing: same patch, same interpolated samples, same difference, same 4x4 transform -- the work-list pass left such
+  // (4x4 position, key) pairs out of the 4x4 list (me_frac_dedupe4).  On coherent content that is every one of them.
+  uint32_t match4 = 0;
+  const uint16_t* cov4 = cover + kFracPairs8 + (by * 16 + bx) * kFracCover4;
+  if (KIND8) {
+#pragma unroll
+    for (int k = 0; k < kFracCover4; ++k) match4 |= (((st[cov4[k]] ^ sv) & keymask) == 0 ? 1u : 0u) << k;
+  }
+  const bool want4 = KIND8 && __any(match4 != 0);
 #ifndef ME_FRAC_STAGE0_PLAIN
-  if constexpr (STAGE == 0) me_frac_eval0<HAD, BPS, KIND8>(P, orgM, role, bd, clip_lo, dist);
+  if constexpr (STAGE == 0) me_frac_eval0<HAD, BPS, KIND8>(P, orgM, role, bd, clip_lo, want4, dist, dist4);
   else
 #endif
-    me_frac_eval<STAGE, HAD, BPS, KIND8>(P, orgM, cqx, cqy, role, bd, clip_lo, tab_h, tab_v, dist);
+    me_frac_eval<STAGE, HAD, BPS, KIND8>(P, orgM, cqx, cqy, role, bd, clip_lo, tab_h, tab_v, want4, dist, dist4);
+#ifndef ME_FRAC_T_NOATOMICS   // timing-only builds (tools/r04_frac_breakdown.sh; results are wrong by design): ME_FRAC_T_NOATOMICS, ME_FRAC_T_NOITEMS
+  if (KIND8 && want4) {
+#pragma unroll
+    for (int k = 0; k < kFracCover4; ++k)
+      if (match4 >> k & 1) {
+        const int s4 = cov4[k];
+#pragma unroll
+        for (int i = STAGE; i < 9; ++i) atomicAdd(&acc[s4 * kFracAccRow + i], dist4[i]);
+      }
+  }
   // Every slot of this position with the same key takes the distortions; the quad's lanes split the slot list.
   // (Round 3 tried to relieve these adds -- the large slots cover many positions, so lanes of one wave often add to the same address:
   // each quad starting its walk at another list position and two points per ds_add_u64 cut the kernel's LDS conflict cycles by 27 %
@@ -1278,6 +1326,14 @@ __device__ __forceinline__ void me_frac_compute(const FracRaw<BPS>& R, const uin
       for (int i = STAGE; i < 9; ++i) atomicAdd(&acc[s2 * kFracAccRow + i], dist[i]);   // stage 1: point 0 is carried over, not evaluated
     }
   }
+#else   // every distortion still computed, ONE atomic per item: the difference to the product build is what the accumulation costs
+  {
+    uint32_t t = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) t += dist[i] + (KIND8 ? dist4[i] & match4 : 0u);
+    atomicAdd(&acc[(cov[j] * kFracAccRow + (t & 7)) % kFracAcc], t);
+  }
+#endif
 }
 
 // software-pipelined walk over a lane's items of one stage: kind-8 items (whole quads), then kind-4 items; the patch rows of the next
@@ -1349,11 +1405,37 @@ __device__ __forceinline__ void me_frac_dedupe(const uint32_t* st, const uint16_
   }
 }
 
+// the 4x4 kind: a (4x4 position, key) pair is listed only if no slot of the 8x8 kind covers the position with the same key -- otherwise the
+// lane of that 8x8 item that owns this 4x4 block hands its result to the 4x4-kind slots as well (me_frac_compute)
+__device__ __forceinline__ void me_frac_dedupe4(const uint32_t* st, const uint16_t* cover, int p4, uint32_t keymask, uint32_t* counter, uint16_t* list) {
+  const uint16_t* cov = cover + kFracPairs8 + p4 * kFracCover4;
+  const uint16_t* cov8 = cover + (((p4 >> 4) >> 1) * 8 + ((p4 & 15) >> 1)) * kFracCover8;   // the 8x8 position that holds block (p4 & 15, p4 >> 4)
+  uint32_t key[kFracCover4];
+  bool first[kFracCover4];
+#pragma unroll
+  for (int j = 0; j < kFracCover4; ++j) {
+    key[j] = st[cov[j]] & keymask;
+    first[j] = true;
+#pragma unroll
+    for (int k = 0; k < j; ++k) first[j] = first[j] && key[k] != key[j];
+  }
+#pragma unroll
+  for (int k = 0; k < kFracCover8; ++k) {
+    const uint32_t k8 = st[cov8[k]] & keymask;
+#pragma unroll
+    for (int j = 0; j < kFracCover4; ++j) first[j] = first[j] && key[j] != k8;
+  }
+#pragma unroll
+  for (int j = 0; j < kFracCover4; ++j)
+    if (first[j]) list[atomicAdd(counter, 1u)] = (uint16_t)(kFracPairs8 + p4 * kFracCover4 + j);
+}
+
 template <int HAD, int BPS>
 __global__ void __launch_bounds__(frac_threads(BPS), BPS == 1 ? ME_FRAC_WAVES8 : 2)
 me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitch,
-               const MeJob* __restrict__ jobs, int n_jobs, const uint16_t* __restrict__ cover_g, const int16_t* __restrict__ int_mv,
-               uint32_t lambda_q16, int bit_depth_bias, int16_t* __restrict__ out_qmv, uint32_t* __restrict__ out_cost) {
+               const MeJob* __restrict__ jobs, int n_jobs, uint32_t* __restrict__ job_counter, const uint16_t* __restrict__ cover_g,
+               const int16_t* __restrict__ int_mv, uint32_t lambda_q16, int bit_depth_bias, int16_t* __restrict__ out_qmv,
+               uint32_t* __restrict__ out_cost) {
   // bit_depth_bias: bit depth in the low 8 bits; bit 8 set = block and window carry the bias 2^bitDepth of a bi-prediction origin
   // (2*org - pred, TEncSearch.cpp:3702-3712: current samples in [-maxv, 2*maxv]; per-CTU calls only, u16 staging)
   const int bit_depth = bit_depth_bias & 0xff;
@@ -1380,22 +1462,40 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
   }
   for (int i = tid; i < (kFracPairs8 + kFracPairs4) / 8; i += NT) ((uint4*)cover)[i] = ((const uint4*)cover_g)[i];
 
-  // A workgroup walks the jobs blockIdx.x, blockIdx.x + gridDim.x, ...: the host launches as many workgroups as the chip holds at a
-  // time (a job lives ~60 us; launched one workgroup per job, the slots stood empty between a workgroup's end and its successor's
-  // first instruction for a good part of that)
+  // The host launches as many workgroups as the chip holds at a time and each takes job after job from a counter (a job lives ~60 us;
+  // launched one workgroup per job, the slots stood empty between a workgroup's end and its successor's first instruction for a good
+  // part of that).  The counter deals the jobs out as workgroups become free, like the dispatcher would: jobs differ in
+  // length with the content.  job_counter == null (the per-CTU call: one job): blockIdx.x, blockIdx.x + gridDim.x, ...
+  uint32_t* next_job = counter + 2;     // LDS word: the job this workgroup works on
 #pragma unroll 1
-  for (int jb = blockIdx.x; jb < n_jobs; jb += gridDim.x) {
+  for (int jb = blockIdx.x;; jb += gridDim.x) {
+  if (job_counter) {
+    if (tid == 0) *next_job = atomicAdd(job_counter, 1u);
+    __syncthreads();                    // (the barrier that ends the previous job's last stage keeps this write behind every read of it)
+    jb = (int)*next_job;
+  }
+  if (jb >= n_jobs) break;
   MeJob job = jobs[jb];
   const uint8_t* __restrict__ ref_base = refs.base[job.ctu_x & 63];
   const uint8_t* __restrict__ cur_base = curs.base[job.ctu_x & 63];
   job.ctu_x &= ~63;
   const int16_t* mvs = int_mv + (long)jb * kParts * 2;
 
-  for (int i = tid; i < kFracAcc; i += NT) acc[i] = 0;
-  // integer MVs outside the CTU's window (not produced by the search) are clamped to it: the patch stays inside the LDS window
-  for (int s = tid; s < kParts; s += NT) {
-    const int mx = min(max((int)mvs[2 * s], job.lt_x), job.rb_x), my = min(max((int)mvs[2 * s + 1], job.lt_y), job.rb_y);
-    st[s] = (uint32_t)(mx - job.lt_x) | (uint32_t)(my - job.lt_y) << 9 | 1u << 18 | 1u << 20;
+  // integer MVs outside the CTU's window (not produced by the search) are clamped to it: the patch stays inside the LDS window.
+  // One dword per slot (a TComMv), the three loads of a thread in flight together (593 = 2 * 256 + 81)
+  {
+    static_assert(kParts <= 3 * NT, "slot state set-up assumes three slots per thread");
+    const uint32_t* mvw = (const uint32_t*)mvs;
+    uint32_t w[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) w[k] = tid + k * NT < kParts ? mvw[tid + k * NT] : 0u;
+    for (int i = tid; i < kFracAccDw / 4; i += NT) ((uint4*)acc)[i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (tid + k * NT < kParts) {
+        const int mx = min(max((int)(int16_t)(w[k] & 0xffff), job.lt_x), job.rb_x), my = min(max((int)(int16_t)(w[k] >> 16), job.lt_y), job.rb_y);
+        st[tid + k * NT] = (uint32_t)(mx - job.lt_x) | (uint32_t)(my - job.lt_y) << 9 | 1u << 18 | 1u << 20;
+      }
   }
   if (tid < 2) counter[tid] = 0;
   for (int i = tid; i < 256 * BPS; i += NT) {
@@ -1418,12 +1518,14 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
         case 2: me_frac_dedupe<kFracCover8, 4, 2>(st, c8, keymask, p8 * kFracCover8, &counter[0], list8); break;
         default: me_frac_dedupe<kFracCover8, 4, 3>(st, c8, keymask, p8 * kFracCover8, &counter[0], list8); break;
       }
-      me_frac_dedupe<kFracCover4, 1, 0>(st, cover + kFracPairs8 + tid * kFracCover4, keymask, kFracPairs8 + tid * kFracCover4, &counter[1], list4);
+      me_frac_dedupe4(st, cover, tid, keymask, &counter[1], list4);
     }
     __syncthreads();
     const int n8 = 4 * (int)counter[0], n4 = (int)counter[1];
+#ifndef ME_FRAC_T_NOITEMS
     if (stage == 0) me_frac_stage_items<0, HAD, BPS>(src, ref_pitch, curl, st, cover, list8, n8, list4, n4, tid, bd, clip_lo, tab_h, tab_v, acc);
     else me_frac_stage_items<1, HAD, BPS>(src, ref_pitch, curl, st, cover, list8, n8, list4, n4, tid, bd, clip_lo, tab_h, tab_v, acc);
+#endif
     __syncthreads();
     if (tid < 2) counter[tid] = 0;
     for (int s = tid; s < kParts; s += NT) {

@@ -17,13 +17,15 @@ NUM_PARTS = 593
 # every symbol include/hmme.h declares (tests check the library exports all of them)
 SYMBOLS = ["hmme_create", "hmme_destroy", "hmme_last_error", "hmme_device_info", "hmme_set_lambda",
            "hmme_set_lambda_q16", "hmme_get_lambda_q16", "hmme_params_ocl_compat", "hmme_set_search_range",
-           "hmme_slot_index", "hmme_slot_rect", "hmme_search_ctu", "hmme_search_refine_ctu", "hmme_refine_ctu", "hmme_plane_create", "hmme_plane_create_ex", "hmme_plane_bit_depth", "hmme_plane_destroy", "hmme_plane_upload_pel",
+           "hmme_slot_index", "hmme_slot_rect", "hmme_search_ctu", "hmme_search_ctu_w", "hmme_search_refine_ctu", "hmme_refine_ctu", "hmme_plane_create", "hmme_plane_create_ex", "hmme_plane_bit_depth", "hmme_plane_destroy", "hmme_plane_upload_pel",
            "hmme_plane_upload_u8", "hmme_host_register", "hmme_host_unregister", "hmme_plane_set_device_u8", "hmme_plane_width", "hmme_plane_height",
            "hmme_num_ctus", "hmme_search_frame", "hmme_search_frame_device", "hmme_search_frame_multi",
            "hmme_search_frame_multi_device", "hmme_refine_frame", "hmme_refine_frame_multi_device",
-           "hmme_time_search_kernel", "hmme_search_pairs_device", "hmme_refine_pairs_device", "hmme_plane_upload_async",
-           "hmme_upload_status", "hmme_debug_device_address", "hmme_abi_version", "hmme_build_id", "hmme_device_index"]
-ABI_VERSION = 3   # HMME_ABI_VERSION of the include/hmme.h these bindings were written against
+           "hmme_search_pairs_device", "hmme_refine_pairs_device", "hmme_plane_upload_async",
+           "hmme_upload_status", "hmme_abi_version", "hmme_build_id", "hmme_device_index"]
+# test / measurement entry points (include/hmme_test.h): not part of the boundary
+TEST_SYMBOLS = ["hmme_test_time_search_kernel", "hmme_test_device_address"]
+ABI_VERSION = 4   # HMME_ABI_VERSION of the include/hmme.h these bindings were written against
 
 
 class HmmeError(RuntimeError):
@@ -34,6 +36,11 @@ class SearchParams(C.Structure):
     _fields_ = [("lt_x", C.c_int), ("lt_y", C.c_int), ("rb_x", C.c_int), ("rb_y", C.c_int),
                 ("pred_x", C.c_int), ("pred_y", C.c_int), ("fen", C.c_int), ("bit_depth", C.c_int),
                 ("shift_free", C.c_int)]
+
+
+class Weight(C.Structure):
+    """hmme_weight: luma WPScalingParam of the reference picture"""
+    _fields_ = [("w0", C.c_int), ("offset", C.c_int), ("shift", C.c_int), ("round", C.c_int)]
 
 
 class FrameParams(C.Structure):
@@ -80,6 +87,7 @@ def load():
     L.hmme_slot_index.argtypes = [i, i, i, i]
     L.hmme_slot_rect.argtypes = [i] + [C.POINTER(i)] * 4
     L.hmme_search_ctu.argtypes = [vp, vp, i, vp, i, C.POINTER(SearchParams), vp, vp]
+    L.hmme_search_ctu_w.argtypes = [vp, vp, i, vp, i, C.POINTER(SearchParams), C.POINTER(Weight), vp, vp]
     L.hmme_search_refine_ctu.argtypes = [vp, vp, i, vp, i, C.POINTER(SearchParams), i, vp, vp, vp, vp]
     L.hmme_refine_ctu.argtypes = [vp, vp, i, vp, i, C.POINTER(SearchParams), vp, i, vp, vp]
     L.hmme_plane_create.argtypes = [vp, i, i, C.POINTER(vp)]
@@ -101,13 +109,13 @@ def load():
     L.hmme_search_frame_multi_device.argtypes = [vp, vp, C.POINTER(vp), i, C.POINTER(FrameParams), vp, vp, vp, vp]
     L.hmme_refine_frame.argtypes = [vp, vp, vp, C.POINTER(FrameParams), vp, vp, i, vp, vp]
     L.hmme_refine_frame_multi_device.argtypes = [vp, vp, C.POINTER(vp), i, C.POINTER(FrameParams), vp, vp, i, vp, vp, vp]
-    L.hmme_time_search_kernel.argtypes = [vp, vp, vp, C.POINTER(FrameParams), vp, vp, vp, vp, i, C.POINTER(C.c_float)]
+    L.hmme_test_time_search_kernel.argtypes = [vp, vp, vp, C.POINTER(FrameParams), vp, vp, vp, vp, i, C.POINTER(C.c_float)]
     L.hmme_search_pairs_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i, C.POINTER(FrameParams), vp, vp, vp, vp]
     L.hmme_refine_pairs_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i, C.POINTER(FrameParams), vp, vp, i, vp, vp, vp]
     L.hmme_plane_upload_async.argtypes = [vp, vp, i, i, vp]
     L.hmme_upload_status.argtypes = [vp, vp]
-    L.hmme_debug_device_address.argtypes = [vp, vp]
-    L.hmme_debug_device_address.restype = C.c_uint64
+    L.hmme_test_device_address.argtypes = [vp, vp]
+    L.hmme_test_device_address.restype = C.c_uint64
     _lib = L
     return L
 
@@ -137,7 +145,7 @@ class Plane:
 
     @property
     def device_address(self):
-        return int(self.engine.L.hmme_debug_device_address(self.engine.h, self.h))
+        return int(self.engine.L.hmme_test_device_address(self.engine.h, self.h))
 
     def set_device_u8(self, dptr, pitch, stream=0):
         self.engine._check(self.engine.L.hmme_plane_set_device_u8(self.h, dptr, pitch, stream))
@@ -215,6 +223,18 @@ class Engine:
         rp = ref.ctypes.data + 2 * (ref_xy[1] * ref.shape[1] + ref_xy[0])
         self._check(self.L.hmme_search_ctu(self.h, cp, cur.shape[1], rp, ref.shape[1], C.byref(params),
                                            mv.ctypes.data, sad.ctypes.data))
+        return mv, sad
+
+    def search_ctu_w(self, cur_plane, cur_xy, ref_plane, ref_xy, params, wp):
+        """hmme_search_ctu_w: the per-CTU search of a slice with explicit weighted prediction; wp = (w0, offset, shift, round)"""
+        cur = np.ascontiguousarray(cur_plane, dtype=np.int16)
+        ref = np.ascontiguousarray(ref_plane, dtype=np.int16)
+        mv = np.zeros((NUM_PARTS, 2), np.int16)
+        sad = np.zeros(NUM_PARTS, np.uint32)
+        cp = cur.ctypes.data + 2 * (cur_xy[1] * cur.shape[1] + cur_xy[0])
+        rp = ref.ctypes.data + 2 * (ref_xy[1] * ref.shape[1] + ref_xy[0])
+        w = Weight(*[int(v) for v in wp])
+        self._check(self.L.hmme_search_ctu_w(self.h, cp, cur.shape[1], rp, ref.shape[1], C.byref(params), C.byref(w), mv.ctypes.data, sad.ctypes.data))
         return mv, sad
 
     def search_refine_ctu(self, cur_plane, cur_xy, ref_plane, ref_xy, params, use_hadamard=True):
@@ -322,14 +342,14 @@ class Engine:
     @property
     def call_block_address(self):
         """device address of the per-CTU call's current-block staging area (high-address test)"""
-        return int(self.L.hmme_debug_device_address(self.h, None))
+        return int(self.L.hmme_test_device_address(self.h, None))
 
     def search_frame_device(self, cur, ref, fp, d_pred, d_mv, d_sad, stream=0):
         self._check(self.L.hmme_search_frame_device(self.h, cur.h, ref.h, C.byref(fp), d_pred, d_mv, d_sad, stream))
 
     def time_search_kernel(self, cur, ref, fp, d_pred, d_mv, d_sad, stream=0, reps=3):
         ms = C.c_float()
-        self._check(self.L.hmme_time_search_kernel(self.h, cur.h, ref.h, C.byref(fp), d_pred, d_mv, d_sad, stream, reps,
+        self._check(self.L.hmme_test_time_search_kernel(self.h, cur.h, ref.h, C.byref(fp), d_pred, d_mv, d_sad, stream, reps,
                                                    C.byref(ms)))
         return float(ms.value)
 

@@ -11,7 +11,8 @@ TEncOpenCL::TEncOpenCL()
     : m_ctx(0), m_deviceId(0), m_deviceFound(false), m_enabled(false), m_lastOk(false), m_searchRange(0),
       m_mode(ME_MODE_OCL_COMPAT), m_fen(false), m_bitDepth(0), m_inferredDepth(8), m_bi(0), m_lambda(0.0), m_calls(0), m_failed(0), m_edgeCalls(0),
       m_biCalls(0), m_verified(0), m_verifyFailed(0), m_refine(false), m_refineHad(true), m_fracOk(false), m_fracBi(false),
-      m_fracMvTab(0), m_fracDistTab(0), m_fracCostTab(0) {
+      m_fracMvTab(0), m_fracDistTab(0), m_fracCostTab(0), m_wpOn(false) {
+  m_wp[0] = 1; m_wp[1] = m_wp[2] = m_wp[3] = 0;
   for (Int b = 0; b < 2; b++) {
     xPoison(m_tab[b]);   // tables nobody filled yet must not look like results either
   }
@@ -146,17 +147,27 @@ Void TEncOpenCL::calcMotionVectors(Pel* pelCtu, Pel* pelSearch, Int iRefStride, 
   (void)sizeof(tcommv_is_two_shorts); (void)sizeof(distortion_is_u32);
   // refinement rides along on calls with HM's arithmetic, uni-prediction and bi-prediction origins alike (the bBi call of
   // TEncSearch.cpp:3798); where the engine cannot refine the integer search still runs and fracOk() says so
-  const Bool wantFrac = m_refine && m_mode == ME_MODE_HM;
+  const Bool weighted = m_wpOn && m_mode == ME_MODE_HM;   // the reference kernel knows no weights (cl/sad.cl): compat mode ignores them
+  const Bool wantFrac = m_refine && m_mode == ME_MODE_HM && !weighted;
   m_fracOk = false;
   m_fracBi = m_bi != 0;
   Int rc = HMME_ERR_UNSUPPORTED;
+  if (weighted) {   // no unweighted second try: a failed weighted call must reach the caller as failed
+    hmme_weight w = {m_wp[0], m_wp[1], m_wp[2], m_wp[3]};
+    rc = hmme_search_ctu_w(m_ctx, pelCtu, iCtuStride, pelSearch, iRefStride, &p, &w, reinterpret_cast<int16_t*>(t.mv), reinterpret_cast<uint32_t*>(t.cost));
+    if (rc != HMME_OK) {
+      fprintf(stderr, "ERROR: TEncOpenCL::calcMotionVectors (weighted prediction): %s\n", hmme_last_error(m_ctx));
+      xPoison(t);
+      return;
+    }
+  }
   if (wantFrac) {
     rc = hmme_search_refine_ctu(m_ctx, pelCtu, iCtuStride, pelSearch, iRefStride, &p, m_refineHad ? 1 : 0, reinterpret_cast<int16_t*>(t.mv),
                                 reinterpret_cast<uint32_t*>(t.cost), reinterpret_cast<int16_t*>(m_qmv), reinterpret_cast<uint32_t*>(m_fracCost));
     m_fracOk = rc == HMME_OK;
     m_fracPred = m_pred;
   }
-  if (rc != HMME_OK)
+  if (rc != HMME_OK && !weighted)
     rc = hmme_search_ctu(m_ctx, pelCtu, iCtuStride, pelSearch, iRefStride, &p, reinterpret_cast<int16_t*>(t.mv), reinterpret_cast<uint32_t*>(t.cost));
   if (rc != HMME_OK) {
     fprintf(stderr, "ERROR: TEncOpenCL::calcMotionVectors: %s\n", hmme_last_error(m_ctx));

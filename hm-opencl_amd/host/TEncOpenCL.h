@@ -61,6 +61,15 @@ class TEncOpenCL {
   const TComMv* getMvs() const { return m_tab[m_bi].mv; }
   Bool lastCallOk() const { return m_lastOk; }
 
+  // ---- additive: explicit weighted prediction ----
+  /// A slice with weighted prediction searches with m_cDistParam.bApplyWeight (setWpScalingDistParam, TEncSearch.cpp:3740, :5594-5635):
+  /// every candidate is priced by xGetSADw on ((w * ref + round) >> shift) + offset.  While a weight is set, ME_MODE_HM calls run
+  /// hmme_search_ctu_w (integer search only: fracOk() stays false); a call the engine cannot serve exactly (weighted samples beyond a
+  /// Pel, sums beyond its cost field) fails like any other -- lastCallOk() false, tables poisoned -- and the caller searches on the CPU.
+  Void setWeight(Int w, Int offset, Int shift, Int round) { m_wpOn = true; m_wp[0] = w; m_wp[1] = offset; m_wp[2] = shift; m_wp[3] = round; }
+  Void clearWeight() { m_wpOn = false; }
+  Bool getWeightOn() const { return m_wpOn; }
+
   // ---- additive: bi-prediction refinement ----
   /// The bi-prediction pass (bBi, TEncSearch.cpp:3221) searches 2*org - pred_other with BipredSearchRange around the
   /// uni-prediction winner.  While setBiPred(true), calcMotionVectors fills -- and the getters return -- a SECOND table set,
@@ -171,6 +180,8 @@ class TEncOpenCL {
   TComMv (*m_fracMvTab)[33][NUM_CTU_PARTS];          // [2][33][593], allocated on first use (313 KB + 2 x 157 KB)
   Distortion (*m_fracDistTab)[33][NUM_CTU_PARTS];
   Distortion (*m_fracCostTab)[33][NUM_CTU_PARTS];
+  Bool m_wpOn;                         // explicit weighted prediction for the calls that follow (ME_MODE_HM)
+  Int m_wp[4];                         // w, offset, shift, round of the reference picture's luma WPScalingParam
 };
 
 #endif

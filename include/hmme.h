@@ -62,8 +62,9 @@ extern "C" {
  * library was built with.  TEncOpenCL::findDevice and hmme/api.py refuse a library whose version differs from the header they were
  * written against (hmme_search_params grew by `shift_free` in version 2: a caller built against version 1 would have the library
  * read 4 bytes past its struct).  3: hmme_search_pairs_device / hmme_refine_pairs_device, asynchronous uploads, bi-prediction
- * origins in the refinement calls. */
-#define HMME_ABI_VERSION 3
+ * origins in the refinement calls.  4: hmme_search_ctu_w (explicit weighted prediction); hmme_time_search_kernel and
+ * hmme_debug_device_address left this header (include/hmme_test.h). */
+#define HMME_ABI_VERSION 4
 int hmme_abi_version(void);
 /* identifies the kernel sources + build flags the library was compiled from (bench.py ties committed counter summaries to it) */
 const char* hmme_build_id(void);
@@ -139,6 +140,17 @@ int hmme_slot_rect(int slot, int* x, int* y, int* w, int* h);
  * out_mv: int16[593][2] (hor, ver), out_sad: uint32[593] (pure SAD at the arg-min = ruiCost). */
 int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref_at_ctu_origin,
                     int ref_stride, const hmme_search_params* p, int16_t* out_mv, uint32_t* out_sad);
+
+/* The same search in a slice with explicit weighted prediction (TEncSearch::setWpScalingDistParam, TEncSearch.cpp:3740, :5594-5635:
+ * m_cDistParam.bApplyWeight + wpCur): every candidate is priced by TComRdCostWeightPrediction::xGetSADw
+ * (TComRdCostWeightPrediction.cpp:55-90), |org - (((w0 * ref + round) >> shift) + offset)| summed over EVERY row (p->fen is not
+ * consulted: each xGetSAD* hands over to xGetSADw before it looks at iSubShift, TComRdCost.cpp:467-469), the prediction unclipped,
+ * the whole-block sum >> (bitDepth-8).  `wp` = the luma WPScalingParam of the reference picture (w, offset, shift, round; TComSlice.h:1178-
+ * 1190).  HMME_ERR_UNSUPPORTED when a weighted sample of the window would leave int16 (HM keeps it in a Pel and wraps; not
+ * reproduced) or the sums could exceed the engine's cost field: the caller then searches on the CPU.  Integer search only. */
+typedef struct hmme_weight { int w0, offset, shift, round; } hmme_weight;
+int hmme_search_ctu_w(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref_at_ctu_origin, int ref_stride,
+                      const hmme_search_params* p, const hmme_weight* wp, int16_t* out_mv, uint32_t* out_sad);
 
 /* The step after the search, for the same CTU: TEncSearch::xPatternSearchFracDIF (TEncSearch.cpp:4294-4331, called per PU at :3798)
  * for all 593 slots -- half- then quarter-pel refinement around each slot's integer MV, HM's 8-tap interpolation, Hadamard
@@ -235,15 +247,16 @@ int hmme_refine_pairs_device(hmme_ctx* ctx, const hmme_plane* const* curs, const
                              const hmme_frame_params* fp, const void* d_pred_q, const void* d_int_mv, int use_hadamard,
                              void* d_out_qmv, void* d_out_cost, void* stream);
 
-/* ---- measurement / test helpers ------------------------------------------------------------ */
-/* device address of a plane's sample (0,0) (plane != NULL) or of the context's per-CTU current-block staging area: lets a test
- * prove that a launch ran on addresses whose low dword has bit 31 set (tests/test_gpu_parity.py, high-address case) */
-uint64_t hmme_debug_device_address(const hmme_ctx* ctx, const hmme_plane* plane);
-/* average device time in ms of the search kernel over `reps` back-to-back launches on `stream`,
- * measured with hipEvents recorded on that stream */
-int hmme_time_search_kernel(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp,
-                            const void* d_pred_q, void* d_out_mv, void* d_out_sad, void* stream, int reps,
-                            float* avg_ms);
+/* ---- environment (diagnostics and A/B measurements; none of these changes a result) ---------
+ *   HMME_TRACE=1          one stderr line per context about launch geometry the library derives at run time (workgroups of the
+ *                         refinement kernel per CU); the TEncOpenCL host module prints its call summary in its destructor
+ *   HMME_FRAC_GRID=<n>    workgroups of a refinement launch: default = what the chip holds at a time (each takes job after job
+ *                         from a counter); 0 = one workgroup per job (the launch of rounds 1-3); n = exactly n
+ *   HMME_TAIL_PARTS=<n>   pieces per job of a launch's last, partial round of workgroups: default = the planner's choice
+ *                         (DESIGN.md 5 "rounds of workgroups"); 1 = no tail plan
+ *   HMME_STRIPS16=<n>     16-bit search kernel: that many equal window strips per job instead of the planner's number
+ *   HMME_LDS_BUDGET16=<b> 16-bit search kernel: LDS bytes a strip's window rows may take (clamped to what the kernel can address)
+ * Measurement and test entry points live in include/hmme_test.h, not here. */
 
 #ifdef __cplusplus
 }

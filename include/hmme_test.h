@@ -1,0 +1,24 @@
+/* hmme_test.h -- entry points of libhmme.so that exist for tests and measurements only.  NOT part of the drop-in boundary
+ * (include/hmme.h): nothing a host application needs, no stability promise, not counted in HMME_ABI_VERSION. */
+#ifndef HMME_TEST_H
+#define HMME_TEST_H
+
+#include "hmme.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* device address of a plane's sample (0,0) (plane != NULL) or of the context's per-CTU current-block staging area: lets a test
+ * prove that a launch ran on addresses whose low dword has bit 31 set (tests/test_gpu_parity.py, high-address case) */
+uint64_t hmme_test_device_address(const hmme_ctx* ctx, const hmme_plane* plane);
+/* average device time in ms of the search kernel(s) alone over `reps` back-to-back launches on `stream` (job tables prepared once,
+ * outside the timed region), measured with hipEvents recorded on that stream */
+int hmme_test_time_search_kernel(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref, const hmme_frame_params* fp,
+                                 const void* d_pred_q, void* d_out_mv, void* d_out_sad, void* stream, int reps,
+                                 float* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -59,6 +59,22 @@ uint32_t hmo_sad(const hmo_pel* org, int org_stride, const hmo_pel* cur, int cur
   return sum >> (bit_depth - 8);
 }
 
+/* TComRdCostWeightPrediction::xGetSADw, TComRdCostWeightPrediction.cpp:55-90:
+ *   pred = ((w0 * cur[n] + round) >> shift) + offset        (:79, not clipped)
+ *   sum += |org[n] - pred| over EVERY row; return sum >> (bitDepth-8)   (:81, :89) */
+static inline int wp_pred(int v, const hmo_wp* wp) {
+  return (hmo_pel)(((wp->w0 * v + wp->round) >> wp->shift) + wp->offset);   /* `const Pel pred = ...` (:79): the value is kept in a Pel = Short */
+}
+uint32_t hmo_sad_w(const hmo_pel* org, int org_stride, const hmo_pel* cur, int cur_stride, int w, int h, int bit_depth, const hmo_wp* wp) {
+  uint32_t sum = 0;
+  for (int rows = h; rows != 0; --rows) {
+    for (int n = 0; n < w; ++n) sum += (uint32_t)abs((int)org[n] - wp_pred(cur[n], wp));
+    org += org_stride;
+    cur += cur_stride;
+  }
+  return sum >> (bit_depth - 8);
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* slot layout                                                                          */
 /* ------------------------------------------------------------------------------------ */
@@ -230,6 +246,39 @@ void hmo_pattern_search(const hmo_pel* org, int org_stride, int w, int h, const 
   }
   *mvx = best_x; *mvy = best_y;
   *sad = best - hmo_mv_cost(p->lambda_q16, best_x, best_y, p->pred_x, p->pred_y, 2); /* :3895 */
+}
+
+/* xPatternSearch in a slice with weighted prediction: the DistFunc of every candidate is xGetSADw (TComRdCost.cpp:467-469 and the
+ * same two lines at the head of each width's function), so iSubShift set at TEncSearch.cpp:3853-3859 has no effect */
+void hmo_pattern_search_w(const hmo_pel* org, int org_stride, int w, int h, const hmo_pel* ref, int ref_stride, const hmo_params* p,
+                          const hmo_wp* wp, int* mvx, int* mvy, uint32_t* sad) {
+  uint32_t best = UINT_MAX;
+  int best_x = 0, best_y = 0;
+  const hmo_pel* row = ref + (ptrdiff_t)p->lt_y * ref_stride;
+  for (int y = p->lt_y; y <= p->rb_y; ++y) {
+    for (int x = p->lt_x; x <= p->rb_x; ++x) {
+      uint32_t s = hmo_sad_w(org, org_stride, row + x, ref_stride, w, h, p->bit_depth, wp);
+      s += hmo_mv_cost(p->lambda_q16, x, y, p->pred_x, p->pred_y, 2);
+      if (s < best) { best = s; best_x = x; best_y = y; }
+    }
+    row += ref_stride;
+  }
+  *mvx = best_x; *mvy = best_y;
+  *sad = best - hmo_mv_cost(p->lambda_q16, best_x, best_y, p->pred_x, p->pred_y, 2);
+}
+
+/* all 593 slots with weighted prediction: the weighted window is formed once (the prediction of a sample does not depend on the
+ * candidate), then the unweighted all-slot search runs on it with every row counted */
+void hmo_search_ctu_w(const hmo_pel* ctu, int ctu_stride, const hmo_pel* ref, int ref_stride, const hmo_params* p, const hmo_wp* wp,
+                      int32_t* out_x, int32_t* out_y, uint32_t* out_sad, uint32_t* out_cost) {
+  const int wx = p->rb_x - p->lt_x + 64, wy = p->rb_y - p->lt_y + 64;   /* samples the window spans */
+  hmo_pel* win = (hmo_pel*)malloc(sizeof(hmo_pel) * (size_t)wx * wy);
+  for (int y = 0; y < wy; ++y)
+    for (int x = 0; x < wx; ++x) win[(size_t)y * wx + x] = (hmo_pel)wp_pred(ref[(ptrdiff_t)(p->lt_y + y) * ref_stride + p->lt_x + x], wp);
+  hmo_params q = *p;
+  q.fen = 0;
+  hmo_search_ctu(ctu, ctu_stride, win - ((ptrdiff_t)p->lt_y * wx + p->lt_x), wx, &q, out_x, out_y, out_sad, out_cost);
+  free(win);
 }
 
 void hmo_ocl_compat_params(hmo_params* p, int lt_x, int lt_y, int sr, uint32_t lambda_q16) {

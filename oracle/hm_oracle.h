@@ -39,6 +39,10 @@ typedef struct hmo_params {
   int bit_depth;        /* SAD >> (bitDepth-8)  (TComRdCost.cpp:520-521) */
 } hmo_params;
 
+/* explicit weighted prediction of the reference picture (WPScalingParam of the luma component, TComSlice.h:1178-1190): the
+ * integer search of a slice with weighted prediction prices |org - (((w0 * ref + round) >> shift) + offset)| (xGetSADw) */
+typedef struct hmo_wp { int w0, offset, shift, round; } hmo_wp;
+
 /* ---- MV-bit cost ------------------------------------------------------------------- */
 uint32_t hmo_component_bits(int val);                        /* TComRdCost.cpp:278-292 */
 uint32_t hmo_lambda_q16(double lambda);                      /* TComRdCost.cpp:209 */
@@ -80,6 +84,16 @@ void hmo_search_ctu(const hmo_pel* ctu, int ctu_stride, const hmo_pel* ref, int 
 /* reference-GPU-compatible preset: pred=(0,0), window LT..LT+2*sr,
  * no FEN, no bit-depth shift */
 void hmo_ocl_compat_params(hmo_params* p, int lt_x, int lt_y, int sr, uint32_t lambda_q16);
+
+/* ---- the same searches in a slice with explicit weighted prediction (m_cDistParam.bApplyWeight, TEncSearch.cpp:3740, :5594-5635) ---- */
+/* TComRdCostWeightPrediction::xGetSADw (TComRdCostWeightPrediction.cpp:55-90): every row (the FEN sub-sampling is never reached:
+ * each xGetSAD* returns xGetSADw first, TComRdCost.cpp:467-469), prediction not clipped, whole-block sum >> (bitDepth-8) */
+uint32_t hmo_sad_w(const hmo_pel* org, int org_stride, const hmo_pel* cur, int cur_stride, int w, int h, int bit_depth, const hmo_wp* wp);
+/* xPatternSearch with bApplyWeight: p->fen is ignored (see hmo_sad_w) */
+void hmo_pattern_search_w(const hmo_pel* org, int org_stride, int w, int h, const hmo_pel* ref, int ref_stride, const hmo_params* p,
+                          const hmo_wp* wp, int* mvx, int* mvy, uint32_t* sad);
+void hmo_search_ctu_w(const hmo_pel* ctu, int ctu_stride, const hmo_pel* ref, int ref_stride, const hmo_params* p, const hmo_wp* wp,
+                      int32_t* out_x, int32_t* out_y, uint32_t* out_sad, uint32_t* out_cost);
 
 /* ---- TZ search for one PU: xTZSearch + helpers (TEncSearch.cpp:3935-4136, :340-808,
  *      configuration :305-321).  Returns the number of SAD probes made.

@@ -25,6 +25,11 @@ class Params(C.Structure):
                 ("fen", C.c_int), ("bit_depth", C.c_int)]
 
 
+class Wp(C.Structure):
+    """hmo_wp: luma WPScalingParam of the reference picture (w, offset, shift, round)"""
+    _fields_ = [("w0", C.c_int), ("offset", C.c_int), ("shift", C.c_int), ("round", C.c_int)]
+
+
 class Rect(C.Structure):
     _fields_ = [("x", C.c_int), ("y", C.c_int), ("w", C.c_int), ("h", C.c_int)]
 
@@ -78,6 +83,14 @@ def oracle():
         L.hmo_search_ctu.restype = None
         L.hmo_search_ctu.argtypes = [C.POINTER(C.c_int16), C.c_int, C.POINTER(C.c_int16), C.c_int,
                                      C.POINTER(Params), _i32p, _i32p, _u32p, C.c_void_p]
+        L.hmo_sad_w.restype = C.c_uint32
+        L.hmo_sad_w.argtypes = [C.POINTER(C.c_int16), C.c_int, C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Wp)]
+        L.hmo_pattern_search_w.restype = None
+        L.hmo_pattern_search_w.argtypes = [C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int16), C.c_int, C.POINTER(Params),
+                                           C.POINTER(Wp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint32)]
+        L.hmo_search_ctu_w.restype = None
+        L.hmo_search_ctu_w.argtypes = [C.POINTER(C.c_int16), C.c_int, C.POINTER(C.c_int16), C.c_int, C.POINTER(Params), C.POINTER(Wp),
+                                       _i32p, _i32p, _u32p, C.c_void_p]
         L.hmo_ocl_compat_params.restype = None
         L.hmo_ocl_compat_params.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.c_uint32]
         L.hmo_tz_search.restype = C.c_long
@@ -145,6 +158,13 @@ def ref():
             L.ref_tz_frame.restype = C.c_long
             L.ref_tz_frame.argtypes = [C.POINTER(C.c_int16), C.c_int, C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                        C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p, _i32p, _u32p]
+        if hasattr(L, "ref_pattern_search_w"):   # harness of round 4 and later: explicit weighted prediction
+            L.ref_pattern_search_w.restype = None
+            L.ref_pattern_search_w.argtypes = ([C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int16), C.c_int]
+                                               + [C.c_int] * 6 + [C.c_double, C.c_int, C.c_int] + [C.c_int] * 4
+                                               + [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint32)])
+            L.ref_sad_w.restype = C.c_uint32
+            L.ref_sad_w.argtypes = [C.POINTER(C.c_int16), C.c_int, C.POINTER(C.c_int16), C.c_int] + [C.c_int] * 8
         L.ref_frac_refine_bi.restype = None
         L.ref_frac_refine_bi.argtypes = L.ref_frac_refine.argtypes
         _ref = L
@@ -181,6 +201,35 @@ def search_ctu(plane_cur, cur_xy, plane_ref, ref_xy, p):
     L.hmo_search_ctu(_addr(plane_cur, cur_xy[1] * cs + cur_xy[0]), cs,
                      _addr(plane_ref, ref_xy[1] * rs + ref_xy[0]), rs, C.byref(p), ox, oy, osad, None)
     return ox, oy, osad
+
+
+def search_ctu_w(plane_cur, cur_xy, plane_ref, ref_xy, p, wp):
+    """all 593 slots in a slice with explicit weighted prediction; wp = (w0, offset, shift, round)"""
+    L = oracle()
+    ox = np.zeros(NUM_PARTS, np.int32)
+    oy = np.zeros(NUM_PARTS, np.int32)
+    osad = np.zeros(NUM_PARTS, np.uint32)
+    cs, rs = plane_cur.shape[1], plane_ref.shape[1]
+    w = Wp(*[int(v) for v in wp])
+    L.hmo_search_ctu_w(_addr(plane_cur, cur_xy[1] * cs + cur_xy[0]), cs, _addr(plane_ref, ref_xy[1] * rs + ref_xy[0]), rs, C.byref(p), C.byref(w),
+                       ox, oy, osad, None)
+    return ox, oy, osad
+
+
+def pattern_search_w(plane_cur, cur_xy, plane_ref, ref_xy, w, h, p, wp, use_ref=False, lam=None):
+    """exhaustive search of ONE PU with explicit weighted prediction wp = (w0, offset, shift, round): the oracle, or the reference's
+    own xPatternSearch with bApplyWeight (use_ref; `lam` the double-precision lambda)"""
+    cs, rs = plane_cur.shape[1], plane_ref.shape[1]
+    org = _addr(plane_cur, cur_xy[1] * cs + cur_xy[0])
+    rf = _addr(plane_ref, ref_xy[1] * rs + ref_xy[0])
+    mx, my, sad = C.c_int(), C.c_int(), C.c_uint32()
+    if use_ref:
+        ref().ref_pattern_search_w(org, cs, w, h, rf, rs, p.lt_x, p.lt_y, p.rb_x, p.rb_y, p.pred_x, p.pred_y, float(lam), p.fen, p.bit_depth,
+                                   *[int(v) for v in wp], C.byref(mx), C.byref(my), C.byref(sad))
+    else:
+        ww = Wp(*[int(v) for v in wp])
+        oracle().hmo_pattern_search_w(org, cs, w, h, rf, rs, C.byref(p), C.byref(ww), C.byref(mx), C.byref(my), C.byref(sad))
+    return mx.value, my.value, sad.value
 
 
 def pattern_search(plane_cur, cur_xy, plane_ref, ref_xy, w, h, p, use_ref=False, lam=None):

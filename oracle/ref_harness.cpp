@@ -147,6 +147,50 @@ void ref_pattern_search(int16_t* org, int org_stride, int w, int h, int16_t* ref
   *mvx = mv.getHor(); *mvy = mv.getVer(); *sad = d;
 }
 
+// the same with explicit weighted prediction switched on for the search (what setWpScalingDistParam, TEncSearch.cpp:5594-5635, leaves
+// in m_cDistParam for a slice with weighted prediction): bApplyWeight + the luma WPScalingParam of the reference picture.
+// Every candidate's DistFunc is then TComRdCostWeightPrediction::xGetSADw.
+void ref_pattern_search_w(int16_t* org, int org_stride, int w, int h, int16_t* ref_at_pu, int ref_stride, int lt_x,
+                          int lt_y, int rb_x, int rb_y, int pred_x, int pred_y, double lambda, int fen,
+                          int bit_depth, int w0, int offset, int shift, int round, int* mvx, int* mvy, uint32_t* sad) {
+  Rig& r = rig();
+  setup_cost(lambda, pred_x, pred_y, bit_depth);
+  r.cfg->setUseFastEnc(fen != 0);
+  r.cfg->setFastSearch(0);
+  static WPScalingParam wp[MAX_NUM_COMPONENT];
+  memset(wp, 0, sizeof wp);
+  wp[COMPONENT_Y].w = w0; wp[COMPONENT_Y].offset = offset; wp[COMPONENT_Y].shift = shift; wp[COMPONENT_Y].round = round;
+  r.search->m_cDistParam.bApplyWeight = true;
+  r.search->m_cDistParam.wpCur = wp;
+  TComPattern pat;
+  pat.initPattern(org, w, h, org_stride, bit_depth);
+  TComMv lt((Short)lt_x, (Short)lt_y), rb((Short)rb_x, (Short)rb_y), mv;
+  Distortion d = 0;
+  r.search->xPatternSearch(&pat, ref_at_pu, ref_stride, &lt, &rb, mv, d);
+  r.search->m_cDistParam.bApplyWeight = false;
+  r.search->m_cDistParam.wpCur = NULL;
+  *mvx = mv.getHor(); *mvy = mv.getVer(); *sad = d;
+}
+
+// TComRdCostWeightPrediction::xGetSADw through the DistFunc TComRdCost::setDistParam selects (which hands over to it)
+uint32_t ref_sad_w(int16_t* org, int org_stride, int16_t* cur, int cur_stride, int w, int h, int sub_shift, int bit_depth, int w0, int offset,
+                   int shift, int round) {
+  Rig& r = rig();
+  TComPattern pat;
+  pat.initPattern(org, w, h, org_stride, bit_depth);
+  WPScalingParam wp[MAX_NUM_COMPONENT];
+  memset(wp, 0, sizeof wp);
+  wp[COMPONENT_Y].w = w0; wp[COMPONENT_Y].offset = offset; wp[COMPONENT_Y].shift = shift; wp[COMPONENT_Y].round = round;
+  DistParam dp;
+  r.rd->setDistParam(&pat, cur, cur_stride, dp);
+  dp.bApplyWeight = true;
+  dp.wpCur = wp;
+  dp.compIdx = COMPONENT_Y;
+  dp.iSubShift = sub_shift;     // set as the FEN path sets it: xGetSADw never looks at it
+  dp.bitDepth = bit_depth;
+  return dp.DistFunc(&dp);
+}
+
 // TEncSearch::xTZSearch for one PU (FastSearch=1).  start_q = *pcMvPred (TEncSearch.cpp:3778).
 // has_int_mv: pass pIntegerMv2Nx2NPred.  Window LT/RB as computed by the caller.
 void ref_tz_search(int16_t* org, int org_stride, int w, int h, int16_t* ref_at_pu, int ref_stride, int lt_x,

@@ -190,6 +190,41 @@ int main() {
     }
     me.setRefine(false);
   }
+  // ---- explicit weighted prediction: setWeight -> hmme_search_ctu_w == the oracle's weighted search (itself pinned by the reference's
+  // xPatternSearch with bApplyWeight, tests/golden/wp.npz); refinement tables are not produced for weighted calls
+  {
+    const int cu_x = 64, cu_y = 0;
+    std::vector<Pel> faded(64 * 64);
+    Pel* piRefY = &ref[(M + cu_y) * stride + M + cu_x];
+    for (int y = 0; y < 64; ++y)
+      for (int x = 0; x < 64; ++x) {
+        const int v = ((52 * piRefY[(y + 2) * stride + x - 3] + 32) >> 6) + 17 + (int)(rnd() % 3) - 1;
+        faded[y * 64 + x] = (Pel)(v < 0 ? 0 : (v > 255 ? 255 : v));
+      }
+    me.setCostMode(TEncOpenCL::ME_MODE_HM);
+    me.setFastEnc(true);
+    me.setRefine(true, true);
+    me.setWeight(52, 17, 6, 32);
+    int ltx, lty, rbx, rby;
+    hmo_set_search_range(5, -3, SR, cu_x, cu_y, W, H, 64, &ltx, &lty, &rbx, &rby);
+    TComMv lt((Short)ltx, (Short)lty);
+    me.setPredictor(TComMv(5, -3));
+    me.setSearchRangeRB(TComMv((Short)rbx, (Short)rby));
+    me.calcMotionVectors(&faded[0], piRefY, stride, 64, SR, &lt);
+    if (!me.lastCallOk() || me.fracOk()) { fprintf(stderr, "weighted call: ok %d, fracOk %d\n", (int)me.lastCallOk(), (int)me.fracOk()); ++failures; }
+    hmo_params p;
+    p.lt_x = ltx; p.lt_y = lty; p.rb_x = rbx; p.rb_y = rby; p.pred_x = 5; p.pred_y = -3; p.lambda_q16 = hmo_lambda_q16(lambda); p.fen = 1; p.bit_depth = 8;
+    const hmo_wp wp = {52, 17, 6, 32};
+    int32_t ox[HMO_NUM_CTU_PARTS], oy[HMO_NUM_CTU_PARTS];
+    uint32_t osad[HMO_NUM_CTU_PARTS];
+    hmo_search_ctu_w(&faded[0], 64, piRefY, stride, &p, &wp, ox, oy, osad, NULL);
+    int bad = 0;
+    for (int i = 0; i < NUM_CTU_PARTS; i++) bad += me.getMvs()[i].getHor() != ox[i] || me.getMvs()[i].getVer() != oy[i] || me.getRuiCost()[i] != osad[i];
+    if (bad) { fprintf(stderr, "weighted prediction: %d slots differ from the oracle\n", bad); failures += bad; }
+    if (ox[592] != -3 || oy[592] != 2) { fprintf(stderr, "weighted prediction: the fade's displacement was not found (%d,%d)\n", ox[592], oy[592]); ++failures; }
+    me.clearWeight();
+    me.setRefine(false);
+  }
   // ---- picture-edge CTU: 192x128 has none, so pretend the picture ends inside CTU (2,1): 40 x 24 valid
   {
     const int cu_x = 128, cu_y = 64, vw = 40, vh = 24, pw = cu_x + vw, ph = cu_y + vh;

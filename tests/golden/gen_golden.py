@@ -333,12 +333,74 @@ def gen_frac_bipred(table):
     print("frac_bipred:", len(rows))
 
 
+def gen_wp(table):
+    """explicit weighted prediction (TEncSearch::setWpScalingDistParam, TEncSearch.cpp:5594-5635 -> TComRdCostWeightPrediction::xGetSADw):
+    weighted SAD known answers for every width function, and whole 593-slot searches with bApplyWeight from the reference's own
+    xPatternSearch.  wp = (w, offset, shift, round) as WPScalingParam carries them for luma."""
+    rng = np.random.default_rng(23)
+    # ---- SAD known answers: all widths x heights, sub_shift 0 / 1 (must make no difference), 8 / 10 bit, weights incl. negative and shift 0
+    wps = [(64, 0, 6, 32), (80, -12, 6, 32), (45, 21, 6, 32), (3, -100, 0, 0), (-17, 300, 4, 8), (127, -128, 7, 64), (1, 0, 0, 0)]
+    cases, outs, pa, pb = [], [], [], []
+    for bd in (8, 10):
+        maxv = (1 << bd) - 1
+        a = rng.integers(0, maxv + 1, size=(64, 64)).astype(np.int16)
+        b = rng.integers(0, maxv + 1, size=(64, 64)).astype(np.int16)
+        pa.append(a); pb.append(b)
+        for wi, wp in enumerate(wps):
+            for w in (4, 8, 12, 16, 24, 32, 48, 64):
+                for h in (4, 8, 16, 24, 64):
+                    for sub in (0, 1):
+                        ox, oy = int(rng.integers(0, 64 - w + 1)), int(rng.integers(0, 64 - h + 1))
+                        v = R.ref_sad_w(O._addr(a, oy * 64 + ox), 64, O._addr(b, oy * 64 + ox), 64, w, h, sub, bd, *wp)
+                        cases.append((w, h, sub, bd, len(pa) - 1, ox, oy, wi)); outs.append(v)
+    # ---- searches: a fade (cur = gain * displaced ref + offset, the weights that undo it), the same content with a NEGATIVE weight, a
+    # weight table that does not match the content, shift 0, 10-bit with the offset scaled to the bit depth, a clipped window
+    specs = [
+        # seed sr bd  fen lam     pred      lt        rb        wp (w, offset, shift, round)   fade (gain, offset) applied to cur
+        (31, 8, 8, 1, 57.9, (0, 0), None, None, (52, 17, 6, 32), (52 / 64, 17)),
+        (32, 8, 8, 0, 57.9, (9, -6), None, None, (80, -30, 6, 32), (80 / 64, -30)),
+        (33, 8, 8, 1, 57.9, (0, 0), None, None, (-64, 255, 6, 32), (-1.0, 255)),
+        (34, 8, 8, 1, 238.5, (-14, 3), None, None, (71, 5, 6, 32), (1.0, 0)),
+        (35, 8, 8, 1, 57.9, (0, 0), None, None, (2, -100, 0, 0), (1.0, 0)),
+        (36, 8, 10, 1, 57.9, (4, 4), None, None, (100, -64, 7, 64), (100 / 128, -64)),
+        (37, 8, 10, 0, 4.0e6, (0, 0), (-8, -3), (5, 8), (140, 80, 7, 64), (140 / 128, 80)),
+        (38, 8, 8, 1, 0.0, (0, 0), None, None, (64, 0, 6, 32), (1.0, 0)),
+    ]
+    curs, refs, metas, results = [], [], [], []
+    for (seed, sr, bd, fen, lam, pred, lt, rb, wp, fade) in specs:
+        cur, ref_plane, origin = make_case(seed, sr, bd, "motion")
+        maxv = (1 << bd) - 1
+        cur = np.clip(np.rint(cur.astype(np.float64) * fade[0] + fade[1]), 0, maxv).astype(np.int16)
+        if lt is None:
+            lt, rb = (-sr, -sr), (sr, sr)
+        out = np.zeros((593, 3), np.int64)
+        rs = ref_plane.shape[1]
+        for row in table:
+            slot, x, y, w, h = int(row[0]), int(row[6]), int(row[7]), int(row[8]), int(row[9])
+            mx, my, sad = C.c_int(), C.c_int(), C.c_uint32()
+            R.ref_pattern_search_w(O._addr(cur, y * 64 + x), 64, w, h, O._addr(ref_plane, (origin[1] + y) * rs + origin[0] + x), rs,
+                                   lt[0], lt[1], rb[0], rb[1], pred[0], pred[1], float(lam), fen, bd, *wp, C.byref(mx), C.byref(my), C.byref(sad))
+            out[slot] = (mx.value, my.value, sad.value)
+        curs.append(cur); refs.append(ref_plane); results.append(out)
+        metas.append((seed, sr, bd, fen, pred[0], pred[1], lt[0], lt[1], rb[0], rb[1], origin[0], origin[1], R.ref_lambda_q16(float(lam))) + tuple(wp))
+        print(f"  wp case seed={seed} bd={bd} fen={fen} wp={wp} -> slot592 {out[592].tolist()}")
+    np.savez_compressed(os.path.join(HERE, "wp.npz"), sad_cases=np.array(cases, np.int32), sad_a=np.stack(pa), sad_b=np.stack(pb),
+                        sad_wp=np.array(wps, np.int32), sad=np.array(outs, np.uint32),
+                        sad_columns=np.array("w h sub_shift bit_depth pair x y wp_index".split()),
+                        cur=np.stack(curs), ref=np.stack(refs), meta=np.array(metas, np.int64), out=np.stack(results),
+                        meta_columns=np.array("seed sr bit_depth fen pred_x pred_y lt_x lt_y rb_x rb_y origin_x origin_y lambda_q16 wp_w wp_offset wp_shift wp_round".split()))
+    print("wp:", len(outs), "weighted SADs,", len(specs), "weighted searches")
+
+
 def main():
     global R
     O.build(ref=True)
     R = O.ref()
     if sys.argv[1:] == ["frac_bipred"]:   # this file alone; the slot table comes from the committed slots.npz
         gen_frac_bipred(np.load(os.path.join(HERE, "slots.npz"))["table"])
+        return
+    if sys.argv[1:] == ["wp"]:
+        gen_wp(np.load(os.path.join(HERE, "slots.npz"))["table"])
         return
     table = gen_slots()
     gen_cost()
@@ -372,6 +434,7 @@ def main():
     gen_tz(table)
     gen_frac(table)
     gen_frac_bipred(table)
+    gen_wp(table)
     gen_border()
 
 

@@ -18,6 +18,13 @@ def test_library_exports_every_declared_symbol():
     assert declared == sorted(api.SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name
+    # measurement / test entry points are declared in a header of their own, not in the boundary
+    test_header = open(os.path.join(ROOT, "include", "hmme_test.h")).read()
+    test_declared = sorted(set(re.findall(r"\b(hmme_[a-z0-9_]+)\s*\(", test_header)))
+    assert test_declared == sorted(api.TEST_SYMBOLS) and all(n.startswith("hmme_test_") for n in test_declared)
+    for name in test_declared:
+        assert hasattr(L, name), name
+    assert not re.search(r"hmme_(test|debug|time)_[a-z0-9_]*\s*\(", header)      # mentioned in comments at most, never declared
 
 
 def test_host_search_range_matches_reference_goldens():

@@ -79,6 +79,80 @@ def test_search_ctu_random_windows_vs_oracle(engine, oracle_lib):
             assert tuple(mv[592]) == (dx, dy) and sad[592] == 0
 
 
+def test_weighted_prediction_search_matches_reference_goldens_and_oracle(engine, oracle_lib):
+    """hmme_search_ctu_w == TEncSearch::xPatternSearch with m_cDistParam.bApplyWeight (explicit weighted prediction: every candidate priced
+    by xGetSADw) on all 593 PU rectangles: goldens from the compiled reference (tests/golden/wp.npz: fades and the weights that undo them,
+    a negative weight, a mismatched weight, shift 0, 10 bit, a clipped window), then random weights / windows / search ranges against the
+    oracle, and what the engine must refuse (weighted samples beyond a Pel)."""
+    from hmme import api
+    d = np.load(os.path.join(GOLDEN, "wp.npz"))
+    for i in range(len(d["cur"])):
+        m = dict(zip(d["meta_columns"].tolist(), (int(v) for v in d["meta"][i])))
+        engine.set_lambda_q16(m["lambda_q16"])
+        p = api.SearchParams(m["lt_x"], m["lt_y"], m["rb_x"], m["rb_y"], m["pred_x"], m["pred_y"], m["fen"], m["bit_depth"])
+        wp = (m["wp_w"], m["wp_offset"], m["wp_shift"], m["wp_round"])
+        mv, sad = engine.search_ctu_w(np.ascontiguousarray(d["cur"][i]), (0, 0), np.ascontiguousarray(d["ref"][i]), (m["origin_x"], m["origin_y"]), p, wp)
+        want = d["out"][i]
+        assert np.array_equal(mv.astype(np.int64), want[:, :2]), f"wp case {i}: MV mismatch"
+        assert np.array_equal(sad.astype(np.int64), want[:, 2]), f"wp case {i}: SAD mismatch"
+    rng = np.random.default_rng(4242)
+    refused = 0
+    for it in range(30):
+        bd = int(rng.choice([8, 8, 10, 12]))
+        sr = int(rng.choice([2, 8, 17, 40, 64, 100]))
+        side = 64 + 2 * sr + 8
+        o = sr + 4
+        maxv = (1 << bd) - 1
+        ref = rng.integers(0, maxv + 1, size=(side, side)).astype(np.int16)
+        shift = int(rng.integers(0, 8))
+        denom = 1 << shift
+        w0 = int(rng.integers(-denom, 2 * denom + 1)) if it % 3 else int(rng.integers(-128, 128))
+        wp = (w0, int(rng.integers(-128, 128)) << (bd - 8), shift, denom >> 1)
+        dx, dy = int(rng.integers(-min(sr, 9), min(sr, 9) + 1)), int(rng.integers(-min(sr, 9), min(sr, 9) + 1))
+        blk = ref[o + dy:o + dy + 64, o + dx:o + dx + 64].astype(np.int64)
+        if it % 2:   # the current block IS the weighted reference at (dx, dy), clipped like a real picture, + noise
+            cur = np.clip(((wp[0] * blk + wp[3]) >> wp[2]) + wp[1] + rng.integers(-2, 3, size=(64, 64)), 0, maxv).astype(np.int16)
+        else:
+            cur = rng.integers(0, maxv + 1, size=(64, 64)).astype(np.int16)
+        if it % 7 == 3:   # a bi-prediction origin under weighted prediction: samples in [-maxv, 2 maxv]
+            cur = rng.integers(-maxv, 2 * maxv + 1, size=(64, 64)).astype(np.int16)
+        lt = (-int(rng.integers(0, sr + 1)), -int(rng.integers(0, sr + 1)))
+        rb = (int(rng.integers(0, sr + 1)), int(rng.integers(0, sr + 1)))
+        if it % 4 == 0:
+            lt, rb = (-sr, -sr), (sr, sr)
+        pred = (int(rng.integers(-60, 61)), int(rng.integers(-60, 61)))
+        lam = float(rng.choice([0.0, 57.9, 3000.0]))
+        lq = oracle_lib.oracle().hmo_lambda_q16(lam)
+        engine.set_lambda(lam)
+        fen = int(rng.integers(0, 2))
+        p = api.SearchParams(lt[0], lt[1], rb[0], rb[1], pred[0], pred[1], fen, bd)
+        wlo = min(((w0 * v + wp[3]) >> shift) + wp[1] for v in (0, maxv))
+        whi = max(((w0 * v + wp[3]) >> shift) + wp[1] for v in (0, maxv))
+        try:
+            mv, sad = engine.search_ctu_w(cur, (0, 0), ref, (o, o), p, wp)
+        except api.HmmeError as e:
+            # refusals are allowed only where the engine says so: weighted samples beyond a Pel / 16 bits, or sums beyond the cost field
+            assert ("beyond a Pel" in str(e) and (wlo < -32768 or whi > 32767)) or "cost field" in str(e) or "16 bits" in str(e), (it, wp, str(e))
+            refused += 1
+            continue
+        op = oracle_lib.make_params(lt, rb, pred, lq, fen, bd)
+        ox, oy, osad = oracle_lib.search_ctu_w(cur, (0, 0), ref, (o, o), op, wp)
+        assert np.array_equal(mv[:, 0], ox) and np.array_equal(mv[:, 1], oy), f"iter {it} {wp}: MV mismatch"
+        assert np.array_equal(sad, osad), f"iter {it} {wp}: SAD mismatch"
+    assert refused <= 12
+    # beyond a Pel: refused, never wrapped
+    ref = np.full((88, 88), 1023, np.int16)
+    with pytest.raises(api.HmmeError, match="beyond a Pel"):
+        engine.search_ctu_w(np.zeros((64, 64), np.int16), (0, 0), ref, (12, 12), api.SearchParams(-8, -8, 8, 8, 0, 0, 1, 10), (127, 0, 0, 0))
+    # weight (1 << shift, 0): the unweighted search with every row counted
+    cur = rng.integers(0, 256, size=(64, 64)).astype(np.int16)
+    ref = rng.integers(0, 256, size=(88, 88)).astype(np.int16)
+    engine.set_lambda(57.9)
+    a = engine.search_ctu_w(cur, (0, 0), ref, (12, 12), api.SearchParams(-8, -8, 8, 8, 3, -5, 1, 8), (64, 0, 6, 32))
+    b = engine.search_ctu(cur, (0, 0), ref, (12, 12), api.SearchParams(-8, -8, 8, 8, 3, -5, 0, 8))
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
 def test_ocl_compat_mode_vs_oracle(engine, oracle_lib):
     """the reference GPU path's choices (pred (0,0), window LT..LT+2SR, all rows): cl/sad.cl:374-408"""
     from hmme import api

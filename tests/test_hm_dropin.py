@@ -155,25 +155,31 @@ def test_patched_encoder_gpu_refinement_of_the_biprediction_pass(tmp_path, cfg, 
 
 
 @pytest.mark.gpu
-def test_patched_encoder_leaves_weighted_prediction_slices_to_the_cpu_search(tmp_path):
-    """--WeightedPredP=1 on a fade: HM estimates explicit weights, and its CPU search then prices weighted SADs (xGetSADw,
-    setWpScalingDistParam at TEncSearch.cpp:3740) -- not what the engine (or the reference's kernel) computes.  The patch routes
-    such slices to the CPU search: the bitstream must equal the CPU encoder's bit for bit when every slice is weighted, and
-    HMME_VERIFY must never see a difference."""
+@pytest.mark.parametrize("cfg,wp_flag,frames", [(CFG, "--WeightedPredP=1", 4), (CFG_B, "--WeightedPredB=1", 4)])
+def test_patched_encoder_searches_weighted_prediction_slices_on_the_engine(tmp_path, cfg, wp_flag, frames):
+    """--WeightedPredP/B=1 on a fade: HM estimates explicit weights, and its integer search then prices weighted SADs (xGetSADw,
+    setWpScalingDistParam at TEncSearch.cpp:3740).  Round 4: the patch hands the slice's luma weights to the engine (setWeight ->
+    hmme_search_ctu_w) instead of sending such slices back to the CPU search.  HMME_VERIFY=1 runs HM's OWN xPatternSearch -- with
+    bApplyWeight, i.e. xGetSADw -- beside every engine call: zero differences, on at least as many engine calls as the unweighted
+    encode of the same clip makes, and exhaustive-search quality against --FastSearch=0."""
     _build()
-    common = dict(frames=4, w=208, h=120, cfg=CFG, extra=("--SearchRange=24", "--WeightedPredP=1"), fade=0.12)
+    common = dict(frames=frames, w=208, h=120, cfg=cfg, extra=("--SearchRange=24", wp_flag), fade=0.12)
     r, p = _encode(tmp_path, 1, exe=EXE_HM, env_extra={"HMME_VERIFY": "1"}, **common)
     m = _TRACE.search(r.stderr)
-    calls, failed, edge, bi, verified, differ = (int(v) for v in m.groups()) if m else (0, 0, 0, 0, 0, 0)
-    assert failed == 0 and differ == 0
-    r0, p0 = _encode(tmp_path, 0, exe=EXE_HM, **common)
-    rn, pn = _encode(tmp_path, 1, exe=EXE_HM, **dict(common, extra=("--SearchRange=24",)))          # the same clip without WP: engine in use
+    assert m, r.stderr[-1500:]
+    calls, failed, edge, bi, verified, differ = (int(v) for v in m.groups())
+    assert failed == 0 and differ == 0, m.group(0)
+    assert calls > 0 and verified >= 4 * (calls - edge - bi), m.group(0)
+    assert "weighted prediction" not in r.stderr                       # no call was refused
+    # the slices really carried weights: the same encode without the flag produces another bitstream
+    rn, pn = _encode(tmp_path, 1, exe=EXE_HM, **dict(common, extra=("--SearchRange=24",)))
+    assert pn != p
     mn = _TRACE.search(rn.stderr)
-    assert mn and int(mn.group(1)) > calls, "the weighted run should have sent fewer (or no) CTUs to the engine"
-    weighted_everywhere = calls == 0
-    if weighted_everywhere:      # every P slice carried weights: the patched encoder IS the CPU encoder
-        assert p == p0, (p, p0)
-    print("WP fade:", p, "CPU:", p0, "engine calls with / without WP:", calls, int(mn.group(1)))
+    assert mn and calls >= int(mn.group(1)) // 2, (m.group(0), mn.group(0))   # weighted slices are searched on the engine, not skipped
+    rf, pf = _encode(tmp_path, 0, exe=EXE_HM, **dict(common, extra=("--SearchRange=24", wp_flag, "--FastSearch=0")))
+    bits, bits_full = sum(b for _, b, _ in p[1:]), sum(b for _, b, _ in pf[1:])
+    assert bits < 1.06 * bits_full + 500, (bits, bits_full)
+    print("WP fade on the engine:", p, "\nFastSearch=0:", pf, "\n", m.group(0))
 
 
 @pytest.mark.gpu

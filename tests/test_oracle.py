@@ -90,6 +90,33 @@ def test_full_search_all_slots_sr8(oracle_lib):
     _check_search(oracle_lib, "search_sr8.npz", range(0, 593, 7))
 
 
+def test_weighted_prediction_sads_and_searches(oracle_lib):
+    """explicit weighted prediction: TComRdCostWeightPrediction::xGetSADw (TComRdCostWeightPrediction.cpp:55-90) for every width function,
+    and the reference's xPatternSearch with bApplyWeight on all 593 rectangles (tests/golden/wp.npz, gen_golden.py wp)"""
+    L = oracle_lib.oracle()
+    d = g("wp.npz")
+    for (w, h, sub, bd, pair, x, y, wi), want in zip(d["sad_cases"], d["sad"]):
+        a, b = d["sad_a"][pair], d["sad_b"][pair]
+        off = int(y) * 64 + int(x)
+        wp = oracle_lib.Wp(*[int(v) for v in d["sad_wp"][wi]])
+        got = L.hmo_sad_w(oracle_lib._addr(a, off), 64, oracle_lib._addr(b, off), 64, int(w), int(h), int(bd), C.byref(wp))
+        assert got == int(want), (w, h, sub, bd, pair, wi)      # sub_shift 0 and 1 give the same value: the FEN rows are never skipped
+    table = oracle_lib.slot_table()
+    for i in range(len(d["cur"])):
+        m = dict(zip(d["meta_columns"].tolist(), (int(v) for v in d["meta"][i])))
+        cur, ref = np.ascontiguousarray(d["cur"][i]), np.ascontiguousarray(d["ref"][i])
+        p = oracle_lib.make_params((m["lt_x"], m["lt_y"]), (m["rb_x"], m["rb_y"]), (m["pred_x"], m["pred_y"]), m["lambda_q16"], m["fen"], m["bit_depth"])
+        wp = (m["wp_w"], m["wp_offset"], m["wp_shift"], m["wp_round"])
+        ox, oy, osad = oracle_lib.search_ctu_w(cur, (0, 0), ref, (m["origin_x"], m["origin_y"]), p, wp)
+        want = d["out"][i]
+        assert np.array_equal(ox, want[:, 0]) and np.array_equal(oy, want[:, 1]), f"case {i}: MV mismatch"
+        assert np.array_equal(osad.astype(np.int64), want[:, 2]), f"case {i}: SAD mismatch"
+        for s in range(0, 593, 37):
+            x, y, w, h = (int(v) for v in table[s])
+            got = oracle_lib.pattern_search_w(cur, (x, y), ref, (m["origin_x"] + x, m["origin_y"] + y), w, h, p, wp)
+            assert got == tuple(int(v) for v in want[s]), (i, s)
+
+
 def test_full_search_all_slots_sr64(oracle_lib):
     _check_search(oracle_lib, "search_sr64.npz", (592, 588, 576, 300, 5))
 

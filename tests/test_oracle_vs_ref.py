@@ -37,6 +37,35 @@ def test_random_pu_searches_match_reference(oracle_lib):
             assert oracle_lib.pattern_search(cur, (x, y), ref, (o + x, o + y), w, h, p) == want
 
 
+def test_random_weighted_pu_searches_match_reference(oracle_lib):
+    """live: the reference's xPatternSearch with bApplyWeight (explicit weighted prediction) against the oracle's all-slot and
+    per-PU weighted searches, random weights incl. negative ones and shift 0"""
+    R = oracle_lib.ref()
+    if not hasattr(R, "ref_pattern_search_w"):
+        pytest.skip("libhmref.so predates the weighted-prediction harness")
+    rng = np.random.default_rng(404)
+    table = oracle_lib.slot_table()
+    for it in range(24):
+        bd = int(rng.choice([8, 10]))
+        sr = int(rng.choice([3, 8]))
+        side = 64 + 2 * sr + 8
+        cur = rng.integers(0, 1 << bd, size=(64, 64)).astype(np.int16)
+        ref = rng.integers(0, 1 << bd, size=(side, side)).astype(np.int16)
+        o = sr + 4
+        lam = float(rng.choice([0.0, 57.9, 900.0]))
+        pred = (int(rng.integers(-40, 41)), int(rng.integers(-40, 41)))
+        shift = int(rng.integers(0, 8))
+        wp = (int(rng.integers(-40, 128)), int(rng.integers(-128, 128)) << (bd - 8), shift, (1 << (shift - 1)) if shift else 0)
+        fen = int(rng.integers(0, 2))
+        p = oracle_lib.make_params((-sr, -sr), (sr, sr), pred, R.ref_lambda_q16(lam), fen, bd)
+        ox, oy, osad = oracle_lib.search_ctu_w(cur, (0, 0), ref, (o, o), p, wp)
+        for s in rng.choice(593, size=16, replace=False):
+            x, y, w, h = (int(v) for v in table[s])
+            want = oracle_lib.pattern_search_w(cur, (x, y), ref, (o + x, o + y), w, h, p, wp, use_ref=True, lam=lam)
+            assert (int(ox[s]), int(oy[s]), int(osad[s])) == want, (it, s, wp)
+            assert oracle_lib.pattern_search_w(cur, (x, y), ref, (o + x, o + y), w, h, p, wp) == want
+
+
 def test_cost_and_bits_match_reference(oracle_lib):
     L, R = oracle_lib.oracle(), oracle_lib.ref()
     rng = np.random.default_rng(5)
