@@ -588,7 +588,7 @@ def main():
             # abs-diff operations the kernel performs: every candidate touches each of the CTU's 4096 samples once (FEN halves
             # nothing in the kernel: the even-row sums are the first half of the full sums)
             absdiff = sads * 16 / (kernel_ms * 1e-3)
-            # measured SAD-only ceiling (profiles/r01_valu_lds_rates_ubench.txt, 2 waves/SIMD): v_qsad_pk_u16_u8 issues 0.55
+            # measured SAD-only ceiling (profiles/archive/r01_valu_lds_rates_ubench.txt, 2 waves/SIMD): v_qsad_pk_u16_u8 issues 0.55
             # wave-instructions per ns and CU, 1024 abs-diffs each -> 144e12 abs-diff/s on 256 CUs; v_sad_u16 1.917 per ns and CU,
             # 128 abs-diffs each -> 62.8e12
             ceiling = 144.2e12 if bd == 8 else 62.8e12

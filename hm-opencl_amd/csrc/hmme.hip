@@ -46,7 +46,7 @@ const size_t kLdsBudget16 = lds_budget16_from_env();
 // an immediate).  A lane reads dwords 3 * (lane in row) + 0..33 of its window row, lanes-per-row L = ceil(ceil(wx / 2) / 3), so a
 // row needs 3 * (L - 1) + 34 dwords; the pitch also decides which banks the rows of one wave-wide read share (64 lanes cover 1.5 .. 6
 // window rows): with pitch == 3 * L (mod 32) the 64 lanes form ONE stride-3 progression over the 32 banks and a ds_read2_b32 costs
-// its minimum.  Measured (profiles/r02Y_pdw_sweep.txt, GSAD/s at 2160p 10-bit): SR 128 -- 160: 1 782, 161: 1 812, 162: 1 780,
+// its minimum.  Measured (profiles/archive/r02Y_pdw_sweep.txt, GSAD/s at 2160p 10-bit): SR 128 -- 160: 1 782, 161: 1 812, 162: 1 780,
 // 164..170: 1 698..1 724; SR 64 -- 130: 1 687, 97..106 otherwise: 1 630..1 651.  Four pitches are compiled, the right ones for the
 // full windows of SR 32 / 64 / 96 / 128 (round 2 had two, and SR 32 / 96 ran 5 % below the tuned ranges); any other window takes the
 // smallest pitch that holds it, preferring the right residue (pick_pdw16).
@@ -966,7 +966,7 @@ static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_para
     const int nt = hmme::me_num_tasks(w, w);
     const int k_max = std::max(1, (nt + 3) / 4);   // never below 4 tasks (one per wave) per workgroup
     // in lane-iterations of the slowest wave (4 waves share a piece's tasks); a quarter iteration per workgroup for window load, flush
-    // and merge fits the sweeps of profiles/r02Q_tail_sweep.txt (1440p: 5 pieces beat 1 and 3; 1200p: 17 beat 8; 720p: 2..6 alike)
+    // and merge fits the sweeps of profiles/archive/r02Q_tail_sweeps.txt (1440p: 5 pieces beat 1 and 3; 1200p: 17 beat 8; 720p: 2..6 alike)
     auto part_cost = [&](int k) { return (double)(((nt + k - 1) / k + 3) / 4) + 0.25; };
     const int k = tail_knob > 1 ? std::min(tail_knob, k_max) : plan_tail(tail, slots, 1, k_max, part_cost);
     if (k > 1) { pl->tail_first = jobs - tail; pl->tail_parts = k; }

@@ -30,8 +30,8 @@ constexpr uint32_t kInvCost = 3146751u;  // > any valid cost (<= 1047552 + 65535
 constexpr int kGroups = 10;
 // lane-iterations per task (<= 4: 2 iteration bits in the key).  A task ends with the flush of ten running-minimum registers into the
 // CTU's LDS table; whole-picture launches run 4 per task (measured on 2160p: 1 / 2 / 4 -> 3 252 / 3 256 / 3 284 GSAD/s,
-// profiles/r02f_*), split launches (one CTU dealt to many workgroups, where the number of tasks is the parallelism) 1: the per-CTU
-// call at SR 64 goes from 9 to 17 workgroups of one iteration per wave, 0.086 -> 0.065 ms (profiles/r02l_*)
+// profiles/archive/r02f_*), split launches (one CTU dealt to many workgroups, where the number of tasks is the parallelism) 1: the per-CTU
+// call at SR 64 goes from 9 to 17 workgroups of one iteration per wave, 0.086 -> 0.065 ms (profiles/archive/r02l_*)
 #ifndef ME_ITER_PER_TASK
 #define ME_ITER_PER_TASK 4
 #endif
@@ -1318,7 +1318,7 @@ __device__ __forceinline__ void me_frac_compute(const FracRaw<BPS>& R, const uin
   // Every slot of this position with the same key takes the distortions; the quad's lanes split the slot list.
   // (Round 3 tried to relieve these adds -- the large slots cover many positions, so lanes of one wave often add to the same address:
   // each quad starting its walk at another list position and two points per ds_add_u64 cut the kernel's LDS conflict cycles by 27 %
-  // and its LDS waits by 90 %, and changed its time by -2 % .. +3 %: LDS is busy 10 % of the CU cycles here.  profiles/r03d_frac_ab.txt)
+  // and its LDS waits by 90 %, and changed its time by -2 % .. +3 %: LDS is busy 10 % of the CU cycles here.  profiles/archive/r03d_frac_ab.txt)
   for (int j2 = j + (KIND8 ? role : 0); j2 < NCOV; j2 += KIND8 ? 4 : 1) {
     const int s2 = cov[j2];
     if (j2 == j || ((st[s2] ^ sv) & keymask) == 0) {
@@ -1472,9 +1472,20 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
   if (job_counter) {
     if (tid == 0) *next_job = atomicAdd(job_counter, 1u);
     __syncthreads();                    // (the barrier that ends the previous job's last stage keeps this write behind every read of it)
+    // last jobs first: the jobs at the end of the table are the bottom CTU row of a picture, which is partial whenever the height is
+    // not a multiple of 64 (2160, 1080) -- its slots reach into the padding, find MVs of their own and share little, so such a job
+    // runs 2-3 x as long as its neighbours; dealt last, 60 of them kept the launch alive for a whole extra job time
+    // (profiles/r04k_frac_timeline.txt)
+#ifndef ME_FRAC_FORWARD
+    jb = n_jobs - 1 - (int)*next_job;
+#else
     jb = (int)*next_job;
+#endif
   }
-  if (jb >= n_jobs) break;
+  if (jb >= n_jobs || jb < 0) break;
+#ifdef ME_FRAC_T_TIMELINE   // timing-only build: when does each job start and end (100 MHz wall clock), and in which workgroup
+  const unsigned long long t_job0 = wall_clock64();
+#endif
   MeJob job = jobs[jb];
   const uint8_t* __restrict__ ref_base = refs.base[job.ctu_x & 63];
   const uint8_t* __restrict__ cur_base = curs.base[job.ctu_x & 63];
@@ -1561,6 +1572,14 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
     }
     __syncthreads();   // slot states, cleared sums and list counters are in place before the quarter-pel stage lists its work / the next job starts
   }
+#ifdef ME_FRAC_T_TIMELINE
+  if (tid == 0) {
+    const unsigned long long t1 = wall_clock64();
+    uint32_t* o = out_cost + (long)jb * kParts;
+    o[0] = (uint32_t)t_job0; o[1] = (uint32_t)(t_job0 >> 32); o[2] = (uint32_t)t1; o[3] = (uint32_t)(t1 >> 32); o[4] = blockIdx.x;
+  }
+  __syncthreads();
+#endif
   }   // jobs of this workgroup
 }
 

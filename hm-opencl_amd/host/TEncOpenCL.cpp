@@ -4,14 +4,23 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <time.h>
 
 #include "../../include/hmme.h"
+
+namespace {
+double nowSeconds() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+}  // namespace
 
 TEncOpenCL::TEncOpenCL()
     : m_ctx(0), m_deviceId(0), m_deviceFound(false), m_enabled(false), m_lastOk(false), m_searchRange(0),
       m_mode(ME_MODE_OCL_COMPAT), m_fen(false), m_bitDepth(0), m_inferredDepth(8), m_bi(0), m_lambda(0.0), m_calls(0), m_failed(0), m_edgeCalls(0),
       m_biCalls(0), m_verified(0), m_verifyFailed(0), m_refine(false), m_refineHad(true), m_fracOk(false), m_fracBi(false),
-      m_fracMvTab(0), m_fracDistTab(0), m_fracCostTab(0), m_wpOn(false) {
+      m_fracMvTab(0), m_fracDistTab(0), m_fracCostTab(0), m_wpOn(false), m_wpCalls(0), m_engineSeconds(0.0) {
   m_wp[0] = 1; m_wp[1] = m_wp[2] = m_wp[3] = 0;
   for (Int b = 0; b < 2; b++) {
     xPoison(m_tab[b]);   // tables nobody filled yet must not look like results either
@@ -23,7 +32,8 @@ TEncOpenCL::TEncOpenCL()
 TEncOpenCL::~TEncOpenCL() {
   if (std::getenv("HMME_TRACE"))   // one summary line for A/B harnesses (tests/test_hm_dropin.py)
     fprintf(stderr, "TEncOpenCL(hmme): %ld calcMotionVectors calls, %ld failed, %ld edge-CTU, %ld bi-pred, %ld results verified against xPatternSearch, "
-            "%ld differ, device: %s\n", m_calls, m_failed, m_edgeCalls, m_biCalls, m_verified, m_verifyFailed, m_ctx ? hmme_device_info(m_ctx) : "none");
+            "%ld differ, %.3f s inside the engine calls (%ld weighted), device: %s\n", m_calls, m_failed, m_edgeCalls, m_biCalls, m_verified, m_verifyFailed,
+            m_engineSeconds, m_wpCalls, m_ctx ? hmme_device_info(m_ctx) : "none");
   if (m_ctx) hmme_destroy(m_ctx);
   m_ctx = 0;
   delete[] m_fracMvTab; delete[] m_fracDistTab; delete[] m_fracCostTab;
@@ -152,7 +162,10 @@ Void TEncOpenCL::calcMotionVectors(Pel* pelCtu, Pel* pelSearch, Int iRefStride, 
   m_fracOk = false;
   m_fracBi = m_bi != 0;
   Int rc = HMME_ERR_UNSUPPORTED;
+  const double t0 = nowSeconds();   // wall time of the engine calls of this object: what the offload costs the encoder (tools/hm_ab.py)
+  struct Timer { double& acc; double t0; Timer(double& a, double t) : acc(a), t0(t) {} ~Timer() { acc += nowSeconds() - t0; } } timer(m_engineSeconds, t0);
   if (weighted) {   // no unweighted second try: a failed weighted call must reach the caller as failed
+    ++m_wpCalls;
     hmme_weight w = {m_wp[0], m_wp[1], m_wp[2], m_wp[3]};
     rc = hmme_search_ctu_w(m_ctx, pelCtu, iCtuStride, pelSearch, iRefStride, &p, &w, reinterpret_cast<int16_t*>(t.mv), reinterpret_cast<uint32_t*>(t.cost));
     if (rc != HMME_OK) {

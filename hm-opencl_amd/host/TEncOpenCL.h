@@ -131,6 +131,7 @@ class TEncOpenCL {
   }
   long numCalls() const { return m_calls; }
   long numFailed() const { return m_failed; }
+  double engineSeconds() const { return m_engineSeconds; }
   /// window of the last call (calcMotionVectorsEdge derives it itself)
   const TComMv& getLastLT() const { return m_lastLT; }
   const TComMv& getLastRB() const { return m_lastRB; }
@@ -182,6 +183,8 @@ class TEncOpenCL {
   Distortion (*m_fracCostTab)[33][NUM_CTU_PARTS];
   Bool m_wpOn;                         // explicit weighted prediction for the calls that follow (ME_MODE_HM)
   Int m_wp[4];                         // w, offset, shift, round of the reference picture's luma WPScalingParam
+  long m_wpCalls;
+  double m_engineSeconds;              // wall time spent inside the engine calls (HMME_TRACE summary)
 };
 
 #endif

@@ -986,6 +986,34 @@ def test_bench_starts_its_own_ranks_two_rank_rehearsal_on_one_gpu(tmp_path):
     assert "no GPU of its own" in r2.stderr
 
 
+def test_profiling_tooling_produces_a_counter_summary(tmp_path):
+    """tools/profile_bench.sh + tools/summarize_profile.py -- the only way the counters behind roofline.traffic / valu_roofline are
+    (re)generated -- on a small picture: rocprofv3 kernel trace + two --pmc passes of bench.py (never combined with other trace
+    domains), a per-kernel summary with the derived figures, tied to the loaded library's build id; profiles/latest_pmc_* stay as they are."""
+    import json
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    from hmme import api
+    if not shutil.which("rocprofv3"):
+        pytest.skip("rocprofv3 not on PATH")
+    before = {f: os.path.getmtime(os.path.join(ROOT, "profiles", f)) for f in os.listdir(os.path.join(ROOT, "profiles")) if f.startswith("latest_pmc_")}
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "profile_bench.sh"), "selftest", "quick"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    path = os.path.join(ROOT, "profiles", "selftest_pmc_summary_quick_512x320_sr16.json")
+    d = json.load(open(path))
+    k = d["kernels"]["me_search_kernel"]
+    assert d["library_build_id"] == api.build_id() and k["valu_wave_instructions_per_launch"] > 1e5 and 0.001 < k["valu_busy_frac"] <= 1.0
+    assert 0.005 < k["avg_waves_per_simd"] <= 2.01 and "me_frac_kernel" in d["kernels"]
+    stats = os.path.join(ROOT, "profiles", "selftest_kernel_stats_quick_512x320_sr16.csv")
+    assert "me_search_kernel" in open(stats).read()
+    for f, t in before.items():
+        assert os.path.getmtime(os.path.join(ROOT, "profiles", f)) == t
+    for f in os.listdir(os.path.join(ROOT, "profiles")):     # scratch of this test, not evidence
+        if f.startswith("selftest_"):
+            os.remove(os.path.join(ROOT, "profiles", f))
+
+
 def test_sequence_driver_reads_a_yuv_file(tmp_path):
     """tools/me_sequence.py --yuv: the frame feeder (planar 8-bit 4:2:0 reader, hmme/yuv.py) in front of the sharded sequence
     search; the file holds a texture panning by (2, 1) per picture, which the 64x64 PUs must find"""

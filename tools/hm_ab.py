@@ -79,11 +79,24 @@ def main():
         p_bits = sum(int(b) for p, b, y in pocs if int(p) > 0)
         p_psnr = float(np.mean([float(y) for p, b, y in pocs if int(p) > 0]))
         m = re.search(r"(\d+) calcMotionVectors calls, (\d+) failed, (\d+) edge-CTU, (\d+) bi-pred, (\d+) results verified against xPatternSearch, (\d+) differ", r.stderr)
-        row = {"config": name, "inter_bits": p_bits, "inter_psnr_y": round(p_psnr, 3), "wall_s": round(dt, 2)}
+        me = re.search(r"differ, ([0-9.]+) s inside the engine calls \((\d+) weighted\)", r.stderr)
+        # HM's own clock per picture ("[ET   12 ]", whole seconds) and for the run ("Total Time:   123.456 sec.")
+        et = [int(v) for v in re.findall(r"\[ET\s+(\d+)\s*\]", r.stdout)]
+        tt = re.search(r"Total Time:\s+([0-9.]+) sec", r.stdout)
+        row = {"config": name, "inter_bits": p_bits, "inter_psnr_y": round(p_psnr, 3), "wall_s": round(dt, 2),
+               "hm_total_time_s": float(tt.group(1)) if tt else None, "hm_et_per_picture_s": et,
+               "timing_run": not (args.verify and exe == EXE_HM)}
         if m and int(m.group(1)):
             row.update(dict(zip(("engine_calls", "failed", "edge_ctu_calls", "bipred_calls", "verified", "verify_mismatches"), (int(v) for v in m.groups()))))
+            if me:   # wall time of the engine calls as the encoder saw them (TEncOpenCL's own clock), and what is left for the rest of HM
+                row["engine_seconds"] = float(me.group(1))
+                row["engine_ms_per_call"] = round(1e3 * float(me.group(1)) / int(m.group(1)), 4)
+                row["engine_share_of_wall"] = round(float(me.group(1)) / dt, 5)
+                row["weighted_calls"] = int(me.group(2))
         rows.append(row)
-    print(json.dumps({"clip": f"{w}x{h} x {args.frames} synthetic", "gop": {"P": "low-delay P", "B": "low-delay B", "P4": "low-delay P, 4 references", "RA": "random access, GOP 8"}[args.gop], "search_range": args.search_range, "hm_args": args.hm_args, "runs": rows}, indent=1))
+    print(json.dumps({"clip": f"{w}x{h} x {args.frames} synthetic", "verify": bool(args.verify),
+                      "note": "wall_s of a run with verify = true includes HM's CPU full search beside every engine call: a correctness run, not a timing" if args.verify else
+                              "timing run: HMME_VERIFY off", "gop": {"P": "low-delay P", "B": "low-delay B", "P4": "low-delay P, 4 references", "RA": "random access, GOP 8"}[args.gop], "search_range": args.search_range, "hm_args": args.hm_args, "runs": rows}, indent=1))
 
 
 if __name__ == "__main__":

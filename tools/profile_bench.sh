@@ -28,5 +28,11 @@ profile_one() {   # label, bench arguments...
   python3 tools/summarize_profile.py $out $TAG $label
 }
 
+# quick: the tooling itself on a small picture (tests/test_gpu_parity.py runs this: kernel trace + the SQ pass, summary written, latest_pmc_* untouched)
+if [ "$WHICH" = quick ]; then
+  PASSES=("SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE GRBM_COUNT")
+  profile_one quick_512x320_sr16 --size 512x320 --search-range 16
+  exit 0
+fi
 if [ "$WHICH" = all ] || [ "$WHICH" = 8bit ]; then profile_one 2160p_sr64; fi
 if [ "$WHICH" = all ] || [ "$WHICH" = 10bit ]; then profile_one 2160p_sr128_10bit --bit-depth 10 --search-range 128; fi

@@ -38,5 +38,22 @@ for had in (1, 0):
         eng.refine_frame_multi_device(pc, [pr], fp, None, d_mv.data_ptr(), had, d_q.data_ptr(), d_c.data_ptr(), st)
     e1.record(); torch.cuda.synchronize()
     out["hadamard" if had else "sad"] = round(e0.elapsed_time(e1) / 5, 3)
+if os.environ.get("HMME_TIMELINE"):   # a library built with -DME_FRAC_T_TIMELINE left (start, end, workgroup) of every job in the cost table
+    import numpy as np
+    c = d_c.cpu().numpy().view(np.uint32)
+    t0 = c[:, 0].astype(np.uint64) | (c[:, 1].astype(np.uint64) << 32)
+    t1 = c[:, 2].astype(np.uint64) | (c[:, 3].astype(np.uint64) << 32)
+    wg = c[:, 4]
+    base = t0.min()
+    s_us, e_us = (t0 - base) / 100.0, (t1 - base) / 100.0
+    dur = e_us - s_us
+    per_wg = np.bincount(wg, minlength=int(wg.max()) + 1)
+    first = np.array([s_us[wg == g].min() for g in np.unique(wg)])
+    out["timeline"] = {"jobs": int(n), "kernel_span_us": round(float(e_us.max()), 1), "job_us_mean_min_max_p95": [round(float(v), 1) for v in (dur.mean(), dur.min(), dur.max(), np.percentile(dur, 95))],
+                       "first_job_start_us_mean_max_p95": [round(float(v), 1) for v in (first.mean(), first.max(), np.percentile(first, 95))],
+                       "jobs_per_workgroup_min_max": [int(per_wg[per_wg > 0].min()), int(per_wg.max())], "workgroups": int((per_wg > 0).sum()),
+                       "last_start_us": round(float(s_us.max()), 1), "longest_jobs": [int(v) for v in np.argsort(-dur)[:12]],
+                       "mean_us_bottom_ctu_row": round(float(dur[-((w + 63) // 64):].mean()), 1),
+                       "busy_share": round(float(dur.sum() / (e_us.max() * (per_wg > 0).sum())), 3)}
 frac = (d_q.to(torch.int32) - 4 * d_mv.to(torch.int32)).abs().amax().item()
 print(json.dumps({"size": f"{w}x{h}", "bit_depth": bd, "content": content, "refine_ms": out, "slots_per_s_hadamard": round(n * 593 / (out["hadamard"] * 1e-3)), "max_frac_offset_qpel": frac}))
