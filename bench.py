@@ -88,6 +88,65 @@ def pmc_profile(size, sr, bd):
     return d
 
 
+LIVE_PASSES = ("FETCH_SIZE", "WRITE_SIZE",
+               "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE",
+               "GRBM_GUI_ACTIVE GRBM_COUNT")
+
+
+def live_pmc(extra_args, kernel_name, budget_s=150.0):
+    """The counters of THIS run: after the timed region the benchmark starts `rocprofv3 --kernel-trace --pmc <one pass>` over a short
+    headline-only run of itself (child processes; each counter group in a pass of its own, never combined with other trace domains, as
+    MI355X_MICROARCH.md prescribes) and condenses the per-dispatch means of the search kernel.  {} when rocprofv3 is not there or a
+    pass fails -- the line then falls back to the committed summary of the same library (pmc_profile)."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return {}
+    tmp = tempfile.mkdtemp(prefix="hmme_pmc_")
+    env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+    means, kns = {}, {}
+    t0 = time.time()
+    try:
+        for i, group in enumerate(LIVE_PASSES):
+            if time.time() - t0 > budget_s:
+                return {}
+            out = os.path.join(tmp, f"pass{i}")
+            r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", *group.split(), "--output-format", "csv", "-d", out, "--",
+                                sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", *extra_args],
+                               capture_output=True, text=True, timeout=120, env=env, cwd=tmp)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {}
+            acc, dur = collections.defaultdict(list), {}
+            for row in csv.DictReader(open(files[0])):
+                if kernel_name + "<" not in row["Kernel_Name"]:
+                    continue
+                acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+                dur[row["Dispatch_Id"]] = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+            if not acc:
+                return {}
+            for c, v in acc.items():
+                means[c] = sum(v) / len(v)
+                kns[c] = sum(dur.values()) / len(dur)
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+        return {}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    d = {"seconds": round(time.time() - t0, 1), "passes": list(LIVE_PASSES)}
+    if "FETCH_SIZE" in means and "WRITE_SIZE" in means:   # KiB; on gfx950 FETCH_SIZE reports half of a coalesced stream (the guide's correction)
+        d["hbm_traffic_bytes_per_launch"] = means["FETCH_SIZE"] * 1024 * 2 + means["WRITE_SIZE"] * 1024
+    if "SQ_INSTS_VALU" in means and "GRBM_GUI_ACTIVE" in means:
+        clk = means["GRBM_GUI_ACTIVE"] / 8 / kns["GRBM_GUI_ACTIVE"]          # GHz: the counter sums over the 8 XCDs
+        d.update({"valu_wave_instructions_per_launch": means["SQ_INSTS_VALU"], "effective_clock_ghz": clk,
+                  "valu_busy_frac": means["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * kns["SQ_INSTS_VALU"] * clk),
+                  "avg_waves_per_simd": means["SQ_WAVE_CYCLES"] * 4 / (1024 * kns["SQ_INSTS_VALU"] * clk)})
+    return d
+
+
 def usable_cores():
     """host threads this process may actually run on: affinity mask capped by the cgroup CPU quota"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -210,6 +269,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true", help="headline only: no CPU legs, no oracle check, no extra configurations "
                     "(tools/profile_bench.sh profiles this command)")
     ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE configurations and the refinement contents")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not run the rocprofv3 --pmc passes of this command after the timed region "
+                    "(the counters then come from the committed summary of the same library, if there is one)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-gpu: rehearse the N > 1 code path on a one-GPU box (not a measurement)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
@@ -555,6 +616,15 @@ def main():
         prof = pmc_profile(args.size, sr, bd) if n_refs == 1 else {}
         search_kernel = "me_search_kernel" if bd == 8 else "me_search16_kernel"
         kprof = prof.get("kernels", {}).get(search_kernel, {})
+        # counters of THIS run where the profiler is at hand (N = 1, the full default-style run): child rocprofv3 passes of this very
+        # command; otherwise the committed summary taken on the library with the same build id
+        live = {}
+        if world == 1 and n_refs == 1 and not args.no_cpu_baseline and not args.no_live_pmc:
+            passthrough = ["--size", args.size, "--search-range", str(sr), "--bit-depth", str(bd)]
+            live = live_pmc(passthrough, search_kernel)
+            if live.get("hbm_traffic_bytes_per_launch") is not None:
+                kprof = dict(kprof, **live)
+        same_run = live.get("hbm_traffic_bytes_per_launch") is not None
         traffic = kprof.get("hbm_traffic_bytes_per_launch")
         out = {
             "metric": "GSAD/s", "value": round(total_sads / elapsed / 1e9, 2), "unit": "GSAD/s (4x4-block SAD evaluations)",
@@ -569,7 +639,12 @@ def main():
                        "sads_4x4_per_frame": sads},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": int(traffic) if traffic is not None else None,
-                         "traffic_same_run": False if traffic is not None else None,   # counters: separate rocprofv3 --pmc passes of this command
+                         # counters: separate rocprofv3 --pmc passes of this command -- started by this very run after its timed region
+                         # (true), or taken earlier on the library with the same build id and committed under profiles/ (false)
+                         "traffic_same_run": (same_run if traffic is not None else None),
+                         "traffic_source": (("rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE, WRITE_SIZE: one pass each) of `bench.py --steps 3 --no-cpu-baseline` "
+                                             "started by this run, %.0f s" % live["seconds"]) if same_run else
+                                            ("profiles/latest_pmc_%s.json" % profile_label(args.size, sr, bd) if traffic is not None else None)),
                          "achieved_is": "ALGORITHMIC bytes per launch (SURVEY 8d: CTU + window + results per CTU-search) / kernel time; "
                                         "`traffic` is the MEASURED HBM bytes per launch (neighbouring windows hit the XCD's L2), "
                                         "`traffic_gbs` = traffic / kernel time",
@@ -592,7 +667,7 @@ def main():
             # wave-instructions per ns and CU, 1024 abs-diffs each -> 144e12 abs-diff/s on 256 CUs; v_sad_u16 1.917 per ns and CU,
             # 128 abs-diffs each -> 62.8e12
             ceiling = 144.2e12 if bd == 8 else 62.8e12
-            out["valu_roofline"] = {"bound": "valu-issue", "same_run": False, "valu_busy_frac": round(kprof["valu_busy_frac"], 4),
+            out["valu_roofline"] = {"bound": "valu-issue", "same_run": live.get("valu_busy_frac") is not None, "valu_busy_frac": round(kprof["valu_busy_frac"], 4),
                                     "valu_wave_instructions_per_launch": int(kprof["valu_wave_instructions_per_launch"]),
                                     "effective_clock_ghz": round(kprof.get("effective_clock_ghz", 0.0), 3),
                                     "abs_diff_per_s": round(absdiff, 0),
@@ -602,8 +677,12 @@ def main():
                                     "note": "sad_only_ceiling = the measured issue rate of the leaf instruction alone (v_qsad_pk_u16_u8 / v_sad_u16 "
                                             "micro-benchmarks under profiles/), i.e. a kernel whose reduction tree and arg-min cost nothing; it is "
                                             "0.46 (u8) of SURVEY 8d's paper figure 314.6e12 (v_sad_u8 at 2 cycles per wave-instruction)",
-                                    "source": "profiles/latest_pmc_%s.json (rocprofv3 --pmc passes of this command on the library with the "
+                                    "source": ("rocprofv3 --pmc passes of this command started by this run (library build id %s)" % library_build_id())
+                                              if live.get("valu_busy_frac") is not None else
+                                              "profiles/latest_pmc_%s.json (rocprofv3 --pmc passes of this command on the library with the "
                                               "same build id: %s)" % (profile_label(args.size, sr, bd), library_build_id())}
+            if kprof.get("avg_waves_per_simd") is not None:
+                out["valu_roofline"]["avg_waves_per_simd"] = round(kprof["avg_waves_per_simd"], 3)
         # the step after the path, reported beside the headline, never part of `value`
         d_q = torch.zeros((n_refs, n_ctu, api.NUM_PARTS, 2), dtype=torch.int16, device=dev)
         d_c = torch.zeros((n_refs, n_ctu, api.NUM_PARTS), dtype=torch.int32, device=dev)

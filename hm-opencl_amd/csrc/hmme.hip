@@ -164,8 +164,12 @@ int fail(hmme_ctx* ctx, int code, const char* fmt, ...) {
   } while (0)
 
 template <typename T>
-int ensure(hmme_ctx* ctx, T** p, size_t* cap_bytes, size_t bytes) {
+int ensure(hmme_ctx* ctx, T** p, size_t* cap_bytes, size_t bytes, size_t grow_to = 0) {
   if (bytes <= *cap_bytes) return HMME_OK;
+  // hipFree synchronises the whole device -- in the middle of a streaming pipeline that stalls the copy and download streams.  A
+  // scratch that has to grow therefore grows to `grow_to` at once (the callers pass what kMaxRefs pairs of this picture size need:
+  // KBs to a few MB), so a steady stream meets this path on its first launch of a picture size and never again.
+  if (grow_to > bytes) bytes = grow_to;
   if (*p) hipFree(*p);
   *p = nullptr; *cap_bytes = 0;
   HIP_TRY(ctx, hipMalloc((void**)p, bytes));
@@ -232,7 +236,8 @@ int finalize_best(hmme_ctx* ctx, const unsigned long long* d_best, const MeJob16
 int merge_table(hmme_ctx* ctx, int n_jobs, unsigned long long* preset, hipStream_t stream, unsigned long long** table) {
   if (preset) { *table = preset; return HMME_OK; }
   size_t cap = ctx->best_cap;
-  int rc = ensure(ctx, &ctx->d_best, &cap, sizeof(unsigned long long) * HMME_NUM_CTU_PARTS * (size_t)n_jobs);
+  int rc = ensure(ctx, &ctx->d_best, &cap, sizeof(unsigned long long) * HMME_NUM_CTU_PARTS * (size_t)n_jobs,
+                  n_jobs > 64 ? sizeof(unsigned long long) * HMME_NUM_CTU_PARTS * (size_t)n_jobs * 2 : 0);
   ctx->best_cap = cap;
   if (rc) return rc;
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_best, 0xFF, sizeof(unsigned long long) * HMME_NUM_CTU_PARTS * (size_t)n_jobs, stream));
@@ -339,6 +344,17 @@ int check_frame_args(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref
   return HMME_OK;
 }
 
+// Range violations are latched on the device: flag 0 by the synchronous uploads (taken right behind the fill, on its stream), flag 1
+// by the asynchronous ones (taken by hmme_upload_status) -- a bad sample of an asynchronous upload can no longer fail the next
+// synchronous upload of another, valid plane.  Read and clear are one atomic exchange on the stream (me_take_flag_kernel).
+int take_flag(hmme_ctx* ctx, int which, hipStream_t s, int* out) {
+  hipLaunchKernelGGL(hmme::me_take_flag_kernel, dim3(1), dim3(1), 0, s, ctx->d_flag + which, ctx->d_flag + 2);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_flag + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  return HMME_OK;
+}
+
 template <typename SrcT, typename DstT>
 int plane_fill(hmme_plane* pl, const SrcT* d_src, int src_pitch_elems, hipStream_t s, bool check) {
   hmme_ctx* ctx = pl->ctx;
@@ -346,18 +362,15 @@ int plane_fill(hmme_plane* pl, const SrcT* d_src, int src_pitch_elems, hipStream
   if (wrc) return wrc;
   dim3 grid((pl->pitch / 4 + 255) / 256, pl->rows);
   hipLaunchKernelGGL((hmme::me_fill_plane_kernel<SrcT, DstT>), grid, dim3(256), 0, s, pl->d_data, pl->pitch, kMarginX, kMarginY,
-                     pl->width, pl->height, d_src, src_pitch_elems, (1 << pl->bit_depth) - 1, ctx->d_flag);
+                     pl->width, pl->height, d_src, src_pitch_elems, (1 << pl->bit_depth) - 1, ctx->d_flag + (check ? 0 : 1));
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(pl->filled, s));
   pl->fill_stream = s; pl->fill_pending = true;
   if (check) {
     int flag = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&flag, ctx->d_flag, sizeof flag, hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
-    if (flag) {
-      HIP_TRY(ctx, hipMemset(ctx->d_flag, 0, sizeof(int)));
-      return fail(ctx, HMME_ERR_RANGE, "plane upload: sample outside [0,%d] for a %d-bit plane", (1 << pl->bit_depth) - 1, pl->bit_depth);
-    }
+    const int rc = take_flag(ctx, 0, s, &flag);
+    if (rc) return rc;
+    if (flag) return fail(ctx, HMME_ERR_RANGE, "plane upload: sample outside [0,%d] for a %d-bit plane", (1 << pl->bit_depth) - 1, pl->bit_depth);
   }
   return HMME_OK;
 }
@@ -433,8 +446,8 @@ int hmme_create(int device, int sr_max, unsigned flags, hmme_ctx** out) {
   CREATE_TRY(hipHostMalloc(&ctx->h_res, kResBytes, hipHostMallocMapped));
   std::memset(ctx->h_res, 0, kResBytes);
   CREATE_TRY(hipHostGetDevicePointer((void**)&ctx->d_res, ctx->h_res, 0));
-  CREATE_TRY(hipMalloc(&ctx->d_flag, sizeof(int)));
-  CREATE_TRY(hipMemset(ctx->d_flag, 0, sizeof(int)));
+  CREATE_TRY(hipMalloc(&ctx->d_flag, 4 * sizeof(int)));   // [0] synchronous uploads, [1] asynchronous uploads, [2] take_flag's result
+  CREATE_TRY(hipMemset(ctx->d_flag, 0, 4 * sizeof(int)));
 #undef CREATE_TRY
   *out = ctx;
   return HMME_OK;
@@ -847,10 +860,9 @@ int hmme_upload_status(hmme_ctx* ctx, void* stream) {
   if (!ctx) return HMME_ERR_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int flag = 0;
-  HIP_TRY(ctx, hipMemcpyAsync(&flag, ctx->d_flag, sizeof flag, hipMemcpyDeviceToHost, (hipStream_t)stream));
-  HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+  const int rc = take_flag(ctx, 1, (hipStream_t)stream, &flag);
+  if (rc) return rc;
   if (!flag) return HMME_OK;
-  HIP_TRY(ctx, hipMemset(ctx->d_flag, 0, sizeof(int)));
   return fail(ctx, HMME_ERR_RANGE, "an asynchronous plane upload carried a sample outside the range of its plane's bit depth");
 }
 
@@ -980,12 +992,13 @@ static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_para
     need = pl->tail_jobs_off + sizeof(MeJob16) * (size_t)n_tail * pl->tail_parts;
   }
   size_t cap = ctx->jobs_bytes;
-  int rc = ensure(ctx, (uint8_t**)&ctx->d_jobs, &cap, need);
+  const size_t per_ref = n_refs > 0 ? (need + n_refs - 1) / n_refs : need;   // what kMaxRefs pairs of this picture size would ask for
+  int rc = ensure(ctx, (uint8_t**)&ctx->d_jobs, &cap, need, per_ref * hmme::kMaxRefs + 4096);
   ctx->jobs_bytes = cap;
   if (rc) return rc;
   if (wide || pl->tile8 || n_tail) {
     size_t fcap = (size_t)ctx->first_strip_cap * sizeof(int);
-    rc = ensure(ctx, &ctx->d_first_strip, &fcap, sizeof(int) * (size_t)jobs);
+    rc = ensure(ctx, &ctx->d_first_strip, &fcap, sizeof(int) * (size_t)jobs, sizeof(int) * (size_t)(jobs / (n_refs > 0 ? n_refs : 1) + 1) * hmme::kMaxRefs);
     ctx->first_strip_cap = (int)(fcap / sizeof(int));
     if (rc) return rc;
   }
@@ -1177,7 +1190,8 @@ int hmme_refine_pairs_device(hmme_ctx* ctx, const hmme_plane* const* curs, const
   rc = build_frac_cover(ctx);
   if (rc == HMME_OK) {
     size_t cap = ctx->jobs_bytes;
-    rc = ensure(ctx, (uint8_t**)&ctx->d_jobs, &cap, sizeof(MeJob) * (size_t)jobs + 64);   // + the launch's job counter behind the table
+    rc = ensure(ctx, (uint8_t**)&ctx->d_jobs, &cap, sizeof(MeJob) * (size_t)jobs + 64,   // + the launch's job counter behind the table
+                sizeof(MeJob) * (size_t)pl.count * hmme::kMaxRefs + 4096);
     ctx->jobs_bytes = cap;
   }
   if (rc == HMME_OK) {

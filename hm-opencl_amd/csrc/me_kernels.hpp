@@ -748,6 +748,10 @@ __global__ void me_weight_window_kernel(uint8_t* __restrict__ win, int pitch, in
   *p = (uint16_t)(((w0 * (int)*p + round) >> shift) + offset_bias);
 }
 
+// read-and-clear of a latched range-violation flag in one step: a fill kernel on another stream that sets it concurrently is either
+// seen by this take or by the next one, never lost between a read and a separate clear
+__global__ void me_take_flag_kernel(int* flag, int* out) { *out = atomicExch(flag, 0); }
+
 // single-job finalize (one workgroup) that writes the results straight into mapped pinned host memory and then publishes a
 // sequence number there: the host polls that word instead of sleeping in hipStreamSynchronize
 __global__ void __launch_bounds__(640)

@@ -186,7 +186,8 @@ int hmme_plane_upload_u8(hmme_plane* plane, const uint8_t* origin, int stride);
  * bit depth.  The host buffer must stay untouched until the copy has run (the caller's event on `stream`) and should be page-locked
  * (hmme_host_register), otherwise the runtime stages it and the call blocks.  Ordering against searches that still read the
  * plane's previous contents on another stream is the library's (see "Streams").  A sample outside the plane's range cannot be
- * reported by this call: it is latched and returned -- once -- by the next hmme_upload_status (or synchronous upload). */
+ * reported by this call: it is latched and returned -- once -- by the next hmme_upload_status (a latch of its own: synchronous
+ * uploads of other planes neither see nor clear it). */
 int hmme_plane_upload_async(hmme_plane* plane, const void* origin, int stride, int sample_bytes, void* stream);
 /* waits for `stream`; HMME_ERR_RANGE if an upload since the last check carried an out-of-range sample */
 int hmme_upload_status(hmme_ctx* ctx, void* stream);

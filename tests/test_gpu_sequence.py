@@ -436,6 +436,18 @@ def test_async_upload_reports_out_of_range_samples_once(engine):
     with pytest.raises(api.HmmeError, match="range"):
         engine.upload_status(s.cuda_stream)
     engine.upload_status(s.cuda_stream)                      # latched once, then clear
+    # the latch of the asynchronous uploads is their own: a bad asynchronous upload does not fail the next SYNCHRONOUS upload of
+    # another, valid plane (round 3 shared one flag), and that synchronous upload does not swallow the violation either
+    other = engine.plane(w, h, 10)
+    pl.upload_async(bad.data_ptr(), w, 2, s.cuda_stream)
+    s.synchronize()
+    other.upload_pel(good.numpy(), (0, 0))
+    with pytest.raises(api.HmmeError, match="range"):
+        engine.upload_status(s.cuda_stream)
+    with pytest.raises(api.HmmeError, match="outside"):     # and a bad synchronous upload reports at once, leaving the other latch alone
+        other.upload_pel(bad.numpy(), (0, 0))
+    engine.upload_status(s.cuda_stream)
+    other.close()
     with pytest.raises(api.HmmeError):
         pl.upload_async(good.data_ptr(), w, 3, s.cuda_stream)
     pl.close()
