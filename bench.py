@@ -29,7 +29,6 @@ random-access sequence streamed through one GPU) and the refinement kernel on co
 unrelated content (`refine`).
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -317,19 +316,11 @@ def self_launch(args):
 
 
 def device_identity(torch, local_rank):
-    """what proves that a rank ran on a device of its own: name, PCI bus id (hipDeviceGetPCIBusId) and uuid of its GPU"""
+    """what proves that a rank ran on a device of its own: name, PCI address and uuid of its GPU (from the runtime torch already holds:
+    no second HIP library is loaded for this)"""
     props = torch.cuda.get_device_properties(local_rank)
-    ident = {"name": props.name, "uuid": str(getattr(props, "uuid", "")), "cus": int(getattr(props, "multi_processor_count", 0))}
-    try:
-        hip = ctypes.CDLL("libamdhip64.so")
-        buf = ctypes.create_string_buffer(64)
-        if hip.hipDeviceGetPCIBusId(buf, 64, ctypes.c_int(local_rank)) == 0:
-            ident["pci_bus_id"] = buf.value.decode()
-    except OSError:
-        pass
-    if "pci_bus_id" not in ident:
-        ident["pci_bus_id"] = "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0))
-    return ident
+    return {"name": props.name, "uuid": str(getattr(props, "uuid", "")), "cus": int(getattr(props, "multi_processor_count", 0)),
+            "pci_bus_id": "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0))}
 
 
 def size_of(args_size):
