@@ -526,6 +526,52 @@ int hmme_slot_index(int part_size, int depth, int part_idx, int abs_z_idx) {
   return slot_of(part_size, depth, part_idx, bx / s4, by / s4);
 }
 
+// ---- the table layout of an encoder built with AMP_ENC_SPEEDUP (TypeDef.h:206, :260-261: NUM_CTU_PARTS 425; cl/sad.cl:4-138 `calcSAD`,
+// TComDataCU.cpp:3393-4675).  Dead in the reference tree as shipped (the macro is 0), kept as a VIEW of the 593 tables: the same
+// rectangles without the AMP shapes.  Bases per CU size 8 / 16 / 32 / 64: 2NxN 0 / 320 / 400 / 420, Nx2N 128 / 352 / 408 / 422,
+// 2Nx2N 256 / 384 / 416 / 424; inside a family the order of the 593 layout -- except that the reference's table numbers the two
+// parts of the 64x64 2NxN and Nx2N CUs in reverse (part 1 before part 0: TComDataCU.cpp:3396-3410), which is reproduced.
+int hmme_slot_index_amp_off(int part_size, int depth, int part_idx, int abs_z_idx) {
+  if (part_size < 0 || part_size > 2 || part_idx < 0 || part_idx > 1 || (part_size == 0 && part_idx)) return -1;
+  const int full = hmme_slot_index(part_size, depth, part_idx, abs_z_idx);
+  if (full < 0) return -1;
+  static const int base593[3][4] = {{592, 584, 544, 384}, {588, 560, 448, 0}, {590, 568, 480, 128}};     // [part size][depth]
+  static const int base425[3][4] = {{424, 416, 384, 256}, {420, 400, 320, 0}, {422, 408, 352, 128}};
+  int in_family = full - base593[part_size][depth];
+  if (depth == 0 && part_size != 0) in_family ^= 1;
+  return base425[part_size][depth] + in_family;
+}
+
+int hmme_amp_off_slot(int index_amp_off) {   // which of the 593 slots holds table entry `index_amp_off` of the 425 layout; -1 out of range
+  static int map[425];
+  static bool built = false;
+  if (!built) {   // idempotent fill: concurrent first calls write the same values
+    for (int i = 0; i < 425; ++i) map[i] = -1;
+    for (int depth = 0; depth < 4; ++depth) {
+      const int n = 1 << depth, s4 = 16 >> depth;
+      for (int cy = 0; cy < n; ++cy)
+        for (int cx = 0; cx < n; ++cx) {
+          int z = 0;   // raster (4x4 units) -> z-order
+          for (int b = 0; b < 4; ++b) z |= (((cx * s4) >> b) & 1) << (2 * b) | (((cy * s4) >> b) & 1) << (2 * b + 1);
+          for (int ps = 0; ps < 3; ++ps)
+            for (int pi = 0; pi < (ps ? 2 : 1); ++pi) map[hmme_slot_index_amp_off(ps, depth, pi, z)] = hmme_slot_index(ps, depth, pi, z);
+        }
+    }
+    built = true;
+  }
+  return index_amp_off >= 0 && index_amp_off < 425 ? map[index_amp_off] : -1;
+}
+
+int hmme_compact_amp_off(const int16_t* mv593, const uint32_t* sad593, int16_t* mv425, uint32_t* sad425) {
+  if (!mv593 || !sad593 || !mv425 || !sad425) return HMME_ERR_ARG;
+  for (int i = 0; i < 425; ++i) {
+    const int s = hmme_amp_off_slot(i);
+    mv425[2 * i] = mv593[2 * s]; mv425[2 * i + 1] = mv593[2 * s + 1];
+    sad425[i] = sad593[s];
+  }
+  return HMME_OK;
+}
+
 int hmme_slot_rect(int slot, int* x, int* y, int* w, int* h) {
   if (!x || !y || !w || !h) return HMME_ERR_ARG;
   static const int part_sizes[7] = {0, 1, 2, 4, 5, 6, 7};

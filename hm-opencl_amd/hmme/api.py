@@ -17,7 +17,7 @@ NUM_PARTS = 593
 # every symbol include/hmme.h declares (tests check the library exports all of them)
 SYMBOLS = ["hmme_create", "hmme_destroy", "hmme_last_error", "hmme_device_info", "hmme_set_lambda",
            "hmme_set_lambda_q16", "hmme_get_lambda_q16", "hmme_params_ocl_compat", "hmme_set_search_range",
-           "hmme_slot_index", "hmme_slot_rect", "hmme_search_ctu", "hmme_search_ctu_w", "hmme_search_refine_ctu", "hmme_refine_ctu", "hmme_plane_create", "hmme_plane_create_ex", "hmme_plane_bit_depth", "hmme_plane_destroy", "hmme_plane_upload_pel",
+           "hmme_slot_index", "hmme_slot_rect", "hmme_slot_index_amp_off", "hmme_amp_off_slot", "hmme_compact_amp_off", "hmme_search_ctu", "hmme_search_ctu_w", "hmme_search_refine_ctu", "hmme_refine_ctu", "hmme_plane_create", "hmme_plane_create_ex", "hmme_plane_bit_depth", "hmme_plane_destroy", "hmme_plane_upload_pel",
            "hmme_plane_upload_u8", "hmme_host_register", "hmme_host_unregister", "hmme_plane_set_device_u8", "hmme_plane_width", "hmme_plane_height",
            "hmme_num_ctus", "hmme_search_frame", "hmme_search_frame_device", "hmme_search_frame_multi",
            "hmme_search_frame_multi_device", "hmme_refine_frame", "hmme_refine_frame_multi_device",

@@ -39,7 +39,9 @@ TEncOpenCL::~TEncOpenCL() {
   delete[] m_fracMvTab; delete[] m_fracDistTab; delete[] m_fracCostTab;
 }
 
-Bool TEncOpenCL::slotRect(Int slot, Int& x, Int& y, Int& w, Int& h) { return hmme_slot_rect(slot, &x, &y, &w, &h) == HMME_OK; }
+Bool TEncOpenCL::slotRect(Int slot, Int& x, Int& y, Int& w, Int& h) {   // `slot` in the caller's layout
+  return hmme_slot_rect(NUM_CTU_PARTS == 593 ? slot : hmme_amp_off_slot(slot), &x, &y, &w, &h) == HMME_OK;
+}
 Bool TEncOpenCL::hmModeEnabled() {
   static const Int on = (std::getenv("HMME_HM_MODE") && std::getenv("HMME_HM_MODE")[0] == '0') ? 0 : 1;
   return on != 0;
@@ -167,7 +169,7 @@ Void TEncOpenCL::calcMotionVectors(Pel* pelCtu, Pel* pelSearch, Int iRefStride, 
   if (weighted) {   // no unweighted second try: a failed weighted call must reach the caller as failed
     ++m_wpCalls;
     hmme_weight w = {m_wp[0], m_wp[1], m_wp[2], m_wp[3]};
-    rc = hmme_search_ctu_w(m_ctx, pelCtu, iCtuStride, pelSearch, iRefStride, &p, &w, reinterpret_cast<int16_t*>(t.mv), reinterpret_cast<uint32_t*>(t.cost));
+    rc = hmme_search_ctu_w(m_ctx, pelCtu, iCtuStride, pelSearch, iRefStride, &p, &w, reinterpret_cast<int16_t*>(m_engMv), reinterpret_cast<uint32_t*>(m_engCost));
     if (rc != HMME_OK) {
       fprintf(stderr, "ERROR: TEncOpenCL::calcMotionVectors (weighted prediction): %s\n", hmme_last_error(m_ctx));
       xPoison(t);
@@ -175,21 +177,27 @@ Void TEncOpenCL::calcMotionVectors(Pel* pelCtu, Pel* pelSearch, Int iRefStride, 
     }
   }
   if (wantFrac) {
-    rc = hmme_search_refine_ctu(m_ctx, pelCtu, iCtuStride, pelSearch, iRefStride, &p, m_refineHad ? 1 : 0, reinterpret_cast<int16_t*>(t.mv),
-                                reinterpret_cast<uint32_t*>(t.cost), reinterpret_cast<int16_t*>(m_qmv), reinterpret_cast<uint32_t*>(m_fracCost));
+    rc = hmme_search_refine_ctu(m_ctx, pelCtu, iCtuStride, pelSearch, iRefStride, &p, m_refineHad ? 1 : 0, reinterpret_cast<int16_t*>(m_engMv),
+                                reinterpret_cast<uint32_t*>(m_engCost), reinterpret_cast<int16_t*>(m_engQmv), reinterpret_cast<uint32_t*>(m_engFracCost));
     m_fracOk = rc == HMME_OK;
     m_fracPred = m_pred;
   }
   if (rc != HMME_OK && !weighted)
-    rc = hmme_search_ctu(m_ctx, pelCtu, iCtuStride, pelSearch, iRefStride, &p, reinterpret_cast<int16_t*>(t.mv), reinterpret_cast<uint32_t*>(t.cost));
+    rc = hmme_search_ctu(m_ctx, pelCtu, iCtuStride, pelSearch, iRefStride, &p, reinterpret_cast<int16_t*>(m_engMv), reinterpret_cast<uint32_t*>(m_engCost));
   if (rc != HMME_OK) {
     fprintf(stderr, "ERROR: TEncOpenCL::calcMotionVectors: %s\n", hmme_last_error(m_ctx));
     xPoison(t);
     return;
   }
-  for (Int i = 0; i < NUM_CTU_PARTS; i++) {   // the reference hands out Int arrays (TEncOpenCL.h:118-119)
+  typedef char known_table_size[(NUM_CTU_PARTS == 593 || NUM_CTU_PARTS == 425) ? 1 : -1];
+  (void)sizeof(known_table_size);
+  for (Int i = 0; i < NUM_CTU_PARTS; i++) {   // the caller's layout; the reference hands out Int arrays (TEncOpenCL.h:118-119)
+    const Int s = NUM_CTU_PARTS == 593 ? i : hmme_amp_off_slot(i);
+    t.mv[i] = m_engMv[s];
+    t.cost[i] = m_engCost[s];
     t.x[i] = t.mv[i].getHor();
     t.y[i] = t.mv[i].getVer();
+    if (m_fracOk) { m_qmv[i] = m_engQmv[s]; m_fracCost[i] = m_engFracCost[s]; }
   }
   m_lastOk = true;
   --m_failed;

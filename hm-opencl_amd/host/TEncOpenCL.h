@@ -173,6 +173,10 @@ class TEncOpenCL {
   Tables m_tab[2];                     // [0] uni-prediction, [1] bi-prediction refinement
   Int m_tagPoc[2][33], m_tagCtu[2][33];
   Bool m_refine, m_refineHad, m_fracOk, m_fracBi;
+  // what the engine returns: always the 593-slot layout.  The tables above are NUM_CTU_PARTS entries in the caller's layout: the same
+  // 593, or the 425 of an encoder built with AMP_ENC_SPEEDUP (TypeDef.h:260-261), filled through hmme_amp_off_slot
+  TComMv m_engMv[593], m_engQmv[593];
+  Distortion m_engCost[593], m_engFracCost[593];
   TComMv m_qmv[NUM_CTU_PARTS];
   Distortion m_fracCost[NUM_CTU_PARTS];
   TComMv m_fracPred;                   // predictor the refinement of the last call priced its MVs against

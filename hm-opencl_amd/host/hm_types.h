@@ -14,7 +14,9 @@ typedef short Short;
 typedef double Double;
 typedef Short Pel;            // TypeDef.h:706 (RExt__HIGH_BIT_DEPTH_SUPPORT == 0)
 typedef UInt Distortion;      // TypeDef.h:717 (FULL_NBIT == 0)
-#define NUM_CTU_PARTS 593     // TypeDef.h:263
+#ifndef NUM_CTU_PARTS
+#define NUM_CTU_PARTS 593     // TypeDef.h:263 (425 in a build with AMP_ENC_SPEEDUP, TypeDef.h:260-261: -DNUM_CTU_PARTS=425)
+#endif
 
 class TComMv {                // {Short hor, Short ver}, TComMv.h:51-55
  public:

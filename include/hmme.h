@@ -132,6 +132,14 @@ void hmme_set_search_range(int pred_x_q, int pred_y_q, int search_range, int cu_
 int hmme_slot_index(int part_size, int depth, int part_idx, int abs_z_idx);
 /* rectangle of a slot inside the 64x64 CTU; returns 0 or HMME_ERR_ARG */
 int hmme_slot_rect(int slot, int* x, int* y, int* w, int* h);
+/* The 425-entry table layout of an encoder built with AMP_ENC_SPEEDUP (TypeDef.h:206, :260-261; TComDataCU.cpp:3393-4675; the
+ * reference's `calcSAD` kernel, cl/sad.cl:4-138) -- the macro is 0 in the reference tree as shipped, so this is a view for such a
+ * build, not a second search: the same rectangles as the 593 layout without the AMP shapes.  hmme_slot_index_amp_off = that build's
+ * getIndexBlock (-1 for what it does not tabulate); hmme_amp_off_slot maps an entry of the 425 layout to the slot of the 593
+ * layout that holds the same rectangle; hmme_compact_amp_off turns a call's 593 results into the 425 tables. */
+int hmme_slot_index_amp_off(int part_size, int depth, int part_idx, int abs_z_idx);
+int hmme_amp_off_slot(int index_amp_off);
+int hmme_compact_amp_off(const int16_t* mv593, const uint32_t* sad593, int16_t* mv425, uint32_t* sad425);
 
 /* ---- per-CTU drop-in (host buffers, HM `Pel` = int16) --------------------------------- */
 /* ctu: 64x64 current block (TEncSearch.cpp:3747); ref_at_ctu_origin: reference plane at the CTU

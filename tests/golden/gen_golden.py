@@ -392,12 +392,35 @@ def gen_wp(table):
     print("wp:", len(outs), "weighted SADs,", len(specs), "weighted searches")
 
 
+def gen_slots_amp_off():
+    """The 425-entry table of a reference build with AMP_ENC_SPEEDUP (TComDataCU.cpp:3393-4675, compiled out in the tree as shipped, so it
+    cannot be called): the (key, index) pairs of its switch, read from the source text -- data, like slots.npz.
+    key = ((((partSize + 10*depth + 100*partIdx)*1000 + absZIdx)*100 + height)*100 + width (TComDataCU.cpp:3379-3391)."""
+    import re
+    src = open("/root/reference/source/Lib/TLibCommon/TComDataCU.cpp").read().split("\n")
+    seg = "\n".join(src[3392:4676])
+    pairs = re.findall(r"case\s+(\d+):\s*\n\s*index\s*=\s*(\d+);", seg)
+    rows = []
+    for k, i in pairs:
+        k = int(k)
+        w, h, z, t = k % 100, (k // 100) % 100, (k // 10000) % 1000, k // 10000000
+        rows.append((int(i), t % 10, (t // 10) % 10, t // 100, z, h, w))
+    rows.sort()
+    assert len(rows) == 425 and [r[0] for r in rows] == list(range(425))
+    np.savez_compressed(os.path.join(HERE, "slots_amp_off.npz"), table=np.array(rows, np.int32),
+                        columns=np.array("index part_size depth part_idx abs_z_idx height width".split()))
+    print("slots_amp_off:", len(rows))
+
+
 def main():
     global R
     O.build(ref=True)
     R = O.ref()
     if sys.argv[1:] == ["frac_bipred"]:   # this file alone; the slot table comes from the committed slots.npz
         gen_frac_bipred(np.load(os.path.join(HERE, "slots.npz"))["table"])
+        return
+    if sys.argv[1:] == ["slots_amp_off"]:
+        gen_slots_amp_off()
         return
     if sys.argv[1:] == ["wp"]:
         gen_wp(np.load(os.path.join(HERE, "slots.npz"))["table"])
@@ -435,6 +458,7 @@ def main():
     gen_frac(table)
     gen_frac_bipred(table)
     gen_wp(table)
+    gen_slots_amp_off()
     gen_border()
 
 

@@ -37,6 +37,39 @@ def test_host_search_range_matches_reference_goldens():
         assert api.set_search_range(px, py, sr, cu_x, cu_y, pw, ph) == tuple(int(v) for v in r[8:12])
 
 
+def test_amp_off_table_view_matches_the_reference_table():
+    """the 425-entry layout of a reference build with AMP_ENC_SPEEDUP (TComDataCU.cpp:3393-4675; tests/golden/slots_amp_off.npz holds the
+    425 (key -> index) pairs of that switch): hmme_slot_index_amp_off reproduces it, incl. the reversed part order of the 64x64 2NxN /
+    Nx2N CUs; every entry maps to the 593-layout slot with the same rectangle; compaction moves results accordingly (no GPU needed)"""
+    from hmme import api
+    api.build()
+    L = api.load()
+    L.hmme_slot_index_amp_off.argtypes = [C.c_int] * 4
+    L.hmme_amp_off_slot.argtypes = [C.c_int]
+    t = np.load(os.path.join(GOLDEN, "slots_amp_off.npz"))["table"]
+    assert len(t) == 425
+    seen = set()
+    for idx, ps, depth, pi, z, h, w in (tuple(int(v) for v in r) for r in t):
+        assert L.hmme_slot_index_amp_off(ps, depth, pi, z) == idx, (idx, ps, depth, pi, z)
+        slot = L.hmme_amp_off_slot(idx)
+        assert slot == api.slot_index(ps, depth, pi, z) and 0 <= slot < 593 and slot not in seen
+        seen.add(slot)
+        x, y, rw, rh = api.slot_rect(slot)
+        assert h == w == 64 >> depth and (rw, rh) == ((w, h) if ps == 0 else ((w, h // 2) if ps == 1 else (w // 2, h)))
+    assert L.hmme_slot_index_amp_off(1, 0, 1, 0) == 420 and L.hmme_slot_index_amp_off(1, 0, 0, 0) == 421      # part 1 before part 0 at 64x64
+    for ps in (3, 4, 5, 6, 7):
+        assert L.hmme_slot_index_amp_off(ps, 1, 0, 0) == -1                                                     # no NxN, no AMP shapes
+    assert L.hmme_amp_off_slot(425) == -1 and L.hmme_amp_off_slot(-1) == -1
+    mv = np.arange(593 * 2, dtype=np.int16).reshape(593, 2)
+    sad = np.arange(593, dtype=np.uint32) * 7
+    mv4, sad4 = np.zeros((425, 2), np.int16), np.zeros(425, np.uint32)
+    L.hmme_compact_amp_off.argtypes = [C.c_void_p] * 4
+    assert L.hmme_compact_amp_off(mv.ctypes.data, sad.ctypes.data, mv4.ctypes.data, sad4.ctypes.data) == 0
+    for i in range(425):
+        s_ = L.hmme_amp_off_slot(i)
+        assert tuple(mv4[i]) == tuple(mv[s_]) and sad4[i] == sad[s_]
+
+
 def test_ocl_compat_preset():
     # reference: TEncOpenCL.cpp:312-313 (x,y in [0,2*SR]), cl/sad.cl:374-398 (pred 0, all rows)
     from hmme import api

@@ -301,6 +301,21 @@ def test_cpp_host_module_tencopencl(oracle_lib):
     assert "PASS" in r.stdout
 
 
+def test_cpp_host_module_for_an_encoder_built_with_amp_enc_speedup(oracle_lib):
+    """the same class compiled with -DNUM_CTU_PARTS=425 (an HM built with AMP_ENC_SPEEDUP, TypeDef.h:260-261): its tables are the 425
+    entries of that build's getIndexBlock (TComDataCU.cpp:3393-4675), filled from the engine's 593 results; against the oracle"""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tests", "cpp", "test_tencopencl_amp_off")
+    subprocess.run(["g++", "-O2", "-std=c++11", "-DNUM_CTU_PARTS=425", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_tencopencl_amp_off.cpp"),
+                    os.path.join(ROOT, "hm-opencl_amd", "host", "TEncOpenCL.cpp"),
+                    "-L" + os.path.join(ROOT, "hm-opencl_amd", "csrc"), "-lhmme", "-L" + os.path.join(ROOT, "oracle"), "-loracle",
+                    "-Wl,-rpath," + os.path.join(ROOT, "hm-opencl_amd", "csrc"), "-Wl,-rpath," + os.path.join(ROOT, "oracle")], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "PASS" in r.stdout
+
+
 def test_16bit_path_random_windows_vs_oracle(engine, oracle_lib):
     """bit depth 10 / 12 (v_sad_u16 kernel): ragged windows up to SR 128, FEN 0/1, strips"""
     from hmme import api
