@@ -18,9 +18,6 @@
 #include <set>
 #include <thread>
 
-#ifndef __HIP_PLATFORM_AMD__
-#define __HIP_PLATFORM_AMD__ 1
-#endif
 #include <hip/hip_runtime_api.h>
 
 namespace hmme_host {

@@ -212,7 +212,7 @@ def test_cpp_sequence_driver_is_clean_under_asan_and_ubsan(tmp_path):
     exe = str(tmp_path / "seq_plan_asan")
     csrc = os.path.join(ROOT, "hm-opencl_amd", "csrc")
     subprocess.run(["g++", "-O1", "-g", "-std=c++11", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
-                    "-I/opt/rocm/include", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_sequence_plan.cpp"),
+                    "-D__HIP_PLATFORM_AMD__=1", "-I/opt/rocm/include", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_sequence_plan.cpp"),
                     os.path.join(ROOT, "hm-opencl_amd", "host", "SequenceME.cpp"), os.path.join(ROOT, "hm-opencl_amd", "host", "MultiDeviceME.cpp"),
                     "-L" + csrc, "-lhmme", "-Wl,-rpath," + csrc, "-L/opt/rocm/lib", "-lrccl", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"], check=True)
     supp = tmp_path / "lsan.supp"
