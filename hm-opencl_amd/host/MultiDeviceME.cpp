@@ -106,6 +106,10 @@ int MultiDeviceSearch::run(const std::vector<std::pair<int, int> >& pairs, const
     return fail(HMME_ERR_ARG, "kGatherRccl needs distinct devices (RCCL refuses one GPU twice in a communicator); use kGatherPeer for a rehearsal");
   const size_t per_pair = (size_t)n_ctu_ * HMME_NUM_CTU_PARTS, pair_bytes = 4 * per_pair;
   const int n_tables = cfg_.refine ? 4 : 2;
+  if (n_pairs == 0) {   // nothing to search: an empty result, not an allocation of zero bytes
+    if (stats) { *stats = MultiDeviceStats(); stats->pairs_per_device.assign(world, 0); stats->device_seconds.assign(world, 0.0); }
+    return HMME_OK;
+  }
 
   // ---- one context, one sequence driver, one exchange stream per rank (kept between runs; a failed set-up leaves nothing behind)
   if (ctx_.empty()) {

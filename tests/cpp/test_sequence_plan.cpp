@@ -130,6 +130,11 @@ int main() {
     if (dup.run(ra, [](int) { return LumaReader(); }, 0) != HMME_ERR_ARG || dup.error().find("distinct") == std::string::npos) { printf("FAIL: RCCL gather with one device twice\n"); rc = 1; }
     MultiDeviceSearch empty(none, cfg, kGatherPeer, 57.9);
     if (empty.run(ra, [](int) { return LumaReader(); }, 0) != HMME_ERR_ARG) { printf("FAIL: no devices\n"); rc = 1; }
+    std::vector<std::pair<int, int> > nothing;
+    MultiDeviceStats ms;
+    if (empty.run(nothing, [](int) { return LumaReader(); }, &ms) != HMME_ERR_ARG) { printf("FAIL: no devices, no pairs\n"); rc = 1; }
+    MultiDeviceSearch idle(twice, cfg, kGatherPeer, 57.9);
+    if (idle.run(nothing, [](int) { return LumaReader(); }, &ms) != HMME_OK || ms.pairs_per_device.size() != 2) { printf("FAIL: empty pair list\n"); rc = 1; }
     std::vector<int> far(1, 1000);   // a device that does not exist: hmme_create fails, run() reports it, nothing leaks
     MultiDeviceSearch nodev(far, cfg, kGatherHost, 57.9);
     if (nodev.run(ra, [](int) { return LumaReader(); }, 0) != HMME_ERR_DEVICE || nodev.error().empty()) { printf("FAIL: missing device\n"); rc = 1; }
