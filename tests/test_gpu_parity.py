@@ -588,6 +588,29 @@ def test_fractional_refinement_vs_oracle(engine, oracle_lib, use_had, sr, use_pr
     assert checked > 1000
 
 
+@pytest.mark.parametrize("bd,use_had", [(8, 1), (8, 0), (10, 1)])
+def test_fractional_refinement_partial_sharing_every_slot_vs_oracle(engine, oracle_lib, bd, use_had):
+    """content on which the slots of a CTU share SOME of their work (24-sample regions of their own motion under noise): 8x8 items, the
+    4x4-kind slots that ride on them and 4x4 items of their own coexist in every CTU.  Every slot of every CTU (partial right column
+    and bottom row included) against the oracle's xPatternSearchFracDIF."""
+    from hmme import synth
+    w, h, sr = 328, 200, 12
+    cur, ref, _ = synth.make_pair(w, h, seed=91 + bd, bit_depth=bd, max_mv=8, region=24, noise_sigma=6.0)
+    m = synth.MARGIN
+    engine.set_lambda(57.9)
+    lq = engine.lambda_q16
+    with engine.plane(w, h, bd) as pc, engine.plane(w, h, bd) as pr:
+        pc.upload_pel(cur, (m, m)); pr.upload_pel(ref, (m, m))
+        mv, sad = engine.search_frame(pc, pr, sr, None)
+        qmv, cost = engine.refine_frame(pc, pr, sr, mv, None, use_hadamard=bool(use_had))
+    oq, oc = oracle_lib.refine_frame(cur, ref, (m, m), w, h, mv, None, lq, use_had, bd, n_threads=16)
+    assert np.array_equal(qmv, oq), np.argwhere(qmv != oq)[:5]
+    assert np.array_equal(cost, oc), np.argwhere(cost != oc)[:5]
+    # the content does what the test is for: neither one MV per CTU nor one per slot
+    distinct = [len({tuple(v) for v in mv[c]}) for c in range(mv.shape[0])]
+    assert 3 < np.median(distinct) < 300, distinct
+
+
 def test_refinement_multi_reference_and_errors(engine):
     """device entry point with two references in one launch == two single-reference calls; unsupported inputs fail loudly"""
     import torch
