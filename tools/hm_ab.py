@@ -34,6 +34,8 @@ def main():
                                                 "GPU box must keep writing under gpurun_out/)")
     ap.add_argument("--hm-args", default="", help="extra TAppEncoder arguments for every configuration, e.g. '--Profile=main10 --InternalBitDepth=10'")
     ap.add_argument("--only", default=None, help="run only the configurations whose name contains this text (e.g. GPU_FRAC)")
+    ap.add_argument("--fade", type=float, default=0.0, help="fade the clip to black by this fraction per picture (what explicit weighted prediction is for; "
+                                                            "combine with --hm-args '--WeightedPredP=1 --WeightedPredB=1')")
     ap.add_argument("--verify", action="store_true", help="HMME_VERIFY=1 on the patched encoder (slower: runs HM's xPatternSearch beside the engine)")
     args = ap.parse_args()
     CFG = CFGS[args.gop]
@@ -44,6 +46,8 @@ def main():
     for t in range(args.frames):   # textured content with per-region motion that grows over time + noise
         cur, _, _ = synth.make_pair(w, h, seed=11, max_mv=2, region=96, noise_sigma=1.5, shift=(3 * t, -2 * t),
                                     pad=3 * args.frames + 8, margin=0)
+        if args.fade:
+            cur = np.clip(np.rint(cur * max(0.0, 1.0 - args.fade * t)), 0, 255)
         pics.append(cur.astype(np.uint8))
     yuv.write_luma_420(src, pics)
     rows = []
@@ -96,7 +100,7 @@ def main():
         rows.append(row)
     print(json.dumps({"clip": f"{w}x{h} x {args.frames} synthetic", "verify": bool(args.verify),
                       "note": "wall_s of a run with verify = true includes HM's CPU full search beside every engine call: a correctness run, not a timing" if args.verify else
-                              "timing run: HMME_VERIFY off", "gop": {"P": "low-delay P", "B": "low-delay B", "P4": "low-delay P, 4 references", "RA": "random access, GOP 8"}[args.gop], "search_range": args.search_range, "hm_args": args.hm_args, "runs": rows}, indent=1))
+                              "timing run: HMME_VERIFY off", "gop": {"P": "low-delay P", "B": "low-delay B", "P4": "low-delay P, 4 references", "RA": "random access, GOP 8"}[args.gop], "search_range": args.search_range, "hm_args": args.hm_args, "fade_per_picture": args.fade, "runs": rows}, indent=1))
 
 
 if __name__ == "__main__":
