@@ -116,6 +116,7 @@ struct hmme_ctx {
   bool lds_optin[8] = {false, false, false, false, false, false, false, false};
   int num_cus = 0;
   int frac_wg_per_cu[2][2] = {{0, 0}, {0, 0}};   // [wide][hadamard] workgroups of me_frac_kernel a CU holds (runtime occupancy query, first use)
+  uint8_t* d_wwin = nullptr;          // per-CTU calls with weighted prediction: the weighted copy of the staged window (the search's)
   uint16_t* d_frac_cover = nullptr;   // fractional refinement: slots covering each 8x8 / 4x4 position, same for every CTU
   int16_t* d_imv = nullptr;           // host-facing refine call: integer MVs / quarter-pel MVs / costs on the device
   int16_t* d_qmv = nullptr;
@@ -461,7 +462,7 @@ void hmme_destroy(hmme_ctx* ctx) {
   hipFree(ctx->d_call);
   hipFree(ctx->d_jobs); hipFree(ctx->d_first_strip); hipFree(ctx->d_best);
   hipFree(ctx->d_pred); hipFree(ctx->d_mv); hipFree(ctx->d_sad); hipFree(ctx->d_flag);
-  hipFree(ctx->d_frac_cover); hipFree(ctx->d_imv); hipFree(ctx->d_qmv); hipFree(ctx->d_fcost);
+  hipFree(ctx->d_wwin); hipFree(ctx->d_frac_cover); hipFree(ctx->d_imv); hipFree(ctx->d_qmv); hipFree(ctx->d_fcost);
   if (ctx->h_call) hipHostFree(ctx->h_call);
   if (ctx->h_res) hipHostFree(ctx->h_res);
   delete ctx;
@@ -602,11 +603,13 @@ int hmme_slot_rect(int slot, int* x, int* y, int* w, int* h) {
 // ---- per-CTU drop-in ---------------------------------------------------------------------------------
 namespace {
 int build_frac_cover(hmme_ctx* ctx);
-using frac_fn = void (*)(const RefSet, int, const RefSet, int, const MeJob*, int, uint32_t*, const uint16_t*, const int16_t*, uint32_t, int, int16_t*, uint32_t*);
-inline frac_fn frac_kernel(int wide, int had) {
-  static const frac_fn fns[2][2] = {{hmme::me_frac_kernel<0, 1>, hmme::me_frac_kernel<1, 1>}, {hmme::me_frac_kernel<0, 2>, hmme::me_frac_kernel<1, 2>}};
-  return fns[wide ? 1 : 0][had ? 1 : 0];
+using frac_fn = void (*)(const RefSet, int, const RefSet, int, const MeJob*, int, uint32_t*, const uint16_t*, const int16_t*, uint32_t, int, const hmme::FracWp, int16_t*, uint32_t*);
+inline frac_fn frac_kernel(int wide, int had, int wp = 0) {
+  static const frac_fn fns[2][2] = {{hmme::me_frac_kernel<0, 1, 0>, hmme::me_frac_kernel<1, 1, 0>}, {hmme::me_frac_kernel<0, 2, 0>, hmme::me_frac_kernel<1, 2, 0>}};
+  static const frac_fn fns_wp[2] = {hmme::me_frac_kernel<0, 2, 1>, hmme::me_frac_kernel<1, 2, 1>};   // weighted calls always stage u16 samples
+  return wp ? fns_wp[had ? 1 : 0] : fns[wide ? 1 : 0][had ? 1 : 0];
 }
+const hmme::FracWp kNoWp = {0.f, 0.f, 0.f};
 // workgroups of a refinement launch: as many as the chip holds at a time (the runtime's occupancy figure for this kernel with its
 // LDS block x the CUs), each walking every grid-th job; HMME_FRAC_GRID=<n> forces a grid (0 = one workgroup per job, as before round 4)
 int frac_grid(hmme_ctx* ctx, int wide, int had, int jobs) {
@@ -647,7 +650,7 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
              const hmme_weight* wp = nullptr) {
   if (!ctx) return HMME_ERR_ARG;
   const bool refine = refine_had >= 0;
-  if (wp && (!do_search || refine)) return fail(ctx, HMME_ERR_UNSUPPORTED, "weighted prediction: integer search only (the refinement prices xGetHADsw, not built)");
+  if (wp && !do_search) return fail(ctx, HMME_ERR_UNSUPPORTED, "weighted prediction: refinement of caller-supplied integer MVs is not built (search + refinement is)");
   if (wp && (wp->shift < 0 || wp->shift > 15)) return fail(ctx, HMME_ERR_ARG, "weighted prediction: shift %d outside 0..15", wp->shift);
   if (!ctu || !ref0 || !p || (do_search && (!out_mv || !out_sad)) || (refine && (!out_qmv || !out_cost)) || (!do_search && !int_mv))
     return fail(ctx, HMME_ERR_ARG, "hmme_search_ctu: null argument");
@@ -718,6 +721,9 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
     const long span = std::max<long>((long)hi - wlo, whi - (long)lo);
     if (((4096 * span) >> (shift_bd - 8)) + 65535 >= (long)hmme::kInvCost16)
       return fail(ctx, HMME_ERR_UNSUPPORTED, "weighted SADs of this block could reach %ld: beyond the cost field", 4096 * span);
+    // the refinement's Hadamard sums are exact in fp32 below 2^24: 64 coefficients of up to 64 * span each
+    if (refine && 4096 * span >= (1L << 24))
+      return fail(ctx, HMME_ERR_UNSUPPORTED, "weighted refinement: sample differences up to %ld exceed what the Hadamard sums hold exactly", span);
   }
   // unshifted sums must fit the 24-bit cost field of the 16-bit kernel's keys (me_kernels.hpp kInvCost16).  The bound is taken
   // from the samples of THIS call (both scans are made anyway): no |cur - ref| exceeds max(hi - vlo, vhi - lo), so any content whose
@@ -775,14 +781,16 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
     const int n16 = (int)((kCallWin + (size_t)rows * kWinPitch + 64 + 15) / 16);
     hipLaunchKernelGGL(hmme::me_stage_call_kernel, dim3((n16 + 255) / 256), dim3(256), 0, s, (const uint4*)ctx->h_call_dev, (uint4*)ctx->d_call, n16);
     HIP_TRY(ctx, hipGetLastError());
-    if (wp) {
-      hipLaunchKernelGGL(hmme::me_weight_window_kernel, dim3((rows * cols + 255) / 256), dim3(256), 0, s, ctx->d_call + kCallWin, (int)kWinPitch, rows, cols,
-                         wp->w0, wp->round, wp->shift, wp->offset + bias);
+    if (wp) {   // the weighted window the integer search runs on; the raw one stays where it is for the refinement's interpolation
+      if (!ctx->d_wwin) HIP_TRY(ctx, hipMalloc(&ctx->d_wwin, (size_t)kWinRows * kWinPitch + 64));
+      hipLaunchKernelGGL(hmme::me_weight_window_kernel, dim3((rows * cols + 255) / 256), dim3(256), 0, s, (const uint8_t*)(ctx->d_call + kCallWin), ctx->d_wwin,
+                         (int)kWinPitch, rows, cols, wp->w0, wp->round, wp->shift, wp->offset + bias);
       HIP_TRY(ctx, hipGetLastError());
     }
   }
   // the kernel addresses ref(ctu + lt): bias the base so that (lt_x, lt_y) lands on the window copy's first sample
   const uint8_t* ref_base = ctx->d_call + kCallWin - (long)(p->lt_y - halo) * kWinPitch - (long)(p->lt_x - halo) * bps;
+  const uint8_t* ref_base_search = wp ? ctx->d_wwin - (long)(p->lt_y - halo) * kWinPitch - (long)(p->lt_x - halo) * bps : ref_base;
   const MeJob16* d_js = (const MeJob16*)(ctx->d_call + kCallJobs);
   const int* d_first = (const int*)(ctx->d_call + kCallFirst);
   unsigned long long* d_best1 = (unsigned long long*)(ctx->d_call + kCallBest);
@@ -795,7 +803,7 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
   if (!wide)
     rc = launch_search8_split(ctx, one_ref(ctx->d_call + kCallCtu), 64, one_ref(ref_base), kWinPitch, d_js, d_first, 1, n_wg, p->fen, d_mv1, d_sad1, s, d_best1, false);
   else
-    rc = launch_search16(ctx, one_ref(ctx->d_call + kCallCtu), 128, one_ref(ref_base), kWinPitch, d_js, d_first, 1, n_wg, pdw, smax, wp ? 0 : p->fen, shift_bd,   // xGetSADw reads every row
+    rc = launch_search16(ctx, one_ref(ctx->d_call + kCallCtu), 128, one_ref(ref_base_search), kWinPitch, d_js, d_first, 1, n_wg, pdw, smax, wp ? 0 : p->fen, shift_bd,   // xGetSADw reads every row
                          d_mv1, d_sad1, s, d_best1, false);
   if (rc) return rc;
   hipLaunchKernelGGL(hmme::me_finalize1_kernel, dim3(1), dim3(640), 0, s, d_best1, d_js, ctx->lambda_q16, d_mv1, d_sad1,
@@ -808,9 +816,11 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
     rc = build_frac_cover(ctx);
     if (rc) return rc;
     const int16_t* d_imv = do_search ? d_mv1 : (const int16_t*)(ctx->d_call + kCallImv);
-    hipLaunchKernelGGL(frac_kernel(wide ? 1 : 0, refine_had ? 1 : 0), dim3(1), dim3(hmme::frac_threads(bps)), hmme::frac_lds_bytes(bps), s, one_ref(ctx->d_call + kCallCtu),
+    // weighted: the interpolated prediction is weighted sample by sample (me_frac_eval, FracWp); the current samples carry `bias`, the raw window none
+    const hmme::FracWp fw = wp ? hmme::FracWp{std::ldexp((float)wp->w0, -wp->shift), std::ldexp((float)wp->round, -wp->shift), (float)(bias + wp->offset)} : kNoWp;
+    hipLaunchKernelGGL(frac_kernel(wide ? 1 : 0, refine_had ? 1 : 0, wp ? 1 : 0), dim3(1), dim3(hmme::frac_threads(bps)), hmme::frac_lds_bytes(bps), s, one_ref(ctx->d_call + kCallCtu),
                        64 * bps, one_ref(ref_base), kWinPitch, (const MeJob*)(ctx->d_call + kCallFracJob), 1, (uint32_t*)nullptr, ctx->d_frac_cover, d_imv, ctx->lambda_q16,
-                       p->bit_depth | (bipred_origin ? 0x100 : 0), (int16_t*)(ctx->d_res + kResQmv), (uint32_t*)(ctx->d_res + kResCost));
+                       p->bit_depth | ((bipred_origin && !wp) ? 0x100 : 0), fw, (int16_t*)(ctx->d_res + kResQmv), (uint32_t*)(ctx->d_res + kResCost));
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(hmme::me_publish_kernel, dim3(1), dim3(1), 0, s, (volatile uint32_t*)(ctx->d_res + kResDone2), seq);
     HIP_TRY(ctx, hipGetLastError());
@@ -843,6 +853,12 @@ int hmme_search_ctu_w(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const i
                       const hmme_search_params* p, const hmme_weight* wp, int16_t* out_mv, uint32_t* out_sad) {
   if (ctx && !wp) return fail(ctx, HMME_ERR_ARG, "hmme_search_ctu_w: null weight");
   return ctu_call(ctx, ctu, ctu_stride, ref0, ref_stride, p, true, nullptr, -1, out_mv, out_sad, nullptr, nullptr, wp);
+}
+
+int hmme_search_refine_ctu_w(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref0, int ref_stride, const hmme_search_params* p,
+                             const hmme_weight* wp, int use_hadamard, int16_t* out_mv, uint32_t* out_sad, int16_t* out_qmv, uint32_t* out_cost) {
+  if (ctx && !wp) return fail(ctx, HMME_ERR_ARG, "hmme_search_refine_ctu_w: null weight");
+  return ctu_call(ctx, ctu, ctu_stride, ref0, ref_stride, p, true, nullptr, use_hadamard ? 1 : 0, out_mv, out_sad, out_qmv, out_cost, wp);
 }
 
 int hmme_search_refine_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref0, int ref_stride, const hmme_search_params* p,
@@ -1249,7 +1265,7 @@ int hmme_refine_pairs_device(hmme_ctx* ctx, const hmme_plane* const* curs, const
     hipLaunchKernelGGL(frac_kernel(wide, had), dim3(grid), dim3(hmme::frac_threads(wide ? 2 : 1)), hmme::frac_lds_bytes(wide ? 2 : 1), s, pl.curs,
                        curs[0]->pitch, pl.refs, refs[0]->pitch, (const MeJob*)ctx->d_jobs, jobs, grid < jobs ? counter : (uint32_t*)nullptr, ctx->d_frac_cover,
                        (const int16_t*)d_int_mv, ctx->lambda_q16,
-                       fp->bit_depth, (int16_t*)d_out_qmv, (uint32_t*)d_out_cost);
+                       fp->bit_depth, kNoWp, (int16_t*)d_out_qmv, (uint32_t*)d_out_cost);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) rc = fail(ctx, HMME_ERR_DEVICE, "refinement launch -> %s", hipGetErrorString(e));
   }

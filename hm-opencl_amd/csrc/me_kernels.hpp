@@ -738,14 +738,15 @@ __global__ void me_stage_call_kernel(const uint4* __restrict__ host_block, uint4
 // explicit weighted prediction (TEncSearch::setWpScalingDistParam, TEncSearch.cpp:5594-5635): the search of a slice with weighted
 // prediction prices |org - (((w0 * ref + round) >> shift) + offset)| (TComRdCostWeightPrediction::xGetSADw,
 // TComRdCostWeightPrediction.cpp:79-81).  The prediction of a sample does not depend on the candidate, so the staged window of a
-// per-CTU call is weighted ONCE, in place (u16 samples, `bias` added so that block and window stay unsigned), and the 16-bit search
+// per-CTU call is weighted ONCE, into a second buffer (u16 samples, `bias` added so that block and window stay unsigned), and the 16-bit search
 // kernel runs on it unchanged.
-__global__ void me_weight_window_kernel(uint8_t* __restrict__ win, int pitch, int rows, int cols, int w0, int round, int shift, int offset_bias) {
+__global__ void me_weight_window_kernel(const uint8_t* __restrict__ win, uint8_t* __restrict__ out, int pitch, int rows, int cols, int w0, int round,
+                                        int shift, int offset_bias) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * cols) return;
   const int y = i / cols, x = i - y * cols;
-  uint16_t* p = (uint16_t*)(win + (long)y * pitch) + x;
-  *p = (uint16_t)(((w0 * (int)*p + round) >> shift) + offset_bias);
+  const uint16_t v = ((const uint16_t*)(win + (long)y * pitch))[x];
+  ((uint16_t*)(out + (long)y * pitch))[x] = (uint16_t)(((w0 * (int)v + round) >> shift) + offset_bias);   // the raw window stays: the refinement interpolates IT
 }
 
 // read-and-clear of a latched range-violation flag in one step: a fill kernel on another stream that sets it concurrently is either
@@ -1015,12 +1016,18 @@ __device__ __forceinline__ uint32_t me_frac_dist(const float (&d)[16], float s1,
 // 2^23, so fp32 is exact and v_fmac_f32 issues at the full VALU rate where v_mad_i32_i24 does not
 // (tools/ubench/valu_rates3).  bd = bit depth of the video (8 when BPS == 1): the two passes shift by bd-8 and
 // 20-bd around the 14-bit intermediate (TComInterpolationFilter.cpp:170-212: headRoom = 14 - bd).
+// explicit weighted prediction in the refinement (xGetHADsw / xGetSADw, TComRdCostWeightPrediction.cpp:407-470, :55-90): the interpolated,
+// clipped prediction p is weighted sample by sample, pred = ((w0 * p + round) >> shift) + offset, before the difference is taken.
+// ws = w0 * 2^-shift, rs = round * 2^-shift: fma(ws, p, rs) IS (w0 * p + round) / 2^shift exactly (|w0 * p + round| < 2^24), v_floor_f32
+// the shift; org_sub = what to take off a staged current sample: its staging bias + offset.  WP = 0: none of this is compiled in.
+struct FracWp { float ws, rs, org_sub; };
 constexpr float kRoundMagic = 12582912.0f;   // 1.5 * 2^23: x + magic rounds x to the nearest integer (ties to even)
 // KIND8: the lane is one quadrant (role 0..3 = TL, TR, BL, BR) of an 8x8 Hadamard block; all four lanes of the quad
 // return the block's distortion.  out[point]: distortion of the 9 refinement points in HM's point order.
-template <int STAGE, int HAD, int BPS, int KIND8>
+template <int STAGE, int HAD, int BPS, int KIND8, int WP>
 __device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3 * BPS], const float (&orgM)[16], int cqx, int cqy, int role, int bd, float clip_lo,
-                                             const uint32_t* tab_h, const float* tab_v, bool want4, uint32_t (&out)[9], uint32_t (&out4)[9]) {
+                                             const uint32_t* tab_h, const float* tab_v, bool want4, const FracWp wp, uint32_t (&out)[9],
+                                             uint32_t (&out4)[9]) {
   constexpr int step = STAGE == 0 ? 2 : 1, PW = 3 * BPS;
   // point index of (dx, dy) in s_acMvRefineH / s_acMvRefineQ order (reference TEncSearch.cpp:51-75)
   constexpr int idxH[3][3] = {{5, 1, 6}, {3, 0, 4}, {7, 2, 8}}, idxQ[3][3] = {{3, 1, 4}, {5, 0, 6}, {7, 2, 8}};   // [dy+1][dx+1]
@@ -1107,8 +1114,8 @@ __device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3 * BPS], c
             if (STAGE == 0 && me_tap9(step * (dyi - 1), j) == 0) continue;
             a = __builtin_fmaf(cv[j], tmp[r + j][c], a);
           }
-          const float y = __builtin_amdgcn_fmed3f(a, clip_lo, maxv);   // clip, then round (the bounds are integers)
-          d[4 * r + c] = orgM[4 * r + c] - (y + kRoundMagic);
+          const float y = __builtin_amdgcn_fmed3f(a, clip_lo, maxv) + kRoundMagic;   // clip, then round (the bounds are integers)
+          d[4 * r + c] = orgM[4 * r + c] - (WP ? __builtin_floorf(__builtin_fmaf(wp.ws, y - kRoundMagic, wp.rs)) : y);
         }
       uint32_t own4 = 0;
       const uint32_t contrib = me_frac_dist<HAD, KIND8>(d, s1, s2, want4, own4);
@@ -1138,9 +1145,9 @@ constexpr uint32_t kFracKey0 = 0x3ffffu, kFracKey1 = 0x3fffffu;
 // five rows of each column (rows above 0..3 and below 3) instead of 2 x 4, and every filtered value is rounded and clipped once, not once
 // per point that reads it: 396 second-pass FMAs instead of 816, 165 first-pass dot products instead of 264.  Same values as
 // me_frac_eval<0, ...> bit for bit: every intermediate is exact in fp32 (me_frac_eval's header), so the order of summation is free.
-template <int HAD, int BPS, int KIND8>
+template <int HAD, int BPS, int KIND8, int WP>
 __device__ __forceinline__ void me_frac_eval0(const uint32_t (&P)[12][3 * BPS], const float (&orgM)[16], int role, int bd, float clip_lo,
-                                              bool want4, uint32_t (&out)[9], uint32_t (&out4)[9]) {
+                                              bool want4, const FracWp wp, uint32_t (&out)[9], uint32_t (&out4)[9]) {
   constexpr int PW = 3 * BPS;
   constexpr int idxH[3][3] = {{5, 1, 6}, {3, 0, 4}, {7, 2, 8}};   // [dy+1][dx+1], s_acMvRefineH order (TEncSearch.cpp:51-75)
   const float s1 = (role & 1) ? -1.f : 1.f, s2 = (role & 2) ? -1.f : 1.f;
@@ -1168,7 +1175,10 @@ __device__ __forceinline__ void me_frac_eval0(const uint32_t (&P)[12][3 * BPS], 
     }
     return (float)(BPS == 1 ? a : a >> sh1);
   };
-  auto clipround = [&](float a) -> float { return __builtin_amdgcn_fmed3f(a, clip_lo, maxv) + kRoundMagic; };
+  auto clipround = [&](float a) -> float {
+    const float y = __builtin_amdgcn_fmed3f(a, clip_lo, maxv) + kRoundMagic;
+    return WP ? __builtin_floorf(__builtin_fmaf(wp.ws, y - kRoundMagic, wp.rs)) : y;   // WP: orgM carries no magic either (me_frac_compute)
+  };
   // one point: d = org - pred over the 4x4 block, pred(r, c) = y[r0 + r][c0 + c]
 #define ME_FRAC_POINT(Y, R0, C0, DYI, DXI)                                                   \
   {                                                                                          \
@@ -1264,9 +1274,9 @@ __device__ __forceinline__ void me_frac_fetch(const uint8_t* __restrict__ src, i
   R.o = o;
 }
 
-template <int STAGE, int HAD, int BPS, int KIND8>
+template <int STAGE, int HAD, int BPS, int KIND8, int WP>
 __device__ __forceinline__ void me_frac_compute(const FracRaw<BPS>& R, const uint32_t* curl, const uint32_t* st, const uint16_t* cover, int pair, int role,
-                                                int bd, float clip_lo, const uint32_t* tab_h, const float* tab_v, uint32_t* acc) {
+                                                int bd, float clip_lo, const FracWp wp, const uint32_t* tab_h, const float* tab_v, uint32_t* acc) {
   constexpr int PW = 3 * BPS, NCOV = KIND8 ? kFracCover8 : kFracCover4;
   constexpr uint32_t keymask = STAGE ? kFracKey1 : kFracKey0;
   const int q = KIND8 ? pair : pair - kFracPairs8;
@@ -1279,17 +1289,18 @@ __device__ __forceinline__ void me_frac_compute(const FracRaw<BPS>& R, const uin
   for (int r = 0; r < 12; ++r)
 #pragma unroll
     for (int k = 0; k < PW; ++k) P[r][k] = __builtin_amdgcn_alignbyte(R.w[r][k + 1], R.w[r][k], R.o) ^ (BPS == 1 ? 0x80808080u : 0u);
-  float orgM[16];   // current samples + kRoundMagic (exact: integers below 2^24)
+  float orgM[16];   // current samples + kRoundMagic (exact: integers below 2^24); WP: current samples - staging bias - offset, no magic
+  const float org_add = WP ? -wp.org_sub : kRoundMagic;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     if constexpr (BPS == 1) {
       const uint32_t w = curl[(by * 4 + r) * 16 + bx];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) orgM[4 * r + c] = (float)((w >> (8 * c)) & 0xff) + kRoundMagic;
+      for (int c = 0; c < 4; ++c) orgM[4 * r + c] = (float)((w >> (8 * c)) & 0xff) + org_add;
     } else {
       const uint2 w = *(const uint2*)&curl[(by * 4 + r) * 32 + bx * 2];
-      orgM[4 * r] = (float)(w.x & 0xffff) + kRoundMagic; orgM[4 * r + 1] = (float)(w.x >> 16) + kRoundMagic;
-      orgM[4 * r + 2] = (float)(w.y & 0xffff) + kRoundMagic; orgM[4 * r + 3] = (float)(w.y >> 16) + kRoundMagic;
+      orgM[4 * r] = (float)(w.x & 0xffff) + org_add; orgM[4 * r + 1] = (float)(w.x >> 16) + org_add;
+      orgM[4 * r + 2] = (float)(w.y & 0xffff) + org_add; orgM[4 * r + 3] = (float)(w.y >> 16) + org_add;
     }
   }
   uint32_t dist[9], dist4[9];
@@ -1305,10 +1316,10 @@ __device__ __forceinline__ void me_frac_compute(const FracRaw<BPS>& R, const uin
   }
   const bool want4 = KIND8 && __any(match4 != 0);
 #ifndef ME_FRAC_STAGE0_PLAIN
-  if constexpr (STAGE == 0) me_frac_eval0<HAD, BPS, KIND8>(P, orgM, role, bd, clip_lo, want4, dist, dist4);
+  if constexpr (STAGE == 0) me_frac_eval0<HAD, BPS, KIND8, WP>(P, orgM, role, bd, clip_lo, want4, wp, dist, dist4);
   else
 #endif
-    me_frac_eval<STAGE, HAD, BPS, KIND8>(P, orgM, cqx, cqy, role, bd, clip_lo, tab_h, tab_v, want4, dist, dist4);
+    me_frac_eval<STAGE, HAD, BPS, KIND8, WP>(P, orgM, cqx, cqy, role, bd, clip_lo, tab_h, tab_v, want4, wp, dist, dist4);
 #ifndef ME_FRAC_T_NOATOMICS   // timing-only builds (tools/r04_frac_breakdown.sh; results are wrong by design): ME_FRAC_T_NOATOMICS, ME_FRAC_T_NOITEMS
   if (KIND8 && want4) {
 #pragma unroll
@@ -1345,10 +1356,10 @@ __device__ __forceinline__ void me_frac_compute(const FracRaw<BPS>& R, const uin
 #ifndef ME_FRAC_PIPE
 #define ME_FRAC_PIPE 0
 #endif
-template <int STAGE, int HAD, int BPS>
+template <int STAGE, int HAD, int BPS, int WP>
 __device__ __forceinline__ void me_frac_stage_items(const uint8_t* __restrict__ src, int gpitch, const uint32_t* curl, const uint32_t* st, const uint16_t* cover,
                                                     const uint16_t* list8, int n8, const uint16_t* list4, int n4, int tid, int bd, float clip_lo,
-                                                    const uint32_t* tab_h, const float* tab_v, uint32_t* acc) {
+                                                    const FracWp wp, const uint32_t* tab_h, const float* tab_v, uint32_t* acc) {
   constexpr int NT = frac_threads(BPS);
   const int role = tid & 3;
   FracRaw<BPS> R;
@@ -1364,7 +1375,7 @@ __device__ __forceinline__ void me_frac_stage_items(const uint8_t* __restrict__ 
     i8 += NT;
     if (i8 < n8) { pair = list8[i8 >> 2]; me_frac_fetch<BPS, 1>(src, gpitch, st, cover, pair, role, R); }
     else if (i4 < n4) { pair = list4[i4]; me_frac_fetch<BPS, 0>(src, gpitch, st, cover, pair, 0, R); }
-    me_frac_compute<STAGE, HAD, BPS, 1>(C, curl, st, cover, cpair, role, bd, clip_lo, tab_h, tab_v, acc);
+    me_frac_compute<STAGE, HAD, BPS, 1, WP>(C, curl, st, cover, cpair, role, bd, clip_lo, wp, tab_h, tab_v, acc);
   }
 #pragma unroll 1
   while (i4 < n4) {
@@ -1372,20 +1383,20 @@ __device__ __forceinline__ void me_frac_stage_items(const uint8_t* __restrict__ 
     const int cpair = pair;
     i4 += NT;
     if (i4 < n4) { pair = list4[i4]; me_frac_fetch<BPS, 0>(src, gpitch, st, cover, pair, 0, R); }
-    me_frac_compute<STAGE, HAD, BPS, 0>(C, curl, st, cover, cpair, 0, bd, clip_lo, tab_h, tab_v, acc);
+    me_frac_compute<STAGE, HAD, BPS, 0, WP>(C, curl, st, cover, cpair, 0, bd, clip_lo, wp, tab_h, tab_v, acc);
   }
 #else
 #pragma unroll 1
   for (; i8 < n8; i8 += NT) {
     pair = list8[i8 >> 2];
     me_frac_fetch<BPS, 1>(src, gpitch, st, cover, pair, role, R);
-    me_frac_compute<STAGE, HAD, BPS, 1>(R, curl, st, cover, pair, role, bd, clip_lo, tab_h, tab_v, acc);
+    me_frac_compute<STAGE, HAD, BPS, 1, WP>(R, curl, st, cover, pair, role, bd, clip_lo, wp, tab_h, tab_v, acc);
   }
 #pragma unroll 1
   for (; i4 < n4; i4 += NT) {
     pair = list4[i4];
     me_frac_fetch<BPS, 0>(src, gpitch, st, cover, pair, 0, R);
-    me_frac_compute<STAGE, HAD, BPS, 0>(R, curl, st, cover, pair, 0, bd, clip_lo, tab_h, tab_v, acc);
+    me_frac_compute<STAGE, HAD, BPS, 0, WP>(R, curl, st, cover, pair, 0, bd, clip_lo, wp, tab_h, tab_v, acc);
   }
 #endif
 }
@@ -1434,11 +1445,11 @@ __device__ __forceinline__ void me_frac_dedupe4(const uint32_t* st, const uint16
     if (first[j]) list[atomicAdd(counter, 1u)] = (uint16_t)(kFracPairs8 + p4 * kFracCover4 + j);
 }
 
-template <int HAD, int BPS>
+template <int HAD, int BPS, int WP>
 __global__ void __launch_bounds__(frac_threads(BPS), BPS == 1 ? ME_FRAC_WAVES8 : 2)
 me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitch,
                const MeJob* __restrict__ jobs, int n_jobs, uint32_t* __restrict__ job_counter, const uint16_t* __restrict__ cover_g,
-               const int16_t* __restrict__ int_mv, uint32_t lambda_q16, int bit_depth_bias, int16_t* __restrict__ out_qmv,
+               const int16_t* __restrict__ int_mv, uint32_t lambda_q16, int bit_depth_bias, const FracWp wp, int16_t* __restrict__ out_qmv,
                uint32_t* __restrict__ out_cost) {
   // bit_depth_bias: bit depth in the low 8 bits; bit 8 set = block and window carry the bias 2^bitDepth of a bi-prediction origin
   // (2*org - pred, TEncSearch.cpp:3702-3712: current samples in [-maxv, 2*maxv]; per-CTU calls only, u16 staging)
@@ -1538,8 +1549,8 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
     __syncthreads();
     const int n8 = 4 * (int)counter[0], n4 = (int)counter[1];
 #ifndef ME_FRAC_T_NOITEMS
-    if (stage == 0) me_frac_stage_items<0, HAD, BPS>(src, ref_pitch, curl, st, cover, list8, n8, list4, n4, tid, bd, clip_lo, tab_h, tab_v, acc);
-    else me_frac_stage_items<1, HAD, BPS>(src, ref_pitch, curl, st, cover, list8, n8, list4, n4, tid, bd, clip_lo, tab_h, tab_v, acc);
+    if (stage == 0) me_frac_stage_items<0, HAD, BPS, WP>(src, ref_pitch, curl, st, cover, list8, n8, list4, n4, tid, bd, clip_lo, wp, tab_h, tab_v, acc);
+    else me_frac_stage_items<1, HAD, BPS, WP>(src, ref_pitch, curl, st, cover, list8, n8, list4, n4, tid, bd, clip_lo, wp, tab_h, tab_v, acc);
 #endif
     __syncthreads();
     if (tid < 2) counter[tid] = 0;

@@ -160,7 +160,7 @@ Void TEncOpenCL::calcMotionVectors(Pel* pelCtu, Pel* pelSearch, Int iRefStride, 
   // refinement rides along on calls with HM's arithmetic, uni-prediction and bi-prediction origins alike (the bBi call of
   // TEncSearch.cpp:3798); where the engine cannot refine the integer search still runs and fracOk() says so
   const Bool weighted = m_wpOn && m_mode == ME_MODE_HM;   // the reference kernel knows no weights (cl/sad.cl): compat mode ignores them
-  const Bool wantFrac = m_refine && m_mode == ME_MODE_HM && !weighted;
+  const Bool wantFrac = m_refine && m_mode == ME_MODE_HM;
   m_fracOk = false;
   m_fracBi = m_bi != 0;
   Int rc = HMME_ERR_UNSUPPORTED;
@@ -169,14 +169,21 @@ Void TEncOpenCL::calcMotionVectors(Pel* pelCtu, Pel* pelSearch, Int iRefStride, 
   if (weighted) {   // no unweighted second try: a failed weighted call must reach the caller as failed
     ++m_wpCalls;
     hmme_weight w = {m_wp[0], m_wp[1], m_wp[2], m_wp[3]};
-    rc = hmme_search_ctu_w(m_ctx, pelCtu, iCtuStride, pelSearch, iRefStride, &p, &w, reinterpret_cast<int16_t*>(m_engMv), reinterpret_cast<uint32_t*>(m_engCost));
+    if (wantFrac) {   // weighted search + weighted refinement (xGetHADsw) in one call; where the engine cannot refine, the search alone
+      rc = hmme_search_refine_ctu_w(m_ctx, pelCtu, iCtuStride, pelSearch, iRefStride, &p, &w, m_refineHad ? 1 : 0, reinterpret_cast<int16_t*>(m_engMv),
+                                    reinterpret_cast<uint32_t*>(m_engCost), reinterpret_cast<int16_t*>(m_engQmv), reinterpret_cast<uint32_t*>(m_engFracCost));
+      m_fracOk = rc == HMME_OK;
+      m_fracPred = m_pred;
+    }
+    if (rc != HMME_OK)
+      rc = hmme_search_ctu_w(m_ctx, pelCtu, iCtuStride, pelSearch, iRefStride, &p, &w, reinterpret_cast<int16_t*>(m_engMv), reinterpret_cast<uint32_t*>(m_engCost));
     if (rc != HMME_OK) {
       fprintf(stderr, "ERROR: TEncOpenCL::calcMotionVectors (weighted prediction): %s\n", hmme_last_error(m_ctx));
       xPoison(t);
       return;
     }
   }
-  if (wantFrac) {
+  if (wantFrac && !weighted) {
     rc = hmme_search_refine_ctu(m_ctx, pelCtu, iCtuStride, pelSearch, iRefStride, &p, m_refineHad ? 1 : 0, reinterpret_cast<int16_t*>(m_engMv),
                                 reinterpret_cast<uint32_t*>(m_engCost), reinterpret_cast<int16_t*>(m_engQmv), reinterpret_cast<uint32_t*>(m_engFracCost));
     m_fracOk = rc == HMME_OK;

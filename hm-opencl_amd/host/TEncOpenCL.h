@@ -64,8 +64,9 @@ class TEncOpenCL {
   // ---- additive: explicit weighted prediction ----
   /// A slice with weighted prediction searches with m_cDistParam.bApplyWeight (setWpScalingDistParam, TEncSearch.cpp:3740, :5594-5635):
   /// every candidate is priced by xGetSADw on ((w * ref + round) >> shift) + offset.  While a weight is set, ME_MODE_HM calls run
-  /// hmme_search_ctu_w (integer search only: fracOk() stays false); a call the engine cannot serve exactly (weighted samples beyond a
-  /// Pel, sums beyond its cost field) fails like any other -- lastCallOk() false, tables poisoned -- and the caller searches on the CPU.
+  /// hmme_search_ctu_w -- with setRefine on, hmme_search_refine_ctu_w: the refinement prices xGetHADsw / xGetSADw like HM's own; a call
+  /// the engine cannot serve exactly (weighted samples beyond a Pel, sums beyond its cost field) fails like any other -- lastCallOk()
+  /// false, tables poisoned -- and the caller searches on the CPU.
   Void setWeight(Int w, Int offset, Int shift, Int round) { m_wpOn = true; m_wp[0] = w; m_wp[1] = offset; m_wp[2] = shift; m_wp[3] = round; }
   Void clearWeight() { m_wpOn = false; }
   Bool getWeightOn() const { return m_wpOn; }

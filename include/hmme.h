@@ -159,6 +159,13 @@ int hmme_search_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
 typedef struct hmme_weight { int w0, offset, shift, round; } hmme_weight;
 int hmme_search_ctu_w(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref_at_ctu_origin, int ref_stride,
                       const hmme_search_params* p, const hmme_weight* wp, int16_t* out_mv, uint32_t* out_sad);
+/* ... and with xPatternSearchFracDIF of the 593 winners in the same call, as hmme_search_refine_ctu: in such a slice the refinement's
+ * distortion is xGetHADsw / xGetSADw (TComRdCostWeightPrediction.cpp:407-470) -- the interpolated, clipped prediction weighted sample by
+ * sample before the difference is taken.  Additionally refused (HMME_ERR_UNSUPPORTED; hmme_search_ctu_w still serves the call) when
+ * the weighted sample differences of the block could exceed 4095 (the Hadamard sums are kept exactly). */
+int hmme_search_refine_ctu_w(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref_at_ctu_origin, int ref_stride,
+                             const hmme_search_params* p, const hmme_weight* wp, int use_hadamard, int16_t* out_mv, uint32_t* out_sad,
+                             int16_t* out_qmv, uint32_t* out_cost);
 
 /* The step after the search, for the same CTU: TEncSearch::xPatternSearchFracDIF (TEncSearch.cpp:4294-4331, called per PU at :3798)
  * for all 593 slots -- half- then quarter-pel refinement around each slot's integer MV, HM's 8-tap interpolation, Hadamard

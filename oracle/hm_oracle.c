@@ -791,9 +791,16 @@ static const int k_refine_q[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1},
 /* xPatternSearchFracDIF for one PU.  `ref` = reference plane at the PU origin; (int_x, int_y) = the integer MV.
  * out: half-pel offset (-1..1), quarter-pel offset (-1..1), cost of the winner (distortion + MV cost at scale 0).
  * The final quarter-pel MV is (int << 2) + (half << 1) + qter (TEncSearch.cpp:3800-3803). */
-void hmo_frac_refine(const hmo_pel* org, int org_stride, int w, int h, const hmo_pel* ref, int ref_stride, int int_x,
-                     int int_y, int pred_x, int pred_y, uint32_t lambda_q16, int use_had, int bit_depth, int* half_x,
-                     int* half_y, int* qter_x, int* qter_y, uint32_t* cost) {
+/* wp != NULL: the slice carries explicit weighted prediction -- the distortion functions of xPatternRefinement are then xGetHADsw /
+ * xGetSADw (TComRdCostWeightPrediction.cpp:407-470, :55-90): the interpolated (and clipped) prediction is weighted sample by sample,
+ * `Pel pred = ((w0 * cur + round) >> shift) + offset`, before the difference is taken; everything else is unchanged */
+static void weight_block(hmo_pel* blk, int stride, int w, int h, const hmo_wp* wp) {
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) blk[y * stride + x] = (hmo_pel)wp_pred(blk[y * stride + x], wp);
+}
+static void frac_refine_impl(const hmo_pel* org, int org_stride, int w, int h, const hmo_pel* ref, int ref_stride, int int_x,
+                             int int_y, int pred_x, int pred_y, uint32_t lambda_q16, int use_had, int bit_depth, const hmo_wp* wp, int* half_x,
+                             int* half_y, int* qter_x, int* qter_y, uint32_t* cost) {
   hmo_pel blk[64 * 64];
   uint32_t best = UINT_MAX;
   int bi = 0;
@@ -801,6 +808,7 @@ void hmo_frac_refine(const hmo_pel* org, int org_stride, int w, int h, const hmo
   for (int i = 0; i < 9; ++i) {
     const int hx = k_refine_h[i][0], hy = k_refine_h[i][1];
     hmo_pred_block_qpel(ref, ref_stride, w, h, 4 * int_x + 2 * hx, 4 * int_y + 2 * hy, bit_depth, blk, 64);
+    if (wp) weight_block(blk, 64, w, h, wp);
     uint32_t d = use_had ? hmo_had(org, org_stride, blk, 64, w, h, bit_depth) : hmo_sad(org, org_stride, blk, 64, w, h, 0, bit_depth);
     d += hmo_mv_cost(lambda_q16, 2 * int_x + hx, 2 * int_y + hy, pred_x, pred_y, 1);
     if (d < best) { best = d; bi = i; }
@@ -812,12 +820,26 @@ void hmo_frac_refine(const hmo_pel* org, int org_stride, int w, int h, const hmo
   for (int i = 0; i < 9; ++i) {
     const int qx = k_refine_q[i][0], qy = k_refine_q[i][1];
     hmo_pred_block_qpel(ref, ref_stride, w, h, bx + qx, by + qy, bit_depth, blk, 64);
+    if (wp) weight_block(blk, 64, w, h, wp);
     uint32_t d = use_had ? hmo_had(org, org_stride, blk, 64, w, h, bit_depth) : hmo_sad(org, org_stride, blk, 64, w, h, 0, bit_depth);
     d += hmo_mv_cost(lambda_q16, bx + qx, by + qy, pred_x, pred_y, 0);
     if (d < best) { best = d; bi = i; }
   }
   *qter_x = k_refine_q[bi][0]; *qter_y = k_refine_q[bi][1];
   *cost = best;
+}
+
+void hmo_frac_refine(const hmo_pel* org, int org_stride, int w, int h, const hmo_pel* ref, int ref_stride, int int_x,
+                     int int_y, int pred_x, int pred_y, uint32_t lambda_q16, int use_had, int bit_depth, int* half_x,
+                     int* half_y, int* qter_x, int* qter_y, uint32_t* cost) {
+  frac_refine_impl(org, org_stride, w, h, ref, ref_stride, int_x, int_y, pred_x, pred_y, lambda_q16, use_had, bit_depth, NULL, half_x, half_y, qter_x,
+                   qter_y, cost);
+}
+void hmo_frac_refine_w(const hmo_pel* org, int org_stride, int w, int h, const hmo_pel* ref, int ref_stride, int int_x, int int_y, int pred_x,
+                       int pred_y, uint32_t lambda_q16, int use_had, int bit_depth, const hmo_wp* wp, int* half_x, int* half_y, int* qter_x,
+                       int* qter_y, uint32_t* cost) {
+  frac_refine_impl(org, org_stride, w, h, ref, ref_stride, int_x, int_y, pred_x, pred_y, lambda_q16, use_had, bit_depth, wp, half_x, half_y, qter_x,
+                   qter_y, cost);
 }
 
 /* ---- whole-picture refinement: hmo_frac_refine for every slot of every CTU in [ctu_first, ctu_first + ctu_count), threaded over

@@ -92,6 +92,10 @@ uint32_t hmo_sad_w(const hmo_pel* org, int org_stride, const hmo_pel* cur, int c
 /* xPatternSearch with bApplyWeight: p->fen is ignored (see hmo_sad_w) */
 void hmo_pattern_search_w(const hmo_pel* org, int org_stride, int w, int h, const hmo_pel* ref, int ref_stride, const hmo_params* p,
                           const hmo_wp* wp, int* mvx, int* mvy, uint32_t* sad);
+/* xPatternSearchFracDIF in a slice with weighted prediction (xGetHADsw / xGetSADw on the weighted interpolated prediction) */
+void hmo_frac_refine_w(const hmo_pel* org, int org_stride, int w, int h, const hmo_pel* ref, int ref_stride, int int_x, int int_y, int pred_x,
+                       int pred_y, uint32_t lambda_q16, int use_had, int bit_depth, const hmo_wp* wp, int* half_x, int* half_y, int* qter_x,
+                       int* qter_y, uint32_t* cost);
 void hmo_search_ctu_w(const hmo_pel* ctu, int ctu_stride, const hmo_pel* ref, int ref_stride, const hmo_params* p, const hmo_wp* wp,
                       int32_t* out_x, int32_t* out_y, uint32_t* out_sad, uint32_t* out_cost);
 

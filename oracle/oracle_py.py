@@ -91,6 +91,10 @@ def oracle():
         L.hmo_search_ctu_w.restype = None
         L.hmo_search_ctu_w.argtypes = [C.POINTER(C.c_int16), C.c_int, C.POINTER(C.c_int16), C.c_int, C.POINTER(Params), C.POINTER(Wp),
                                        _i32p, _i32p, _u32p, C.c_void_p]
+        L.hmo_frac_refine_w.restype = None
+        L.hmo_frac_refine_w.argtypes = ([C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int16), C.c_int]
+                                        + [C.c_int] * 4 + [C.c_uint32, C.c_int, C.c_int, C.POINTER(Wp)] + [C.POINTER(C.c_int)] * 4
+                                        + [C.POINTER(C.c_uint32)])
         L.hmo_ocl_compat_params.restype = None
         L.hmo_ocl_compat_params.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.c_uint32]
         L.hmo_tz_search.restype = C.c_long
@@ -163,6 +167,10 @@ def ref():
             L.ref_pattern_search_w.argtypes = ([C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int16), C.c_int]
                                                + [C.c_int] * 6 + [C.c_double, C.c_int, C.c_int] + [C.c_int] * 4
                                                + [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint32)])
+            L.ref_frac_refine_w.restype = None
+            L.ref_frac_refine_w.argtypes = ([C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int16), C.c_int]
+                                            + [C.c_int] * 4 + [C.c_double, C.c_int, C.c_int] + [C.c_int] * 4 + [C.POINTER(C.c_int)] * 4
+                                            + [C.POINTER(C.c_uint32)])
             L.ref_sad_w.restype = C.c_uint32
             L.ref_sad_w.argtypes = [C.POINTER(C.c_int16), C.c_int, C.POINTER(C.c_int16), C.c_int] + [C.c_int] * 8
         L.ref_frac_refine_bi.restype = None
@@ -342,4 +350,22 @@ def frac_refine(plane_cur, cur_xy, plane_ref, ref_xy, w, h, int_mv, pred, lam_or
     else:
         oracle().hmo_frac_refine(org, cs, w, h, rf, rs, int_mv[0], int_mv[1], pred[0], pred[1], int(lam_or_q16), int(use_had),
                                  bit_depth, *[C.byref(v) for v in o], C.byref(cost))
+    return tuple(v.value for v in o) + (cost.value,)
+
+
+def frac_refine_w(plane_cur, cur_xy, plane_ref, ref_xy, w, h, int_mv, pred, lam_or_q16, use_had, bit_depth, wp, use_ref=False):
+    """xPatternSearchFracDIF for one PU in a slice with explicit weighted prediction wp = (w0, offset, shift, round): the oracle
+    (lam_or_q16 = lambda_q16) or the reference (lam_or_q16 = lambda).  -> (half_x, half_y, qter_x, qter_y, cost)"""
+    cs, rs = plane_cur.shape[1], plane_ref.shape[1]
+    org = _addr(plane_cur, cur_xy[1] * cs + cur_xy[0])
+    rf = _addr(plane_ref, ref_xy[1] * rs + ref_xy[0])
+    o = [C.c_int() for _ in range(4)]
+    cost = C.c_uint32()
+    if use_ref:
+        ref().ref_frac_refine_w(org, cs, w, h, rf, rs, int_mv[0], int_mv[1], pred[0], pred[1], float(lam_or_q16), int(use_had), bit_depth,
+                                *[int(v) for v in wp], *[C.byref(v) for v in o], C.byref(cost))
+    else:
+        ww = Wp(*[int(v) for v in wp])
+        oracle().hmo_frac_refine_w(org, cs, w, h, rf, rs, int_mv[0], int_mv[1], pred[0], pred[1], int(lam_or_q16), int(use_had), bit_depth,
+                                   C.byref(ww), *[C.byref(v) for v in o], C.byref(cost))
     return tuple(v.value for v in o) + (cost.value,)

@@ -264,6 +264,23 @@ void ref_frac_refine(int16_t* org, int org_stride, int w, int h, int16_t* ref_at
   *half_x = half.getHor(); *half_y = half.getVer(); *qter_x = qter.getHor(); *qter_y = qter.getVer(); *cost = d;
 }
 
+// xPatternSearchFracDIF in a slice with explicit weighted prediction: m_cDistParam carries bApplyWeight + wpCur from
+// setWpScalingDistParam (TEncSearch.cpp:3740) into the refinement (:3798), whose distortion functions are then xGetHADsw / xGetSADw
+void ref_frac_refine_w(int16_t* org, int org_stride, int w, int h, int16_t* ref_at_pu, int ref_stride, int int_x, int int_y,
+                       int pred_x, int pred_y, double lambda, int use_had, int bit_depth, int w0, int offset, int shift, int round,
+                       int* half_x, int* half_y, int* qter_x, int* qter_y, uint32_t* cost) {
+  Rig& r = rig();
+  static WPScalingParam wp[MAX_NUM_COMPONENT];
+  memset(wp, 0, sizeof wp);
+  wp[COMPONENT_Y].w = w0; wp[COMPONENT_Y].offset = offset; wp[COMPONENT_Y].shift = shift; wp[COMPONENT_Y].round = round;
+  r.search->m_cDistParam.bApplyWeight = true;
+  r.search->m_cDistParam.wpCur = wp;
+  ref_frac_refine(org, org_stride, w, h, ref_at_pu, ref_stride, int_x, int_y, pred_x, pred_y, lambda, use_had, bit_depth, half_x, half_y,
+                  qter_x, qter_y, cost);
+  r.search->m_cDistParam.bApplyWeight = false;
+  r.search->m_cDistParam.wpCur = NULL;
+}
+
 // the bBi call of TEncSearch::xMotionEstimation (TEncSearch.cpp:3798 with bBi = true): `org` is the bi-prediction origin
 // 2*org - pred_other (TEncSearch.cpp:3702-3712, TComYuv::removeHighFreq: unclipped, so samples lie in [-maxv, 2*maxv])
 void ref_frac_refine_bi(int16_t* org, int org_stride, int w, int h, int16_t* ref_at_pu, int ref_stride, int int_x, int int_y,

@@ -211,7 +211,7 @@ int main() {
     me.setPredictor(TComMv(5, -3));
     me.setSearchRangeRB(TComMv((Short)rbx, (Short)rby));
     me.calcMotionVectors(&faded[0], piRefY, stride, 64, SR, &lt);
-    if (!me.lastCallOk() || me.fracOk()) { fprintf(stderr, "weighted call: ok %d, fracOk %d\n", (int)me.lastCallOk(), (int)me.fracOk()); ++failures; }
+    if (!me.lastCallOk() || !me.fracOk()) { fprintf(stderr, "weighted call: ok %d, fracOk %d\n", (int)me.lastCallOk(), (int)me.fracOk()); ++failures; }
     hmo_params p;
     p.lt_x = ltx; p.lt_y = lty; p.rb_x = rbx; p.rb_y = rby; p.pred_x = 5; p.pred_y = -3; p.lambda_q16 = hmo_lambda_q16(lambda); p.fen = 1; p.bit_depth = 8;
     const hmo_wp wp = {52, 17, 6, 32};
@@ -222,6 +222,18 @@ int main() {
     for (int i = 0; i < NUM_CTU_PARTS; i++) bad += me.getMvs()[i].getHor() != ox[i] || me.getMvs()[i].getVer() != oy[i] || me.getRuiCost()[i] != osad[i];
     if (bad) { fprintf(stderr, "weighted prediction: %d slots differ from the oracle\n", bad); failures += bad; }
     if (ox[592] != -3 || oy[592] != 2) { fprintf(stderr, "weighted prediction: the fade's displacement was not found (%d,%d)\n", ox[592], oy[592]); ++failures; }
+    for (int slot = 0; slot < NUM_CTU_PARTS; slot += 13) {   // the refinement tables of the same call: xGetHADsw on the weighted interpolated prediction
+      hmo_rect r;
+      hmo_slot_rect(slot, &r);
+      int hx, hy, qx, qy;
+      uint32_t cost;
+      hmo_frac_refine_w(&faded[r.y * 64 + r.x], 64, r.w, r.h, piRefY + r.y * stride + r.x, stride, ox[slot], oy[slot], 5, -3, p.lambda_q16, 1, 8, &wp,
+                        &hx, &hy, &qx, &qy, &cost);
+      if (me.getQMvs()[slot].getHor() != 4 * ox[slot] + 2 * hx + qx || me.getQMvs()[slot].getVer() != 4 * oy[slot] + 2 * hy + qy || me.getFracCost()[slot] != cost) {
+        if (failures < 10) fprintf(stderr, "weighted refinement slot %d differs from the oracle\n", slot);
+        ++failures;
+      }
+    }
     me.clearWeight();
     me.setRefine(false);
   }

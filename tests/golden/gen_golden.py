@@ -290,6 +290,56 @@ def gen_frac(table):
     print("frac:", len(rows))
 
 
+def gen_frac_wp(table):
+    """xPatternSearchFracDIF in a slice with explicit weighted prediction (m_cDistParam.bApplyWeight: xGetHADsw / xGetSADw on the weighted
+    interpolated prediction): faded current pictures and the weights that undo them, mismatched weights, a negative weight, shift 0"""
+    rng = np.random.default_rng(29)
+    wps = [(52, 17, 6, 32), (80, -30, 6, 32), (-64, 255, 6, 32), (71, 5, 6, 32), (2, -100, 0, 0), (100, -64, 7, 64), (64, 0, 6, 32)]
+    planes = {}
+    for bd in (8, 10):
+        cur_p, ref_p, _ = synth.make_pair(192, 192, seed=70 + bd, bit_depth=bd, max_mv=3, region=64, margin=16, noise_sigma=2.0)
+        planes[bd] = (cur_p, ref_p)
+    rows, outs, curs = [], [], []
+    for it in range(112):
+        bd = 10 if it % 4 == 3 else 8
+        cur_p, ref_p = planes[bd]
+        maxv = (1 << bd) - 1
+        wp = wps[it % len(wps)]
+        wp = (wp[0], wp[1] << (bd - 8), wp[2], wp[3])
+        # the current block as the weighted reference would predict it (a fade), so that the weights matter and the search has a clear minimum
+        denom = float(1 << wp[2])
+        faded = np.clip(np.rint(cur_p.astype(np.float64) * (wp[0] / denom) + wp[1]), 0, maxv).astype(np.int16) if it % 3 else cur_p
+        slot = int(rng.integers(0, 593)) if it >= 16 else [592, 588, 590, 576, 512, 544, 448, 256, 300, 340, 384, 0, 128, 130, 584, 560][it]
+        x, y, w, h = (int(v) for v in table[table[:, 0] == slot][0, 6:10])
+        mv = [int(v) for v in rng.integers(-6, 7, size=2)]
+        pred = [int(v) for v in rng.integers(-40, 41, size=2)]
+        lam = float(rng.choice([0.0, 4.7, 57.9, 900.0]))
+        had = int(it % 5 != 4)
+        o = 16 + 64
+        cs = cur_p.shape[1]
+        off = (o + y) * cs + o + x
+        h_ = [C.c_int() for _ in range(4)]
+        cost = C.c_uint32()
+        R.ref_frac_refine_w(O._addr(faded, off), cs, w, h, O._addr(ref_p, off), cs, mv[0], mv[1], pred[0], pred[1], lam, had, bd, *wp,
+                            *[C.byref(v) for v in h_], C.byref(cost))
+        rows.append((slot, x, y, w, h, mv[0], mv[1], pred[0], pred[1], had, bd, R.ref_lambda_q16(lam), o) + wp + (len(curs),))
+        curs.append(faded)
+        outs.append(tuple(v.value for v in h_) + (cost.value,))
+    # the faded planes repeat: keep the distinct ones
+    uniq, index = [], []
+    for c in curs:
+        for i, u in enumerate(uniq):
+            if u.shape == c.shape and np.array_equal(u, c):
+                index.append(i); break
+        else:
+            index.append(len(uniq)); uniq.append(c)
+    rows = [r[:-1] + (index[r[-1]],) for r in rows]
+    np.savez_compressed(os.path.join(HERE, "frac_wp.npz"), rows=np.array(rows, np.int64), out=np.array(outs, np.int64),
+                        cur=np.stack(uniq), ref8=planes[8][1], ref10=planes[10][1],
+                        columns=np.array("slot x y w h int_x int_y pred_x pred_y had bit_depth lambda_q16 origin wp_w wp_offset wp_shift wp_round cur_index".split()))
+    print("frac_wp:", len(rows), "cases,", len(uniq), "current planes")
+
+
 def gen_frac_bipred(table):
     """the bBi call: (PU of the origin plane 2*org - pred_other, integer MV, predictor, lambda, HAD on/off, bit depth) -> (half, quarter, cost)"""
     rng = np.random.default_rng(29)
@@ -425,6 +475,9 @@ def main():
     if sys.argv[1:] == ["wp"]:
         gen_wp(np.load(os.path.join(HERE, "slots.npz"))["table"])
         return
+    if sys.argv[1:] == ["frac_wp"]:
+        gen_frac_wp(np.load(os.path.join(HERE, "slots.npz"))["table"])
+        return
     table = gen_slots()
     gen_cost()
     gen_sad()
@@ -458,6 +511,7 @@ def main():
     gen_frac(table)
     gen_frac_bipred(table)
     gen_wp(table)
+    gen_frac_wp(table)
     gen_slots_amp_off()
     gen_border()
 

@@ -153,6 +153,65 @@ def test_weighted_prediction_search_matches_reference_goldens_and_oracle(engine,
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
+def test_weighted_search_and_refinement_in_one_call_vs_oracle(engine, oracle_lib):
+    """hmme_search_refine_ctu_w: the integer search priced by xGetSADw and, on its winners, xPatternSearchFracDIF priced by xGetHADsw /
+    xGetSADw (the interpolated prediction weighted sample by sample) -- all 593 slots against the oracle, whose weighted refinement is
+    pinned by 112 goldens from the compiled reference (tests/golden/frac_wp.npz); fades and mismatched weights, negative weights,
+    shift 0, 8 / 10 bit, Hadamard and SAD, bi-prediction origins"""
+    from hmme import api
+    table = oracle_lib.slot_table()
+    rng = np.random.default_rng(515)
+    done = 0
+    for it in range(14):
+        bd = 10 if it % 4 == 3 else 8
+        sr = int(rng.choice([4, 8, 16, 33]))
+        side = 64 + 2 * sr + 16
+        o = sr + 8
+        maxv = (1 << bd) - 1
+        base = rng.integers(0, maxv + 1, size=(side + 8, side + 8))
+        k = np.ones(3) / 3.0   # a little smoothing: fractional positions then matter
+        sm = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), 1, np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), 0, base.astype(np.float64)))
+        ref = np.clip(np.rint(sm[4:4 + side, 4:4 + side]), 0, maxv).astype(np.int16)
+        shift = int(rng.choice([0, 5, 6, 7]))
+        denom = 1 << shift
+        w0 = int(rng.integers(denom // 2, 2 * denom + 1)) if it % 5 else -int(rng.integers(1, denom + 1))
+        wp = (w0, int(rng.integers(-40, 41)) << (bd - 8), shift, denom >> 1)
+        dx, dy = int(rng.integers(-min(sr, 5), min(sr, 5) + 1)), int(rng.integers(-min(sr, 5), min(sr, 5) + 1))
+        blk = ref[o + dy:o + dy + 64, o + dx:o + dx + 64].astype(np.int64)
+        cur = np.clip(((wp[0] * blk + wp[3]) >> wp[2]) + wp[1] + rng.integers(-3, 4, size=(64, 64)), 0, maxv).astype(np.int16)
+        if it % 6 == 5:
+            cur = np.clip(2 * cur.astype(np.int64) - rng.integers(0, maxv + 1, size=(64, 64)), -maxv, 2 * maxv).astype(np.int16)   # a bi-prediction origin
+        pred = (int(rng.integers(-30, 31)), int(rng.integers(-30, 31)))
+        lam = float(rng.choice([0.0, 57.9, 600.0]))
+        lq = oracle_lib.oracle().hmo_lambda_q16(lam)
+        engine.set_lambda(lam)
+        had = it % 3 != 2
+        p = api.SearchParams(-sr, -sr, sr, sr, pred[0], pred[1], 1, bd)
+        try:
+            mv, sad, qmv, cost = engine.search_refine_ctu_w(cur, (0, 0), ref, (o, o), p, wp, use_hadamard=had)
+        except api.HmmeError as e:
+            assert "Pel" in str(e) or "cost field" in str(e) or "16 bits" in str(e) or "Hadamard sums" in str(e), str(e)
+            continue
+        op = oracle_lib.make_params((-sr, -sr), (sr, sr), pred, lq, 1, bd)
+        ox, oy, osad = oracle_lib.search_ctu_w(cur, (0, 0), ref, (o, o), op, wp)
+        assert np.array_equal(mv[:, 0], ox) and np.array_equal(mv[:, 1], oy) and np.array_equal(sad, osad), (it, wp)
+        for s_ in range(593):
+            x, y, bw, bh = (int(v) for v in table[s_])
+            imv = (int(mv[s_, 0]), int(mv[s_, 1]))
+            hx, hy, qx, qy, c = oracle_lib.frac_refine_w(cur, (x, y), ref, (o + x, o + y), bw, bh, imv, pred, lq, int(had), bd, wp)
+            assert (int(qmv[s_, 0]), int(qmv[s_, 1]), int(cost[s_])) == (4 * imv[0] + 2 * hx + qx, 4 * imv[1] + 2 * hy + qy, c), (it, s_, wp, (bw, bh))
+        done += 1
+    assert done >= 10
+    # the identity weight: the refinement of the unweighted call (its integer search runs with FEN off, as xGetSADw reads every row)
+    cur = rng.integers(0, 256, size=(64, 64)).astype(np.int16)
+    ref = rng.integers(0, 256, size=(96, 96)).astype(np.int16)
+    engine.set_lambda(57.9)
+    a = engine.search_refine_ctu_w(cur, (0, 0), ref, (16, 16), api.SearchParams(-8, -8, 8, 8, 2, 1, 1, 8), (64, 0, 6, 32))
+    b = engine.search_refine_ctu(cur, (0, 0), ref, (16, 16), api.SearchParams(-8, -8, 8, 8, 2, 1, 0, 8))
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v)
+
+
 def test_ocl_compat_mode_vs_oracle(engine, oracle_lib):
     """the reference GPU path's choices (pred (0,0), window LT..LT+2SR, all rows): cl/sad.cl:374-408"""
     from hmme import api

@@ -179,7 +179,14 @@ def test_patched_encoder_searches_weighted_prediction_slices_on_the_engine(tmp_p
     rf, pf = _encode(tmp_path, 0, exe=EXE_HM, **dict(common, extra=("--SearchRange=24", wp_flag, "--FastSearch=0")))
     bits, bits_full = sum(b for _, b, _ in p[1:]), sum(b for _, b, _ in pf[1:])
     assert bits < 1.06 * bits_full + 500, (bits, bits_full)
-    print("WP fade on the engine:", p, "\nFastSearch=0:", pf, "\n", m.group(0))
+    # ... and with the refinement tables: the weighted xPatternSearchFracDIF of the 64x64 PU comes from the engine (xGetHADsw pricing),
+    # HM's own weighted refinement runs beside every lookup: more checks than before, still none differs
+    rg, pg = _encode(tmp_path, 1, exe=EXE_HM, env_extra={"HMME_VERIFY": "1", "HMME_GPU_FRAC": "1"}, **common)
+    mg = _TRACE.search(rg.stderr)
+    assert mg, rg.stderr[-1500:]
+    calls_g, failed_g, _, _, verified_g, differ_g = (int(v) for v in mg.groups())
+    assert failed_g == 0 and differ_g == 0 and verified_g > verified, (mg.group(0), m.group(0))
+    print("WP fade on the engine:", p, "\nFastSearch=0:", pf, "\n", m.group(0), "\nwith refinement tables:", mg.group(0))
 
 
 @pytest.mark.gpu

@@ -117,6 +117,28 @@ def test_weighted_prediction_sads_and_searches(oracle_lib):
             assert got == tuple(int(v) for v in want[s]), (i, s)
 
 
+def test_weighted_fractional_refinement(oracle_lib):
+    """xPatternSearchFracDIF with m_cDistParam.bApplyWeight (xGetHADsw / xGetSADw on the weighted interpolated prediction): 112 goldens
+    from the compiled reference (tests/golden/frac_wp.npz, gen_golden.py frac_wp)"""
+    d = g("frac_wp.npz")
+    cols = d["columns"].tolist()
+    differs_from_unweighted = 0
+    for row, want in zip(d["rows"], d["out"]):
+        m = dict(zip(cols, (int(v) for v in row)))
+        cur = np.ascontiguousarray(d["cur"][m["cur_index"]])
+        ref = np.ascontiguousarray(d["ref8"] if m["bit_depth"] == 8 else d["ref10"])
+        o = m["origin"]
+        xy = (o + m["x"], o + m["y"])
+        wp = (m["wp_w"], m["wp_offset"], m["wp_shift"], m["wp_round"])
+        got = oracle_lib.frac_refine_w(cur, xy, ref, xy, m["w"], m["h"], (m["int_x"], m["int_y"]), (m["pred_x"], m["pred_y"]), m["lambda_q16"],
+                                       m["had"], m["bit_depth"], wp)
+        assert got == tuple(int(v) for v in want), (m, got, want)
+        plain = oracle_lib.frac_refine(cur, xy, ref, xy, m["w"], m["h"], (m["int_x"], m["int_y"]), (m["pred_x"], m["pred_y"]), m["lambda_q16"],
+                                       m["had"], m["bit_depth"])
+        differs_from_unweighted += plain != got
+    assert differs_from_unweighted > 60      # the weights matter in these cases (the identity weight (64, 0, 6, 32) is among them)
+
+
 def test_full_search_all_slots_sr64(oracle_lib):
     _check_search(oracle_lib, "search_sr64.npz", (592, 588, 576, 300, 5))
 
