@@ -650,7 +650,6 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
              const hmme_weight* wp = nullptr) {
   if (!ctx) return HMME_ERR_ARG;
   const bool refine = refine_had >= 0;
-  if (wp && !do_search) return fail(ctx, HMME_ERR_UNSUPPORTED, "weighted prediction: refinement of caller-supplied integer MVs is not built (search + refinement is)");
   if (wp && (wp->shift < 0 || wp->shift > 15)) return fail(ctx, HMME_ERR_ARG, "weighted prediction: shift %d outside 0..15", wp->shift);
   if (!ctu || !ref0 || !p || (do_search && (!out_mv || !out_sad)) || (refine && (!out_qmv || !out_cost)) || (!do_search && !int_mv))
     return fail(ctx, HMME_ERR_ARG, "hmme_search_ctu: null argument");
@@ -781,7 +780,7 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
     const int n16 = (int)((kCallWin + (size_t)rows * kWinPitch + 64 + 15) / 16);
     hipLaunchKernelGGL(hmme::me_stage_call_kernel, dim3((n16 + 255) / 256), dim3(256), 0, s, (const uint4*)ctx->h_call_dev, (uint4*)ctx->d_call, n16);
     HIP_TRY(ctx, hipGetLastError());
-    if (wp) {   // the weighted window the integer search runs on; the raw one stays where it is for the refinement's interpolation
+    if (wp && do_search) {   // the weighted window the integer search runs on; the raw one stays where it is for the refinement's interpolation
       if (!ctx->d_wwin) HIP_TRY(ctx, hipMalloc(&ctx->d_wwin, (size_t)kWinRows * kWinPitch + 64));
       hipLaunchKernelGGL(hmme::me_weight_window_kernel, dim3((rows * cols + 255) / 256), dim3(256), 0, s, (const uint8_t*)(ctx->d_call + kCallWin), ctx->d_wwin,
                          (int)kWinPitch, rows, cols, wp->w0, wp->round, wp->shift, wp->offset + bias);
@@ -869,6 +868,12 @@ int hmme_search_refine_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, co
 int hmme_refine_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref0, int ref_stride, const hmme_search_params* p,
                     const int16_t* int_mv, int use_hadamard, int16_t* out_qmv, uint32_t* out_cost) {
   return ctu_call(ctx, ctu, ctu_stride, ref0, ref_stride, p, false, int_mv, use_hadamard ? 1 : 0, nullptr, nullptr, out_qmv, out_cost);
+}
+
+int hmme_refine_ctu_w(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref0, int ref_stride, const hmme_search_params* p,
+                      const hmme_weight* wp, const int16_t* int_mv, int use_hadamard, int16_t* out_qmv, uint32_t* out_cost) {
+  if (ctx && !wp) return fail(ctx, HMME_ERR_ARG, "hmme_refine_ctu_w: null weight");
+  return ctu_call(ctx, ctu, ctu_stride, ref0, ref_stride, p, false, int_mv, use_hadamard ? 1 : 0, nullptr, nullptr, out_qmv, out_cost, wp);
 }
 
 // ---- planes ----------------------------------------------------------------------------------------------

@@ -17,7 +17,7 @@ NUM_PARTS = 593
 # every symbol include/hmme.h declares (tests check the library exports all of them)
 SYMBOLS = ["hmme_create", "hmme_destroy", "hmme_last_error", "hmme_device_info", "hmme_set_lambda",
            "hmme_set_lambda_q16", "hmme_get_lambda_q16", "hmme_params_ocl_compat", "hmme_set_search_range",
-           "hmme_slot_index", "hmme_slot_rect", "hmme_slot_index_amp_off", "hmme_amp_off_slot", "hmme_compact_amp_off", "hmme_search_ctu", "hmme_search_ctu_w", "hmme_search_refine_ctu_w", "hmme_search_refine_ctu", "hmme_refine_ctu", "hmme_plane_create", "hmme_plane_create_ex", "hmme_plane_bit_depth", "hmme_plane_destroy", "hmme_plane_upload_pel",
+           "hmme_slot_index", "hmme_slot_rect", "hmme_slot_index_amp_off", "hmme_amp_off_slot", "hmme_compact_amp_off", "hmme_search_ctu", "hmme_search_ctu_w", "hmme_search_refine_ctu_w", "hmme_refine_ctu_w", "hmme_search_refine_ctu", "hmme_refine_ctu", "hmme_plane_create", "hmme_plane_create_ex", "hmme_plane_bit_depth", "hmme_plane_destroy", "hmme_plane_upload_pel",
            "hmme_plane_upload_u8", "hmme_host_register", "hmme_host_unregister", "hmme_plane_set_device_u8", "hmme_plane_width", "hmme_plane_height",
            "hmme_num_ctus", "hmme_search_frame", "hmme_search_frame_device", "hmme_search_frame_multi",
            "hmme_search_frame_multi_device", "hmme_refine_frame", "hmme_refine_frame_multi_device",
@@ -89,6 +89,7 @@ def load():
     L.hmme_search_ctu.argtypes = [vp, vp, i, vp, i, C.POINTER(SearchParams), vp, vp]
     L.hmme_search_ctu_w.argtypes = [vp, vp, i, vp, i, C.POINTER(SearchParams), C.POINTER(Weight), vp, vp]
     L.hmme_search_refine_ctu_w.argtypes = [vp, vp, i, vp, i, C.POINTER(SearchParams), C.POINTER(Weight), i, vp, vp, vp, vp]
+    L.hmme_refine_ctu_w.argtypes = [vp, vp, i, vp, i, C.POINTER(SearchParams), C.POINTER(Weight), vp, i, vp, vp]
     L.hmme_search_refine_ctu.argtypes = [vp, vp, i, vp, i, C.POINTER(SearchParams), i, vp, vp, vp, vp]
     L.hmme_refine_ctu.argtypes = [vp, vp, i, vp, i, C.POINTER(SearchParams), vp, i, vp, vp]
     L.hmme_plane_create.argtypes = [vp, i, i, C.POINTER(vp)]
@@ -275,6 +276,20 @@ class Engine:
         rp = ref.ctypes.data + 2 * (ref_xy[1] * ref.shape[1] + ref_xy[0])
         self._check(self.L.hmme_refine_ctu(self.h, cp, cur.shape[1], rp, ref.shape[1], C.byref(params), imv.ctypes.data, int(use_hadamard),
                                            qmv.ctypes.data, cost.ctypes.data))
+        return qmv, cost
+
+    def refine_ctu_w(self, cur_plane, cur_xy, ref_plane, ref_xy, params, wp, int_mv, use_hadamard=True):
+        """hmme_refine_ctu_w: the weighted xPatternSearchFracDIF alone, at the caller's integer MVs -> (qmv, cost)"""
+        cur = np.ascontiguousarray(cur_plane, dtype=np.int16)
+        ref = np.ascontiguousarray(ref_plane, dtype=np.int16)
+        imv = np.ascontiguousarray(int_mv, dtype=np.int16)
+        assert imv.shape == (NUM_PARTS, 2)
+        qmv, cost = np.zeros((NUM_PARTS, 2), np.int16), np.zeros(NUM_PARTS, np.uint32)
+        cp = cur.ctypes.data + 2 * (cur_xy[1] * cur.shape[1] + cur_xy[0])
+        rp = ref.ctypes.data + 2 * (ref_xy[1] * ref.shape[1] + ref_xy[0])
+        w = Weight(*[int(v) for v in wp])
+        self._check(self.L.hmme_refine_ctu_w(self.h, cp, cur.shape[1], rp, ref.shape[1], C.byref(params), C.byref(w), imv.ctypes.data, int(use_hadamard),
+                                             qmv.ctypes.data, cost.ctypes.data))
         return qmv, cost
 
     def search_frame(self, cur, ref, sr, pred_q=None, fen=1, bit_depth=None, ctu_first=0, ctu_count=-1):

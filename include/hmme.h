@@ -166,6 +166,9 @@ int hmme_search_ctu_w(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const i
 int hmme_search_refine_ctu_w(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref_at_ctu_origin, int ref_stride,
                              const hmme_search_params* p, const hmme_weight* wp, int use_hadamard, int16_t* out_mv, uint32_t* out_sad,
                              int16_t* out_qmv, uint32_t* out_cost);
+int hmme_refine_ctu_w(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* ref_at_ctu_origin, int ref_stride,
+                      const hmme_search_params* p, const hmme_weight* wp, const int16_t* int_mv, int use_hadamard, int16_t* out_qmv,
+                      uint32_t* out_cost);   /* the weighted refinement alone, at the caller's integer MVs (as hmme_refine_ctu) */
 
 /* The step after the search, for the same CTU: TEncSearch::xPatternSearchFracDIF (TEncSearch.cpp:4294-4331, called per PU at :3798)
  * for all 593 slots -- half- then quarter-pel refinement around each slot's integer MV, HM's 8-tap interpolation, Hadamard

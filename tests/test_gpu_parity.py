@@ -1154,6 +1154,37 @@ def test_refine_ctu_matches_reference_goldens(engine):
     assert n == 160
 
 
+def test_weighted_refine_ctu_matches_reference_goldens(engine):
+    """hmme_refine_ctu_w == the reference's own xPatternSearchFracDIF with m_cDistParam.bApplyWeight (xGetHADsw / xGetSADw on the weighted
+    interpolated prediction): tests/golden/frac_wp.npz, 112 PUs of all shapes on faded pictures, 8/10 bit, Hadamard / SAD, weights incl.
+    a negative one and shift 0 -- straight through the C ABI, no oracle in between"""
+    from hmme import api
+    d = np.load(os.path.join(GOLDEN, "frac_wp.npz"))
+    cols = d["columns"].tolist()
+    n = refused = 0
+    for row, want in zip(d["rows"], d["out"]):
+        m = dict(zip(cols, (int(v) for v in row)))
+        cur = np.ascontiguousarray(d["cur"][m["cur_index"]])
+        ref = np.ascontiguousarray(d["ref8"] if m["bit_depth"] == 8 else d["ref10"])
+        engine.set_lambda_q16(m["lambda_q16"])
+        imv = np.zeros((593, 2), np.int16)
+        imv[m["slot"]] = (m["int_x"], m["int_y"])
+        o = m["origin"]
+        p = api.SearchParams(-8, -8, 8, 8, m["pred_x"], m["pred_y"], 1, m["bit_depth"])
+        wp = (m["wp_w"], m["wp_offset"], m["wp_shift"], m["wp_round"])
+        try:
+            qmv, cost = engine.refine_ctu_w(cur, (o, o), ref, (o, o), p, wp, imv, use_hadamard=bool(m["had"]))
+        except api.HmmeError as e:      # the engine may refuse what it cannot keep exact (here: the whole CTU's sample span, not the PU's)
+            assert "Hadamard sums" in str(e) or "Pel" in str(e) or "cost field" in str(e), str(e)
+            refused += 1
+            continue
+        hx, hy, qx, qy, c = (int(v) for v in want)
+        s_ = m["slot"]
+        assert (int(qmv[s_, 0]), int(qmv[s_, 1]), int(cost[s_])) == (4 * m["int_x"] + 2 * hx + qx, 4 * m["int_y"] + 2 * hy + qy, c), m
+        n += 1
+    assert n >= 90 and refused <= 22, (n, refused)
+
+
 @pytest.mark.parametrize("bd,sr,had", [(8, 16, 1), (8, 64, 0), (10, 24, 1), (8, 100, 1), (12, 128, 0)])
 def test_search_refine_ctu_vs_oracle(engine, oracle_lib, bd, sr, had):
     """hmme_search_refine_ctu: one call = hmme_search_ctu (identical integer tables) + xPatternSearchFracDIF of the winners for all 593
