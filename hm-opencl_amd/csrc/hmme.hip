@@ -610,23 +610,29 @@ inline frac_fn frac_kernel(int wide, int had, int wp = 0) {
   return wp ? fns_wp[had ? 1 : 0] : fns[wide ? 1 : 0][had ? 1 : 0];
 }
 const hmme::FracWp kNoWp = {0.f, 0.f, 0.f};
-// workgroups of a refinement launch: as many as the chip holds at a time (the runtime's occupancy figure for this kernel with its
-// LDS block x the CUs), each walking every grid-th job; HMME_FRAC_GRID=<n> forces a grid (0 = one workgroup per job, as before round 4)
+// workgroups of a refinement launch: one per job, dealt from the end of the job table (me_frac_kernel).  HMME_FRAC_GRID=<n> launches n
+// workgroups that take job after job from a counter instead, HMME_FRAC_GRID=-1 as many of those as the chip holds at a time (the
+// runtime's occupancy figure for this kernel with its LDS block x the CUs): round 4's intermediate launch, kept for A/B runs -- once
+// both orders ran last-first it was the slower one on every content (profiles/r04g_frac_grid_both_last_first.txt)
 int frac_grid(hmme_ctx* ctx, int wide, int had, int jobs) {
-  int& per_cu = ctx->frac_wg_per_cu[wide ? 1 : 0][had ? 1 : 0];
-  if (per_cu == 0) {
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)frac_kernel(wide, had), hmme::frac_threads(wide ? 2 : 1),
-                                                     hmme::frac_lds_bytes(wide ? 2 : 1)) != hipSuccess || n < 1) {
-      (void)hipGetLastError();
-      n = 2;
+  static const int forced = std::getenv("HMME_FRAC_GRID") ? std::atoi(std::getenv("HMME_FRAC_GRID")) : 0;
+  if (forced == 0) return jobs;
+  int grid = forced;
+  if (forced < 0) {
+    int& per_cu = ctx->frac_wg_per_cu[wide ? 1 : 0][had ? 1 : 0];
+    if (per_cu == 0) {
+      int n = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)frac_kernel(wide, had), hmme::frac_threads(wide ? 2 : 1),
+                                                       hmme::frac_lds_bytes(wide ? 2 : 1)) != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        n = 2;
+      }
+      per_cu = n;
+      if (std::getenv("HMME_TRACE")) fprintf(stderr, "hmme: me_frac_kernel<%d, %d>: %d workgroups per CU, %d CUs\n", had ? 1 : 0, wide ? 2 : 1, n, ctx->num_cus);
     }
-    per_cu = n;
-    if (std::getenv("HMME_TRACE")) fprintf(stderr, "hmme: me_frac_kernel<%d, %d>: %d workgroups per CU, %d CUs\n", had ? 1 : 0, wide ? 2 : 1, n, ctx->num_cus);
+    grid = per_cu * ctx->num_cus;
   }
-  static const int forced = std::getenv("HMME_FRAC_GRID") ? std::atoi(std::getenv("HMME_FRAC_GRID")) : -1;
-  int grid = forced == 0 ? jobs : (forced > 0 ? forced : per_cu * ctx->num_cus);
-  return grid < jobs ? (grid < 1 ? 1 : grid) : jobs;
+  return grid < jobs ? grid : jobs;
 }
 
 // host-side packing of the call block, one picture row at a time; separate reduction and narrowing loops so that the compiler

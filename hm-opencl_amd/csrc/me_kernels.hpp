@@ -1240,9 +1240,7 @@ __device__ __forceinline__ void me_frac_eval0(const uint32_t (&P)[12][3 * BPS], 
 }
 
 // One work item = one 4x4 block of one (position, MV) pair; `pair` indexes the cover table (kind-8 pairs first), `role` is the lane's
-// quadrant of an 8x8 Hadamard block.  An item is handled in three steps so that the patch of a lane's NEXT item can be in flight while
-// the current one is evaluated (round 4; until then a lane loaded its 12 patch rows, waited for them, and computed, with nothing
-// outstanding -- the kernel was VALU-busy half of its time on coherent content, profiles/latest_pmc_2160p_sr64.json of round 3):
+// quadrant of an 8x8 Hadamard block.  An item is handled in two steps:
 //   me_frac_fetch    slot state + address -> 12 raw rows of PW + 1 aligned dwords each (global_load_dwordx4 / x3), nothing waited for
 //   me_frac_compute  byte-align the rows (first use = the wait), evaluate the 9 / 8 points, add to the slots that share the key
 template <int BPS>
@@ -1351,11 +1349,9 @@ __device__ __forceinline__ void me_frac_compute(const FracRaw<BPS>& R, const uin
 #endif
 }
 
-// software-pipelined walk over a lane's items of one stage: kind-8 items (whole quads), then kind-4 items; the patch rows of the next
-// item -- of either kind -- are requested before the current item is evaluated.  ME_FRAC_PIPE 0 = request, wait, evaluate (round 3).
-#ifndef ME_FRAC_PIPE
-#define ME_FRAC_PIPE 0
-#endif
+// a lane's items of one stage: kind-8 items (whole quads: n8 and the thread count are multiples of 4), then kind-4 items.  (Round 4 also
+// built this walk software-pipelined -- the next item's 12 patch rows requested before the current item is evaluated, at 2 waves per
+// SIMD and 255 VGPRs without spills, as VERDICT r3 proposed: slower on every content, profiles/r04a_frac_pipelined_vs_plain_ab.txt.)
 template <int STAGE, int HAD, int BPS, int WP>
 __device__ __forceinline__ void me_frac_stage_items(const uint8_t* __restrict__ src, int gpitch, const uint32_t* curl, const uint32_t* st, const uint16_t* cover,
                                                     const uint16_t* list8, int n8, const uint16_t* list4, int n4, int tid, int bd, float clip_lo,
@@ -1363,42 +1359,18 @@ __device__ __forceinline__ void me_frac_stage_items(const uint8_t* __restrict__ 
   constexpr int NT = frac_threads(BPS);
   const int role = tid & 3;
   FracRaw<BPS> R;
-  int i8 = tid, i4 = tid;
-  int pair = 0;
-#if ME_FRAC_PIPE
-  if (i8 < n8) { pair = list8[i8 >> 2]; me_frac_fetch<BPS, 1>(src, gpitch, st, cover, pair, role, R); }
-  else if (i4 < n4) { pair = list4[i4]; me_frac_fetch<BPS, 0>(src, gpitch, st, cover, pair, 0, R); }
 #pragma unroll 1
-  while (i8 < n8) {   // whole quads: n8 and NT are multiples of 4
-    const FracRaw<BPS> C = R;
-    const int cpair = pair;
-    i8 += NT;
-    if (i8 < n8) { pair = list8[i8 >> 2]; me_frac_fetch<BPS, 1>(src, gpitch, st, cover, pair, role, R); }
-    else if (i4 < n4) { pair = list4[i4]; me_frac_fetch<BPS, 0>(src, gpitch, st, cover, pair, 0, R); }
-    me_frac_compute<STAGE, HAD, BPS, 1, WP>(C, curl, st, cover, cpair, role, bd, clip_lo, wp, tab_h, tab_v, acc);
-  }
-#pragma unroll 1
-  while (i4 < n4) {
-    const FracRaw<BPS> C = R;
-    const int cpair = pair;
-    i4 += NT;
-    if (i4 < n4) { pair = list4[i4]; me_frac_fetch<BPS, 0>(src, gpitch, st, cover, pair, 0, R); }
-    me_frac_compute<STAGE, HAD, BPS, 0, WP>(C, curl, st, cover, cpair, 0, bd, clip_lo, wp, tab_h, tab_v, acc);
-  }
-#else
-#pragma unroll 1
-  for (; i8 < n8; i8 += NT) {
-    pair = list8[i8 >> 2];
+  for (int i8 = tid; i8 < n8; i8 += NT) {
+    const int pair = list8[i8 >> 2];
     me_frac_fetch<BPS, 1>(src, gpitch, st, cover, pair, role, R);
     me_frac_compute<STAGE, HAD, BPS, 1, WP>(R, curl, st, cover, pair, role, bd, clip_lo, wp, tab_h, tab_v, acc);
   }
 #pragma unroll 1
-  for (; i4 < n4; i4 += NT) {
-    pair = list4[i4];
+  for (int i4 = tid; i4 < n4; i4 += NT) {
+    const int pair = list4[i4];
     me_frac_fetch<BPS, 0>(src, gpitch, st, cover, pair, 0, R);
     me_frac_compute<STAGE, HAD, BPS, 0, WP>(R, curl, st, cover, pair, 0, bd, clip_lo, wp, tab_h, tab_v, acc);
   }
-#endif
 }
 
 // distinct (position, key) pairs of one stage -> work lists; the first slot (lowest index in the cover list) with a given key is the one
@@ -1483,7 +1455,8 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
   // length with the content.  job_counter == null (the per-CTU call: one job): blockIdx.x, blockIdx.x + gridDim.x, ...
   uint32_t* next_job = counter + 2;     // LDS word: the job this workgroup works on
 #pragma unroll 1
-  for (int jb = blockIdx.x;; jb += gridDim.x) {
+  for (int turn = blockIdx.x;; turn += gridDim.x) {
+  int jb = n_jobs - 1 - turn;           // without a counter: blockIdx.x, blockIdx.x + gridDim.x, ... -- counted from the end of the table as well
   if (job_counter) {
     if (tid == 0) *next_job = atomicAdd(job_counter, 1u);
     __syncthreads();                    // (the barrier that ends the previous job's last stage keeps this write behind every read of it)

@@ -267,10 +267,10 @@ int hmme_refine_pairs_device(hmme_ctx* ctx, const hmme_plane* const* curs, const
                              void* d_out_qmv, void* d_out_cost, void* stream);
 
 /* ---- environment (diagnostics and A/B measurements; none of these changes a result) ---------
- *   HMME_TRACE=1          one stderr line per context about launch geometry the library derives at run time (workgroups of the
- *                         refinement kernel per CU); the TEncOpenCL host module prints its call summary in its destructor
- *   HMME_FRAC_GRID=<n>    workgroups of a refinement launch: default = what the chip holds at a time (each takes job after job
- *                         from a counter); 0 = one workgroup per job (the launch of rounds 1-3); n = exactly n
+ *   HMME_TRACE=1          one stderr line per context about launch geometry the library derives at run time (with HMME_FRAC_GRID=-1:
+ *                         workgroups of the refinement kernel per CU); the TEncOpenCL host module prints its call summary in its destructor
+ *   HMME_FRAC_GRID=<n>    workgroups of a refinement launch: default (0) = one per job; n > 0 = exactly n, each taking job after
+ *                         job from a counter; -1 = as many of those as the chip holds at a time
  *   HMME_TAIL_PARTS=<n>   pieces per job of a launch's last, partial round of workgroups: default = the planner's choice
  *                         (DESIGN.md 5 "rounds of workgroups"); 1 = no tail plan
  *   HMME_STRIPS16=<n>     16-bit search kernel: that many equal window strips per job instead of the planner's number

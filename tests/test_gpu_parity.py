@@ -1111,6 +1111,26 @@ def test_profiling_tooling_produces_a_counter_summary(tmp_path):
             os.remove(os.path.join(ROOT, "profiles", f))
 
 
+def test_refinement_launch_modes_give_the_same_tables():
+    """HMME_FRAC_GRID: one workgroup per job (the default, whole-frame == oracle elsewhere in this file), n workgroups that take job
+    after job from the launch's counter, and as many of those as the chip holds -- the same tables, whoever evaluates a job"""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    crcs = {}
+    for grid in ("0", "7", "-1"):
+        env = dict(os.environ, HMME_FRAC_GRID=grid)
+        for bd in ("8", "10"):
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "refine_rate.py"), "832x480", bd, "mixed"], capture_output=True, text=True,
+                               timeout=600, env=env)
+            assert r.returncode == 0, r.stderr[-1500:]
+            crcs[(grid, bd)] = json.loads(r.stdout.strip().splitlines()[-1])["tables_crc32"]
+    for bd in ("8", "10"):
+        assert crcs[("0", bd)] == crcs[("7", bd)] == crcs[("-1", bd)], crcs
+    assert crcs[("0", "8")] != crcs[("0", "10")]
+
+
 def test_sequence_driver_reads_a_yuv_file(tmp_path):
     """tools/me_sequence.py --yuv: the frame feeder (planar 8-bit 4:2:0 reader, hmme/yuv.py) in front of the sharded sequence
     search; the file holds a texture panning by (2, 1) per picture, which the 64x64 PUs must find"""

@@ -47,6 +47,35 @@ int main() {
       printf(", \"%s_%s_ms_per_call\": %.4f", c.name, tags[k], ms2);
     }
   }
+  // explicit weighted prediction (a fade): the window is weighted once on the device, the 16-bit kernel searches the weighted copy,
+  // the refinement weights its interpolated prediction (hmme_search_ctu_w / hmme_search_refine_ctu_w)
+  {
+    const int sr = 64, side = 64 + 2 * sr + 16;
+    std::vector<int16_t> cur(64 * 64), ref((size_t)side * side);
+    srand(2);
+    for (auto& v : ref) v = (int16_t)(rand() % 256);
+    const int16_t* r0 = ref.data() + (size_t)(sr + 8) * side + (sr + 8);
+    const hmme_weight w = {45, 9, 6, 32};
+    for (int y = 0; y < 64; ++y)
+      for (int x = 0; x < 64; ++x) {
+        const int v = ((w.w0 * r0[(size_t)(y + 3) * side + x - 5] + w.round) >> w.shift) + w.offset;
+        cur[y * 64 + x] = (int16_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+      }
+    hmme_search_params p = {-sr, -sr, sr, sr, 5, -3, 1, 8};
+    std::vector<int16_t> mv(2 * HMME_NUM_CTU_PARTS), qmv(2 * HMME_NUM_CTU_PARTS);
+    std::vector<uint32_t> sad(HMME_NUM_CTU_PARTS), cost(HMME_NUM_CTU_PARTS);
+    const int n = 200;
+    for (int i = 0; i < 5; ++i)
+      if (hmme_search_ctu_w(ctx, cur.data(), 64, r0, side, &p, &w, mv.data(), sad.data()) != HMME_OK) { fprintf(stderr, "%s\n", hmme_last_error(ctx)); return 1; }
+    auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < n; ++i) hmme_search_ctu_w(ctx, cur.data(), 64, r0, side, &p, &w, mv.data(), sad.data());
+    printf(", \"8bit_sr64_weighted_ms_per_call\": %.4f", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / n);
+    for (int i = 0; i < 3; ++i)
+      if (hmme_search_refine_ctu_w(ctx, cur.data(), 64, r0, side, &p, &w, 1, mv.data(), sad.data(), qmv.data(), cost.data()) != HMME_OK) { fprintf(stderr, "%s\n", hmme_last_error(ctx)); return 1; }
+    t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < n; ++i) hmme_search_refine_ctu_w(ctx, cur.data(), 64, r0, side, &p, &w, 1, mv.data(), sad.data(), qmv.data(), cost.data());
+    printf(", \"8bit_sr64_weighted_search_refine_fade_ms_per_call\": %.4f", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / n);
+  }
   printf("}\n");
   hmme_destroy(ctx);
   return 0;

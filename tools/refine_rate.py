@@ -56,4 +56,7 @@ if os.environ.get("HMME_TIMELINE"):   # a library built with -DME_FRAC_T_TIMELIN
                        "mean_us_bottom_ctu_row": round(float(dur[-((w + 63) // 64):].mean()), 1),
                        "busy_share": round(float(dur.sum() / (e_us.max() * (per_wg > 0).sum())), 3)}
 frac = (d_q.to(torch.int32) - 4 * d_mv.to(torch.int32)).abs().amax().item()
-print(json.dumps({"size": f"{w}x{h}", "bit_depth": bd, "content": content, "refine_ms": out, "slots_per_s_hadamard": round(n * 593 / (out["hadamard"] * 1e-3)), "max_frac_offset_qpel": frac}))
+import zlib
+crc = zlib.crc32(d_c.cpu().numpy().tobytes(), zlib.crc32(d_q.cpu().numpy().tobytes()))   # of the last launch's tables (SAD distortion)
+print(json.dumps({"size": f"{w}x{h}", "bit_depth": bd, "content": content, "refine_ms": out, "slots_per_s_hadamard": round(n * 593 / (out["hadamard"] * 1e-3)), "max_frac_offset_qpel": frac,
+                  "tables_crc32": crc}))
