@@ -932,7 +932,31 @@ __host__ __device__ constexpr uint32_t me_htap_dw(int q, int c, int k) {
 #ifndef ME_FRAC_WAVES8
 #define ME_FRAC_WAVES8 3
 #endif
-constexpr int kFracTabH = 8, kFracTabV = 12;   // LDS tap tables: 7 rows (q = -3..3) of packed horizontal / float vertical taps
+// Quarter-pel stage: the three offsets of a component around its half-pel winner h (-1, 0, +1 half samples) all fit ONE 8-sample
+// window: h = -1 -> q = -3..-1, integer part -1: samples -4..+3; h = 0 -> q = -1..1: samples -3..+4 (q = -1 is fraction 3 at integer
+// part -1, whose first tap is 0, so its seven live taps start at sample -3 as well); h = +1 -> q = 1..3: samples -3..+4.  The lane
+// fetches its patch from that window's first sample on -- 11 x 11 samples instead of 12 x 12, 8 taps instead of a 9-tap window with a
+// zero at one end.  me_tap8(h3, d3, j): tap of window sample j (0..7) for winner h3 - 1 and offset d3 - 1 (both 0..2).
+__host__ __device__ constexpr int me_win8_first(int h3) { return h3 == 0 ? -4 : -3; }   // first window sample relative to the output sample
+__host__ __device__ constexpr int me_tap8(int h3, int d3, int j) {
+  const int q = 2 * (h3 - 1) + (d3 - 1);
+  const int t = j + me_win8_first(h3) - ((q >> 2) - 3);   // tap index: sample = out + (q >> 2) - 3 + t
+  return (t < 0 || t > 7) ? 0 : me_luma_tap(q & 3, t);
+}
+static_assert(me_luma_tap(3, 0) == 0, "the tap q = -1 loses to the shared window must be zero");
+// dword k of the packed 8-tap window (BPS 1: four i8 per dword; BPS 2: two i16)
+template <int BPS>
+__host__ __device__ constexpr uint32_t me_htap8_dw(int h3, int d3, int k) {
+  uint32_t w = 0;
+  for (int i = 0; i < 4 / BPS; ++i) {
+    const int j = (4 / BPS) * k + i;
+    const int t = j < 8 ? me_tap8(h3, d3, j) : 0;
+    w |= BPS == 1 ? (uint32_t)(t & 0xff) << (8 * i) : (uint32_t)(t & 0xffff) << (16 * i);
+  }
+  return w;
+}
+constexpr int kFracTabH = 8, kFracTabV = 8;   // LDS tap tables: 9 rows (winner x offset) of packed horizontal / float vertical taps
+constexpr int kFracRows1 = 11;                // patch rows (and samples per row) of the quarter-pel stage
 
 #define ME_FRAC_BFLY(R, T, PERM) "v_fmac_f32_dpp " #R ", " #R ", " #T " quad_perm:" PERM " row_mask:0xf bank_mask:0xf\n\t"
 __device__ __forceinline__ float me_dpp_f(float v, const int ctrl_b1) {
@@ -1022,6 +1046,12 @@ __device__ __forceinline__ uint32_t me_frac_dist(const float (&d)[16], float s1,
 // the shift; org_sub = what to take off a staged current sample: its staging bias + offset.  WP = 0: none of this is compiled in.
 struct FracWp { float ws, rs, org_sub; };
 constexpr float kRoundMagic = 12582912.0f;   // 1.5 * 2^23: x + magic rounds x to the nearest integer (ties to even)
+// First pass on 8-bit planes without v_cvt_f32_i32: the dot-product chain of a filtered sample starts from the BIT PATTERN of
+// kRoundMagic (0x4B400000; ulp 1, so adding an integer k, |k| < 2^22, to the pattern gives the pattern of kRoundMagic + k -- here
+// |k| <= 128 * 112) and one v_sub_f32 takes the magic off again: v_dot4_i32_i8 (the three-operand form, addend = the magic) +
+// v_sub_f32 in place of v_mov_b32 0 + v_dot4c + v_cvt_f32_i32 (13.6 -> 7.7 issue cycles per sample, profiles/r01d_ubench_valu_rates3.txt).
+// (clamp = 1 keeps the instruction in its three-operand form -- the accumulating v_dot4c has no clamp bit -- and never clamps here)
+__device__ __forceinline__ int me_dot4_magic(uint32_t p, uint32_t t) { return __builtin_amdgcn_sdot4((int)p, (int)t, 0x4B400000, true); }
 // KIND8: the lane is one quadrant (role 0..3 = TL, TR, BL, BR) of an 8x8 Hadamard block; all four lanes of the quad
 // return the block's distortion.  out[point]: distortion of the 9 refinement points in HM's point order.
 template <int STAGE, int HAD, int BPS, int KIND8, int WP>
@@ -1081,6 +1111,15 @@ __device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3 * BPS], c
     for (int r = 0; r < 12; ++r)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
+#ifndef ME_FRAC_CVT_FIRST_PASS
+        if constexpr (BPS == 1 && STAGE == 1) {
+          int a = me_dot4_magic(P[r][0], T[c][0]);
+          a = __builtin_amdgcn_sdot4((int)P[r][1], (int)T[c][1], a, false);
+          a = __builtin_amdgcn_sdot4((int)P[r][2], (int)T[c][2], a, false);
+          tmp[r][c] = __int_as_float(a) - kRoundMagic;
+          continue;
+        }
+#endif
         int a = off1;
 #pragma unroll
         for (int k = 0; k < PW; ++k) {
@@ -1125,6 +1164,101 @@ __device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3 * BPS], c
   }
 }
 
+// STAGE 1 as the kernel runs it: the eight quarter-pel points around the half-pel winner (h3x - 1, h3y - 1) from the 11 x 11 patch that
+// starts at the shared window's first sample (me_tap8).  Same arithmetic as me_frac_eval<1, ...>, sample for sample: the taps that are
+// left out are zeros.  P: 11 rows x 11 samples; tab_h / tab_v: [h3 * 3 + offset] rows of 8 taps.
+template <int HAD, int BPS, int KIND8, int WP>
+__device__ __forceinline__ void me_frac_eval1(const uint32_t (&P)[kFracRows1][3 * BPS], const float (&orgM)[16], int h3x, int h3y, int role, int bd,
+                                              float clip_lo, const uint32_t* tab_h, const float* tab_v, bool want4, const FracWp wp,
+                                              uint32_t (&out)[9], uint32_t (&out4)[9]) {
+  constexpr int PW = 3 * BPS;
+  constexpr int idxQ[3][3] = {{3, 1, 4}, {5, 0, 6}, {7, 2, 8}};   // [dy+1][dx+1], s_acMvRefineQ order (reference TEncSearch.cpp:64-75)
+  const float s1 = (role & 1) ? -1.f : 1.f, s2 = (role & 2) ? -1.f : 1.f;
+  const int sh1 = BPS == 1 ? 0 : bd - 8;
+  const int off1 = BPS == 1 ? 0 : -(8192 << sh1);
+  const float sc2 = BPS == 1 ? 1.f / 4096.f : __int_as_float((127 - (20 - bd)) << 23);
+  const float maxv = clip_lo + (BPS == 1 ? 255.f : (float)((1 << bd) - 1));
+  out[0] = 0; out4[0] = 0;   // the centre IS the half-pel winner: carried over by the slot's winner thread, not evaluated again
+#pragma unroll
+  for (int dxi = 0; dxi < 3; ++dxi) {
+    const uint32_t* row = tab_h + (h3x * 3 + dxi) * kFracTabH;
+    float tmp[kFracRows1][4];   // first pass into the 14-bit intermediates
+    if constexpr (BPS == 1) {
+      // output column c reads bytes c .. c + 7 of the row: the packed taps moved up by c bytes (column 0 stays inside two dwords)
+      const uint32_t w0 = row[0], w1 = row[1];
+      uint32_t T[4][3];
+      T[0][0] = w0; T[0][1] = w1; T[0][2] = 0;
+#pragma unroll
+      for (int c = 1; c < 4; ++c) {
+        T[c][0] = w0 << (8 * c);
+        T[c][1] = __builtin_amdgcn_alignbyte(w1, w0, 4 - c);
+        T[c][2] = w1 >> (8 * (4 - c));
+      }
+#pragma unroll
+      for (int r = 0; r < kFracRows1; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#ifndef ME_FRAC_CVT_FIRST_PASS
+          int a = me_dot4_magic(P[r][0], T[c][0]);
+#else
+          int a = __builtin_amdgcn_sdot4((int)P[r][0], (int)T[c][0], 0, false);
+#endif
+          a = __builtin_amdgcn_sdot4((int)P[r][1], (int)T[c][1], a, false);
+          if (c > 0) a = __builtin_amdgcn_sdot4((int)P[r][2], (int)T[c][2], a, false);
+#ifndef ME_FRAC_CVT_FIRST_PASS
+          tmp[r][c] = __int_as_float(a) - kRoundMagic;
+#else
+          tmp[r][c] = (float)a;
+#endif
+        }
+    } else {
+      typedef short v2s __attribute__((ext_vector_type(2)));
+      uint32_t w[4], h[5];   // h: the taps moved up by one sample
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[k] = row[k];
+      h[0] = w[0] << 16;
+#pragma unroll
+      for (int k = 1; k < 4; ++k) h[k] = __builtin_amdgcn_alignbyte(w[k], w[k - 1], 2);
+      h[4] = w[3] >> 16;
+#pragma unroll
+      for (int r = 0; r < kFracRows1; ++r) {
+        int a0 = off1, a1 = off1, a2 = off1, a3 = off1;   // columns 0..3: samples c .. c + 7 = dwords c / 2 .. (c + 7) / 2
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, P[r][k]), __builtin_bit_cast(v2s, w[k]), a0, false);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) a1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, P[r][k]), __builtin_bit_cast(v2s, h[k]), a1, false);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a2 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, P[r][k + 1]), __builtin_bit_cast(v2s, w[k]), a2, false);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) a3 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, P[r][k + 1]), __builtin_bit_cast(v2s, h[k]), a3, false);
+        tmp[r][0] = (float)(a0 >> sh1); tmp[r][1] = (float)(a1 >> sh1); tmp[r][2] = (float)(a2 >> sh1); tmp[r][3] = (float)(a3 >> sh1);
+      }
+    }
+#pragma unroll
+    for (int dyi = 0; dyi < 3; ++dyi) {
+      if (dxi == 1 && dyi == 1) continue;
+      float cv[8];   // taps * 2^-sh2 (exact): the accumulator is the sample value with its fraction
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cv[j] = tab_v[(h3y * 3 + dyi) * kFracTabV + j];
+      float d[16];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float a = 524288.5f * sc2;   // second pass (TComInterpolationFilter.cpp:195-212)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a = __builtin_fmaf(cv[j], tmp[r + j][c], a);
+          const float y = __builtin_amdgcn_fmed3f(a, clip_lo, maxv) + kRoundMagic;   // clip, then round (the bounds are integers)
+          d[4 * r + c] = orgM[4 * r + c] - (WP ? __builtin_floorf(__builtin_fmaf(wp.ws, y - kRoundMagic, wp.rs)) : y);
+        }
+      uint32_t own4 = 0;
+      const uint32_t contrib = me_frac_dist<HAD, KIND8>(d, s1, s2, want4, own4);
+      out[idxQ[dyi][dxi]] = contrib;
+      out4[idxQ[dyi][dxi]] = own4;
+    }
+  }
+}
+
 // Work sharing.  A kind-8 slot (width and height multiples of 8) is a set of 8x8 Hadamard blocks, any other slot a set
 // of 4x4 blocks; each of the 64 8x8 positions of the CTU is covered by kFracCover8 = 18 kind-8 slots (7 partition modes
 // at 64 and 32, three at 16, one at 8) and each of the 256 4x4 positions by kFracCover4 = 6 others (the 4 AMP shapes at
@@ -1162,6 +1296,19 @@ __device__ __forceinline__ void me_frac_eval0(const uint32_t (&P)[12][3 * BPS], 
   const float c64 = 64.f * sc2;
   // first pass of patch row r with the tap window of (quarter offset q, output column c)
   auto first = [&](int r, int q, int c) -> float {
+#ifndef ME_FRAC_CVT_FIRST_PASS
+    if constexpr (BPS == 1) {
+      int a = 0;
+      bool started = false;
+#pragma unroll
+      for (int k = 0; k < PW; ++k) {
+        if (me_htap_dw<BPS>(q, c, k) == 0) continue;
+        a = started ? __builtin_amdgcn_sdot4((int)P[r][k], (int)me_htap_dw<BPS>(q, c, k), a, false) : me_dot4_magic(P[r][k], me_htap_dw<BPS>(q, c, k));
+        started = true;
+      }
+      return __int_as_float(a) - kRoundMagic;
+    }
+#endif
     int a = off1;
 #pragma unroll
     for (int k = 0; k < PW; ++k) {
@@ -1215,6 +1362,38 @@ __device__ __forceinline__ void me_frac_eval0(const uint32_t (&P)[12][3 * BPS], 
     ME_FRAC_POINT(yZ, 0, 0, 1, 0) ME_FRAC_POINT(yZ, 0, 1, 1, 2)
   }
   // ---- integer columns
+#ifndef ME_FRAC_CVT_FIRST_PASS
+  if constexpr (BPS == 1) {
+    // the first pass of an integer column is 64 * p - 8192: the sample itself goes into the vertical filter (v_cvt_f32_ubyteN of the
+    // raw byte), the taps carry the 64 and the constant the -8192 -- the same real number, exact in fp32 like the general form.  The
+    // integer-position sample needs neither filter nor clip (8-bit planes carry no bi-prediction bias: clip_lo = 0)
+    float V0[12][4];
+#pragma unroll
+    for (int r = 0; r < 12; ++r) {
+      const uint32_t raw = P[r][1] ^ 0x80808080u;   // patch columns 4..7 = block columns 0..3
+#pragma unroll
+      for (int c = 0; c < 4; ++c) V0[r][c] = (float)((raw >> (8 * c)) & 0xff);
+    }
+    float cw[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) cw[t] = cv[t] * 64.f;
+    const float init_i = init - 8192.f * 64.f * sc2;
+    float yG[5][4], yZ[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        float a = init_i;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) a = __builtin_fmaf(cw[t], V0[j + t][c], a);
+        yG[j][c] = clipround(a);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) yZ[r][c] = V0[r + 4][c] + kRoundMagic;
+    }
+    ME_FRAC_POINT(yG, 0, 0, 0, 1) ME_FRAC_POINT(yG, 1, 0, 2, 1) ME_FRAC_POINT(yZ, 0, 0, 1, 1)
+  } else
+#endif
   {
     float V0[12][4];
 #pragma unroll
@@ -1250,7 +1429,7 @@ struct FracRaw {
   uint32_t o;       // byte offset of the patch inside its first dword
 };
 
-template <int BPS, int KIND8>
+template <int STAGE, int BPS, int KIND8>
 __device__ __forceinline__ void me_frac_fetch(const uint8_t* __restrict__ src, int gpitch, const uint32_t* st, const uint16_t* cover, int pair, int role,
                                               FracRaw<BPS>& R) {
   constexpr int PW = 3 * BPS, NCOV = KIND8 ? kFracCover8 : kFracCover4;
@@ -1258,16 +1437,20 @@ __device__ __forceinline__ void me_frac_fetch(const uint8_t* __restrict__ src, i
   const int pos = q / NCOV;
   const uint32_t sv = st[cover[pair]];
   const int bx = KIND8 ? 2 * (pos & 7) + (role & 1) : (pos & 15), by = KIND8 ? 2 * (pos >> 3) + (role >> 1) : (pos >> 4);
-  // patch (0,0) = block sample (-4,-4) = window row (by*4 + my - lt_y), sample (bx*4 + mx - lt_x) (halo offsets cancel)
-  const int prow = by * 4 + (int)((sv >> 9) & 0x1ff), pcol = (bx * 4 + (int)(sv & 0x1ff)) * BPS;   // pcol in bytes
+  // patch (0,0) = block sample (-4,-4) = window row (by*4 + my - lt_y), sample (bx*4 + mx - lt_x) (halo offsets cancel); in the
+  // quarter-pel stage the patch starts at the first sample of the component's shared 8-tap window (me_win8_first): (-4 or -3, -4 or -3)
+  const int skip_x = STAGE ? 4 + me_win8_first((int)((sv >> 18) & 3)) : 0, skip_y = STAGE ? 4 + me_win8_first((int)((sv >> 20) & 3)) : 0;
+  const int prow = by * 4 + (int)((sv >> 9) & 0x1ff) + skip_y, pcol = (bx * 4 + (int)(sv & 0x1ff) + skip_x) * BPS;   // pcol in bytes
   const uint8_t* a = src + (long)prow * gpitch + pcol;
   const uint32_t o = (uint32_t)(uintptr_t)a & 3u;
   const uint32_t* __restrict__ rowp = (const uint32_t*)(a - o);
   const int gp = gpitch >> 2;
+  // 11 u16 samples and their alignment fill six dwords at most; the seventh only feeds sample 11, which no tap reads
+  constexpr int ROWS = STAGE ? kFracRows1 : 12, NL = (STAGE && BPS == 2) ? PW : PW + 1;
 #pragma unroll
-  for (int r = 0; r < 12; ++r)
+  for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-    for (int k = 0; k <= PW; ++k) R.w[r][k] = rowp[r * gp + k];
+    for (int k = 0; k <= PW; ++k) R.w[r][k] = k < NL ? rowp[r * gp + k] : 0u;
   R.sv = sv;
   R.o = o;
 }
@@ -1282,9 +1465,10 @@ __device__ __forceinline__ void me_frac_compute(const FracRaw<BPS>& R, const uin
   const uint16_t* cov = cover + (KIND8 ? 0 : kFracPairs8) + pos * NCOV;
   const uint32_t sv = R.sv;
   const int bx = KIND8 ? 2 * (pos & 7) + (role & 1) : (pos & 15), by = KIND8 ? 2 * (pos >> 3) + (role >> 1) : (pos >> 4);
-  uint32_t P[12][PW];
+  constexpr int ROWS = STAGE ? kFracRows1 : 12;
+  uint32_t P[ROWS][PW];
 #pragma unroll
-  for (int r = 0; r < 12; ++r)
+  for (int r = 0; r < ROWS; ++r)
 #pragma unroll
     for (int k = 0; k < PW; ++k) P[r][k] = __builtin_amdgcn_alignbyte(R.w[r][k + 1], R.w[r][k], R.o) ^ (BPS == 1 ? 0x80808080u : 0u);
   float orgM[16];   // current samples + kRoundMagic (exact: integers below 2^24); WP: current samples - staging bias - offset, no magic
@@ -1302,7 +1486,6 @@ __device__ __forceinline__ void me_frac_compute(const FracRaw<BPS>& R, const uin
     }
   }
   uint32_t dist[9], dist4[9];
-  const int cqx = STAGE ? 2 * ((int)((sv >> 18) & 3) - 1) : 0, cqy = STAGE ? 2 * ((int)((sv >> 20) & 3) - 1) : 0;
   // Slots made of 4x4 blocks (the AMP shapes at 16, 8x4, 4x8: six per 4x4 position) whose key equals this item's get this lane's 4x4
   // block for nothing: same patch, same interpolated samples, same difference, same 4x4 transform -- the work-list pass left such
   // (4x4 position, key) pairs out of the 4x4 list (me_frac_dedupe4).  On coherent content that is every one of them.
@@ -1313,11 +1496,15 @@ __device__ __forceinline__ void me_frac_compute(const FracRaw<BPS>& R, const uin
     for (int k = 0; k < kFracCover4; ++k) match4 |= (((st[cov4[k]] ^ sv) & keymask) == 0 ? 1u : 0u) << k;
   }
   const bool want4 = KIND8 && __any(match4 != 0);
+  if constexpr (STAGE == 0) {
 #ifndef ME_FRAC_STAGE0_PLAIN
-  if constexpr (STAGE == 0) me_frac_eval0<HAD, BPS, KIND8, WP>(P, orgM, role, bd, clip_lo, want4, wp, dist, dist4);
-  else
+    me_frac_eval0<HAD, BPS, KIND8, WP>(P, orgM, role, bd, clip_lo, want4, wp, dist, dist4);
+#else
+    me_frac_eval<0, HAD, BPS, KIND8, WP>(P, orgM, 0, 0, role, bd, clip_lo, tab_h, tab_v, want4, wp, dist, dist4);
 #endif
-    me_frac_eval<STAGE, HAD, BPS, KIND8, WP>(P, orgM, cqx, cqy, role, bd, clip_lo, tab_h, tab_v, want4, wp, dist, dist4);
+  } else {
+    me_frac_eval1<HAD, BPS, KIND8, WP>(P, orgM, (int)((sv >> 18) & 3), (int)((sv >> 20) & 3), role, bd, clip_lo, tab_h, tab_v, want4, wp, dist, dist4);
+  }
 #ifndef ME_FRAC_T_NOATOMICS   // timing-only builds (tools/r04_frac_breakdown.sh; results are wrong by design): ME_FRAC_T_NOATOMICS, ME_FRAC_T_NOITEMS
   if (KIND8 && want4) {
 #pragma unroll
@@ -1362,13 +1549,13 @@ __device__ __forceinline__ void me_frac_stage_items(const uint8_t* __restrict__ 
 #pragma unroll 1
   for (int i8 = tid; i8 < n8; i8 += NT) {
     const int pair = list8[i8 >> 2];
-    me_frac_fetch<BPS, 1>(src, gpitch, st, cover, pair, role, R);
+    me_frac_fetch<STAGE, BPS, 1>(src, gpitch, st, cover, pair, role, R);
     me_frac_compute<STAGE, HAD, BPS, 1, WP>(R, curl, st, cover, pair, role, bd, clip_lo, wp, tab_h, tab_v, acc);
   }
 #pragma unroll 1
   for (int i4 = tid; i4 < n4; i4 += NT) {
     const int pair = list4[i4];
-    me_frac_fetch<BPS, 0>(src, gpitch, st, cover, pair, 0, R);
+    me_frac_fetch<STAGE, BPS, 0>(src, gpitch, st, cover, pair, 0, R);
     me_frac_compute<STAGE, HAD, BPS, 0, WP>(R, curl, st, cover, pair, 0, bd, clip_lo, wp, tab_h, tab_v, acc);
   }
 }
@@ -1426,13 +1613,14 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
   // bit_depth_bias: bit depth in the low 8 bits; bit 8 set = block and window carry the bias 2^bitDepth of a bi-prediction origin
   // (2*org - pred, TEncSearch.cpp:3702-3712: current samples in [-maxv, 2*maxv]; per-CTU calls only, u16 staging)
   const int bit_depth = bit_depth_bias & 0xff;
-  const float clip_lo = (bit_depth_bias & 0x100) ? (float)(1 << bit_depth) : 0.f;
+  static_assert(BPS == 2 || !WP, "weighted calls and bi-prediction origins stage u16 samples (hmme.hip ctu_call)");
+  const float clip_lo = (BPS == 2 && (bit_depth_bias & 0x100)) ? (float)(1 << bit_depth) : 0.f;
   constexpr int NT = frac_threads(BPS);
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t* acc = smem;                 // [593][kFracAccRow] distortion sums of the current stage
   uint32_t* st = smem + kFracAccDw;     // [593] slot state: (mx - lt_x) | (my - lt_y) << 9 | (half_x + 1) << 18 | (half_y + 1) << 20
-  uint32_t* tab_h = st + 600;           // [7][kFracTabH] packed horizontal taps of q = -3..3
-  float* tab_v = (float*)(tab_h + 7 * kFracTabH);   // [7][kFracTabV] vertical taps
+  uint32_t* tab_h = st + 600;           // [9][kFracTabH] packed horizontal taps of the quarter-pel stage: row = (half-pel winner + 1) * 3 + (offset + 1), me_tap8
+  float* tab_v = (float*)(tab_h + 9 * kFracTabH);   // [9][kFracTabV] vertical taps, same rows
   uint32_t* counter = tab_h + 152;      // [2] lengths of the two work lists
   uint16_t* list8 = (uint16_t*)(tab_h + 160);                  // distinct (8x8 position, key) pairs
   uint16_t* list4 = (uint16_t*)(tab_h + 160 + kFracPairs8 / 2);   // distinct (4x4 position, key) pairs
@@ -1442,10 +1630,11 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
   const int tid = threadIdx.x;
   const int bd = BPS == 1 ? 8 : bit_depth;
   // tables that do not depend on the job
-  if (tid < 7 * kFracTabH) tab_h[tid] = (tid & 7) < 3 * BPS ? me_htap_dw<BPS>((tid >> 3) - 3, 0, tid & 7) : 0u;
-  if (tid >= 64 && tid < 64 + 7 * kFracTabV) {
-    const int i = tid - 64, row = i / kFracTabV, j = i - row * kFracTabV;
-    tab_v[i] = j < 9 ? (float)me_tap9(row - 3, j) * (BPS == 1 ? 1.f / 4096.f : __int_as_float((127 - (20 - bd)) << 23)) : 0.f;
+  static_assert(9 * (kFracTabH + kFracTabV) <= 152, "me_frac_kernel: the tap tables end where the list counters start");
+  if (tid < 9 * kFracTabH) tab_h[tid] = (tid & 7) < 2 * BPS ? me_htap8_dw<BPS>((tid >> 3) / 3, (tid >> 3) % 3, tid & 7) : 0u;
+  if (tid >= 128 && tid < 128 + 9 * kFracTabV) {
+    const int i = tid - 128, row = i / kFracTabV, j = i - row * kFracTabV;
+    tab_v[i] = (float)me_tap8(row / 3, row % 3, j) * (BPS == 1 ? 1.f / 4096.f : __int_as_float((127 - (20 - bd)) << 23));
   }
   for (int i = tid; i < (kFracPairs8 + kFracPairs4) / 8; i += NT) ((uint4*)cover)[i] = ((const uint4*)cover_g)[i];
 
