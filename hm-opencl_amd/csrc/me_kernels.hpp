@@ -1031,15 +1031,20 @@ __device__ __forceinline__ uint32_t me_frac_dist(const float (&d)[16], float s1,
   return contrib;
 }
 
-// STAGE 0: half-pel points (step 2 quarter units around the integer MV); STAGE 1: quarter-pel points around the
-// slot's half-pel winner (cqx, cqy).  P: 12 patch rows x 12 samples (3 * BPS dwords), patch (0,0) = block (-4,-4);
-// 8-bit samples arrive XORed with 0x80 (signed bytes p - 128: the 128 * 64 this removes IS the -8192 offset of the
-// first pass).  orgM: current samples + kRoundMagic.
-// Arithmetic: first pass in integer dot products (v_dot4c_i32_i8 / v_dot2c_i32_i16, shift bd-8), second pass,
-// rounding, clipping and the Hadamard transform in fp32 -- every value is an integer (or an integer + 0.5) below
-// 2^23, so fp32 is exact and v_fmac_f32 issues at the full VALU rate where v_mad_i32_i24 does not
-// (tools/ubench/valu_rates3).  bd = bit depth of the video (8 when BPS == 1): the two passes shift by bd-8 and
-// 20-bd around the 14-bit intermediate (TComInterpolationFilter.cpp:170-212: headRoom = 14 - bd).
+// The evaluation of one work item.  Stage 0 (me_frac_eval0): the nine half-pel points around the integer MV; stage 1 (me_frac_eval1):
+// the eight quarter-pel points around the slot's half-pel winner.  P: patch rows of 3 * BPS dwords, 8-bit samples XORed with 0x80
+// (signed bytes p - 128: the 128 * 64 this removes IS the -8192 offset of the first pass).  orgM: current samples + kRoundMagic.
+// KIND8: the lane is one quadrant (role 0..3 = TL, TR, BL, BR) of an 8x8 Hadamard block; all four lanes of the quad return the
+// block's distortion.  out[point]: distortion of the refinement points in HM's point order (s_acMvRefineH / Q, TEncSearch.cpp:51-75).
+// Arithmetic: first pass in integer dot products (v_dot4_i32_i8 / v_dot2c_i32_i16, shift bd-8), second pass, rounding, clipping
+// and the Hadamard transform in fp32 -- every value is an integer (or an integer + a fraction of a few bits) below 2^23, so fp32 is
+// exact, the order of summation is free, and v_fmac_f32 issues at the full VALU rate where v_mad_i32_i24 does not
+// (tools/ubench/valu_rates3).  bd = bit depth of the video (8 when BPS == 1): the two passes shift by bd-8 and 20-bd around the
+// 14-bit intermediate (TComInterpolationFilter.cpp:170-212: headRoom = 14 - bd).  Second pass: floor((S + 2^(sh2-1) + (8192 << 6))
+// >> sh2) = nearest integer of (S + 524288 + 0.5) * 2^-sh2 (never a tie).  clip_lo: 0, or the bias 2^bd that block and window of a
+// bi-prediction origin carry (hmme.hip ctu_call): the taps sum to 64, so a bias B = 2^bd passes both filter stages exactly
+// (64 * B >> (bd - 8) = 2^14, 64 * 2^14 >> (20 - bd) = B): the predicted sample comes out as pred + B, is clipped to [B, B + maxv]
+// and meets a current sample that carries the same B.
 // explicit weighted prediction in the refinement (xGetHADsw / xGetSADw, TComRdCostWeightPrediction.cpp:407-470, :55-90): the interpolated,
 // clipped prediction p is weighted sample by sample, pred = ((w0 * p + round) >> shift) + offset, before the difference is taken.
 // ws = w0 * 2^-shift, rs = round * 2^-shift: fma(ws, p, rs) IS (w0 * p + round) / 2^shift exactly (|w0 * p + round| < 2^24), v_floor_f32
@@ -1052,121 +1057,9 @@ constexpr float kRoundMagic = 12582912.0f;   // 1.5 * 2^23: x + magic rounds x t
 // v_sub_f32 in place of v_mov_b32 0 + v_dot4c + v_cvt_f32_i32 (13.6 -> 7.7 issue cycles per sample, profiles/r01d_ubench_valu_rates3.txt).
 // (clamp = 1 keeps the instruction in its three-operand form -- the accumulating v_dot4c has no clamp bit -- and never clamps here)
 __device__ __forceinline__ int me_dot4_magic(uint32_t p, uint32_t t) { return __builtin_amdgcn_sdot4((int)p, (int)t, 0x4B400000, true); }
-// KIND8: the lane is one quadrant (role 0..3 = TL, TR, BL, BR) of an 8x8 Hadamard block; all four lanes of the quad
-// return the block's distortion.  out[point]: distortion of the 9 refinement points in HM's point order.
-template <int STAGE, int HAD, int BPS, int KIND8, int WP>
-__device__ __forceinline__ void me_frac_eval(const uint32_t (&P)[12][3 * BPS], const float (&orgM)[16], int cqx, int cqy, int role, int bd, float clip_lo,
-                                             const uint32_t* tab_h, const float* tab_v, bool want4, const FracWp wp, uint32_t (&out)[9],
-                                             uint32_t (&out4)[9]) {
-  constexpr int step = STAGE == 0 ? 2 : 1, PW = 3 * BPS;
-  // point index of (dx, dy) in s_acMvRefineH / s_acMvRefineQ order (reference TEncSearch.cpp:51-75)
-  constexpr int idxH[3][3] = {{5, 1, 6}, {3, 0, 4}, {7, 2, 8}}, idxQ[3][3] = {{3, 1, 4}, {5, 0, 6}, {7, 2, 8}};   // [dy+1][dx+1]
-  const float s1 = (role & 1) ? -1.f : 1.f, s2 = (role & 2) ? -1.f : 1.f;
-  const int sh1 = BPS == 1 ? 0 : bd - 8;
-  const int off1 = BPS == 1 ? 0 : -(8192 << sh1);
-  // second pass: floor((S + 2^(sh2-1) + (8192 << 6)) >> sh2) = nearest integer of (S + 524288 + 0.5) * 2^-sh2 (never a tie)
-  const float sc2 = BPS == 1 ? 1.f / 4096.f : __int_as_float((127 - (20 - bd)) << 23);
-  // clip_lo: 0, or the bias 2^bd that block and window of a bi-prediction origin carry (hmme.hip ctu_call).  The taps sum to 64, so a
-  // bias B = 2^bd passes both filter stages exactly (64 * B >> (bd - 8) = 2^14, 64 * 2^14 >> (20 - bd) = B): the predicted sample
-  // comes out as pred + B, is clipped to [B, B + maxv] and meets a current sample that carries the same B
-  const float maxv = clip_lo + (BPS == 1 ? 255.f : (float)((1 << bd) - 1));
-#pragma unroll
-  for (int dxi = 0; dxi < 3; ++dxi) {
-    uint32_t T[4][PW];
-    if (STAGE == 0) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int k = 0; k < PW; ++k) T[c][k] = me_htap_dw<BPS>(step * (dxi - 1), c, k);
-    } else {
-      const uint32_t* row = tab_h + (cqx + step * (dxi - 1) + 3) * kFracTabH;
-      if constexpr (BPS == 1) {
-        const uint32_t w0 = row[0], w1 = row[1], w2 = row[2];
-        T[0][0] = w0; T[0][1] = w1; T[0][2] = w2;
-#pragma unroll
-        for (int c = 1; c < 4; ++c) {
-          T[c][0] = w0 << (8 * c);
-          T[c][1] = __builtin_amdgcn_alignbyte(w1, w0, 4 - c);
-          T[c][2] = __builtin_amdgcn_alignbyte(w2, w1, 4 - c);
-        }
-      } else {
-        uint32_t w[5], h[6];   // h: the row shifted up by one sample
-#pragma unroll
-        for (int k = 0; k < 5; ++k) w[k] = row[k];
-        h[0] = w[0] << 16;
-#pragma unroll
-        for (int k = 1; k < 5; ++k) h[k] = __builtin_amdgcn_alignbyte(w[k], w[k - 1], 2);
-        h[5] = 0;   // tap 9 does not exist
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          T[0][k] = k < 5 ? w[k] : 0;
-          T[1][k] = h[k];
-          T[2][k] = k >= 1 ? w[k - 1] : 0;
-          T[3][k] = k >= 1 ? h[k - 1] : 0;
-        }
-      }
-    }
-    float tmp[12][4];   // first pass into the 14-bit intermediates
-#pragma unroll
-    for (int r = 0; r < 12; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-#ifndef ME_FRAC_CVT_FIRST_PASS
-        if constexpr (BPS == 1 && STAGE == 1) {
-          int a = me_dot4_magic(P[r][0], T[c][0]);
-          a = __builtin_amdgcn_sdot4((int)P[r][1], (int)T[c][1], a, false);
-          a = __builtin_amdgcn_sdot4((int)P[r][2], (int)T[c][2], a, false);
-          tmp[r][c] = __int_as_float(a) - kRoundMagic;
-          continue;
-        }
-#endif
-        int a = off1;
-#pragma unroll
-        for (int k = 0; k < PW; ++k) {
-          if (STAGE == 0 && me_htap_dw<BPS>(step * (dxi - 1), c, k) == 0) continue;
-          if constexpr (BPS == 1) {
-            a = __builtin_amdgcn_sdot4((int)P[r][k], (int)T[c][k], a, false);
-          } else {
-            typedef short v2s __attribute__((ext_vector_type(2)));
-            a = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, P[r][k]), __builtin_bit_cast(v2s, T[c][k]), a, false);
-          }
-        }
-        tmp[r][c] = (float)(BPS == 1 ? a : a >> sh1);
-      }
-#pragma unroll
-    for (int dyi = 0; dyi < 3; ++dyi) {
-      // the centre of the quarter-pel stage IS the half-pel stage's winning point: same position, same interpolated samples, same
-      // distortion -- HM evaluates it again (TEncSearch.cpp:4324-4331), here the slot's winner thread carries the sum over
-      if (STAGE == 1 && dxi == 1 && dyi == 1) { out[0] = 0; out4[0] = 0; continue; }
-      float cv[9];   // taps * 2^-sh2 (exact): the accumulator is the sample value with its fraction
-#pragma unroll
-      for (int j = 0; j < 9; ++j)
-        cv[j] = STAGE == 0 ? (float)me_tap9(step * (dyi - 1), j) * sc2 : tab_v[(cqy + step * (dyi - 1) + 3) * kFracTabV + j];
-      float d[16];
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          float a = 524288.5f * sc2;   // second pass (TComInterpolationFilter.cpp:195-212)
-#pragma unroll
-          for (int j = 0; j < 9; ++j) {
-            if (STAGE == 0 && me_tap9(step * (dyi - 1), j) == 0) continue;
-            a = __builtin_fmaf(cv[j], tmp[r + j][c], a);
-          }
-          const float y = __builtin_amdgcn_fmed3f(a, clip_lo, maxv) + kRoundMagic;   // clip, then round (the bounds are integers)
-          d[4 * r + c] = orgM[4 * r + c] - (WP ? __builtin_floorf(__builtin_fmaf(wp.ws, y - kRoundMagic, wp.rs)) : y);
-        }
-      uint32_t own4 = 0;
-      const uint32_t contrib = me_frac_dist<HAD, KIND8>(d, s1, s2, want4, own4);
-      out[STAGE == 0 ? idxH[dyi][dxi] : idxQ[dyi][dxi]] = contrib;
-      out4[STAGE == 0 ? idxH[dyi][dxi] : idxQ[dyi][dxi]] = own4;
-    }
-  }
-}
-
 // STAGE 1 as the kernel runs it: the eight quarter-pel points around the half-pel winner (h3x - 1, h3y - 1) from the 11 x 11 patch that
-// starts at the shared window's first sample (me_tap8).  Same arithmetic as me_frac_eval<1, ...>, sample for sample: the taps that are
-// left out are zeros.  P: 11 rows x 11 samples; tab_h / tab_v: [h3 * 3 + offset] rows of 8 taps.
+// starts at the shared window's first sample (me_tap8): HM's two filter passes sample for sample -- the taps left out are zeros.
+// P: 11 rows x 11 samples; tab_h / tab_v: [h3 * 3 + offset] rows of 8 taps.
 template <int HAD, int BPS, int KIND8, int WP>
 __device__ __forceinline__ void me_frac_eval1(const uint32_t (&P)[kFracRows1][3 * BPS], const float (&orgM)[16], int h3x, int h3y, int role, int bd,
                                               float clip_lo, const uint32_t* tab_h, const float* tab_v, bool want4, const FracWp wp,
@@ -1277,8 +1170,8 @@ constexpr uint32_t kFracKey0 = 0x3ffffu, kFracKey1 = 0x3fffffu;
 // integer column x is the half-pel sample to the left of x + 1, and likewise for rows: the horizontal half-pel pass is computed for five
 // columns (HH[r][k], k = 0..4: the samples left of columns 0..3 and right of column 3) instead of 2 x 4, the vertical half-pel pass for
 // five rows of each column (rows above 0..3 and below 3) instead of 2 x 4, and every filtered value is rounded and clipped once, not once
-// per point that reads it: 396 second-pass FMAs instead of 816, 165 first-pass dot products instead of 264.  Same values as
-// me_frac_eval<0, ...> bit for bit: every intermediate is exact in fp32 (me_frac_eval's header), so the order of summation is free.
+// per point that reads it: 396 second-pass FMAs instead of 816, 165 first-pass dot products instead of 264.  Same values as nine
+// separate evaluations bit for bit: every intermediate is exact in fp32 (above), so the order of summation is free.
 template <int HAD, int BPS, int KIND8, int WP>
 __device__ __forceinline__ void me_frac_eval0(const uint32_t (&P)[12][3 * BPS], const float (&orgM)[16], int role, int bd, float clip_lo,
                                               bool want4, const FracWp wp, uint32_t (&out)[9], uint32_t (&out4)[9]) {
@@ -1497,11 +1390,7 @@ __device__ __forceinline__ void me_frac_compute(const FracRaw<BPS>& R, const uin
   }
   const bool want4 = KIND8 && __any(match4 != 0);
   if constexpr (STAGE == 0) {
-#ifndef ME_FRAC_STAGE0_PLAIN
     me_frac_eval0<HAD, BPS, KIND8, WP>(P, orgM, role, bd, clip_lo, want4, wp, dist, dist4);
-#else
-    me_frac_eval<0, HAD, BPS, KIND8, WP>(P, orgM, 0, 0, role, bd, clip_lo, tab_h, tab_v, want4, wp, dist, dist4);
-#endif
   } else {
     me_frac_eval1<HAD, BPS, KIND8, WP>(P, orgM, (int)((sv >> 18) & 3), (int)((sv >> 20) & 3), role, bd, clip_lo, tab_h, tab_v, want4, wp, dist, dist4);
   }
@@ -1660,8 +1549,13 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
 #endif
   }
   if (jb >= n_jobs || jb < 0) break;
-#ifdef ME_FRAC_T_TIMELINE   // timing-only build: when does each job start and end (100 MHz wall clock), and in which workgroup
+#ifdef ME_FRAC_T_TIMELINE   // timing-only build: when does each job start and end (100 MHz wall clock), in which workgroup, and its phases
   const unsigned long long t_job0 = wall_clock64();
+  unsigned long long t_ph[7];   // set-up | per stage: lists, items, winners
+  int n_ph = 0;
+#define ME_FRAC_STAMP() t_ph[n_ph++] = wall_clock64()
+#else
+#define ME_FRAC_STAMP()
 #endif
   MeJob job = jobs[jb];
   const uint8_t* __restrict__ ref_base = refs.base[job.ctu_x & 63];
@@ -1692,6 +1586,7 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
   }
   const uint8_t* src = ref_base + (long)(job.ctu_y + job.lt_y - 4) * ref_pitch + (job.ctu_x + job.lt_x - 4) * BPS;   // window sample (-4,-4)
   __syncthreads();
+  ME_FRAC_STAMP();
 
 #pragma unroll 1
   for (int stage = 0; stage < 2; ++stage) {
@@ -1709,12 +1604,14 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
       me_frac_dedupe4(st, cover, tid, keymask, &counter[1], list4);
     }
     __syncthreads();
+    ME_FRAC_STAMP();
     const int n8 = 4 * (int)counter[0], n4 = (int)counter[1];
 #ifndef ME_FRAC_T_NOITEMS
     if (stage == 0) me_frac_stage_items<0, HAD, BPS, WP>(src, ref_pitch, curl, st, cover, list8, n8, list4, n4, tid, bd, clip_lo, wp, tab_h, tab_v, acc);
     else me_frac_stage_items<1, HAD, BPS, WP>(src, ref_pitch, curl, st, cover, list8, n8, list4, n4, tid, bd, clip_lo, wp, tab_h, tab_v, acc);
 #endif
     __syncthreads();
+    ME_FRAC_STAMP();
     if (tid < 2) counter[tid] = 0;
     for (int s = tid; s < kParts; s += NT) {
       const uint32_t sv = st[s];
@@ -1748,12 +1645,14 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
       }
     }
     __syncthreads();   // slot states, cleared sums and list counters are in place before the quarter-pel stage lists its work / the next job starts
+    ME_FRAC_STAMP();
   }
 #ifdef ME_FRAC_T_TIMELINE
   if (tid == 0) {
     const unsigned long long t1 = wall_clock64();
     uint32_t* o = out_cost + (long)jb * kParts;
     o[0] = (uint32_t)t_job0; o[1] = (uint32_t)(t_job0 >> 32); o[2] = (uint32_t)t1; o[3] = (uint32_t)(t1 >> 32); o[4] = blockIdx.x;
+    for (int i = 0; i < 7; ++i) o[5 + i] = (uint32_t)(t_ph[i] - (i ? t_ph[i - 1] : t_job0));   // phase durations, 10 ns units
   }
   __syncthreads();
 #endif

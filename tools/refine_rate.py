@@ -54,7 +54,8 @@ if os.environ.get("HMME_TIMELINE"):   # a library built with -DME_FRAC_T_TIMELIN
                        "jobs_per_workgroup_min_max": [int(per_wg[per_wg > 0].min()), int(per_wg.max())], "workgroups": int((per_wg > 0).sum()),
                        "last_start_us": round(float(s_us.max()), 1), "longest_jobs": [int(v) for v in np.argsort(-dur)[:12]],
                        "mean_us_bottom_ctu_row": round(float(dur[-((w + 63) // 64):].mean()), 1),
-                       "busy_share": round(float(dur.sum() / (e_us.max() * (per_wg > 0).sum())), 3)}
+                       "busy_share": round(float(dur.sum() / (e_us.max() * (per_wg > 0).sum())), 3),
+                       "phase_us_mean": dict(zip(("setup", "lists0", "items0", "winners0", "lists1", "items1", "winners1"), (round(float(c[:, 5 + i].mean()) / 100.0, 2) for i in range(7))))}
 frac = (d_q.to(torch.int32) - 4 * d_mv.to(torch.int32)).abs().amax().item()
 import zlib
 crc = zlib.crc32(d_c.cpu().numpy().tobytes(), zlib.crc32(d_q.cpu().numpy().tobytes()))   # of the last launch's tables (SAD distortion)
