@@ -1031,6 +1031,62 @@ __device__ __forceinline__ uint32_t me_frac_dist(const float (&d)[16], float s1,
   return contrib;
 }
 
+#ifndef ME_FRAC_SCALAR_STAGE1   // A/B: the quarter-pel stage one sample per instruction
+// The Hadamard sum of a 4x4 difference block that arrives as pairs of horizontal neighbours (P[r][h]: row r, columns 2h, 2h + 1), two
+// butterflies per instruction (v_pk_add_f32).  Only the sum of the absolute coefficients is wanted, so the transform runs in natural
+// (Sylvester) order -- the same sixteen Walsh functions as xCalcHADs4x4's, in another order and with other signs: three levels pair
+// different registers element by element, the one level that pairs the two halves of a register comes last, in scalar code (measured
+// against the same level first: 2 % slower; and against this function in the half-pel stage, whose differences are born as single
+// registers: 4 % slower, profiles/r04s_frac_instruction_mix_ab.txt).  The 8x8 combination across the quad works on corresponding
+// coefficients of the four quadrants, which every lane orders alike.
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <int KIND8>
+__device__ __forceinline__ uint32_t me_frac_had_pk(const v2f (&P)[4][2], float s1, float s2, bool want4, uint32_t& own4) {
+  v2f A[4][2], B[4][2], C[4][2];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { A[r][0] = P[r][0] + P[r][1]; A[r][1] = P[r][0] - P[r][1]; }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    B[0][h] = A[0][h] + A[1][h]; B[1][h] = A[0][h] - A[1][h]; B[2][h] = A[2][h] + A[3][h]; B[3][h] = A[2][h] - A[3][h];
+    C[0][h] = B[0][h] + B[2][h]; C[2][h] = B[0][h] - B[2][h]; C[1][h] = B[1][h] + B[3][h]; C[3][h] = B[1][h] - B[3][h];
+  }
+  float z[16];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { z[4 * r + 2 * h] = C[r][h].x + C[r][h].y; z[4 * r + 2 * h + 1] = C[r][h].x - C[r][h].y; }
+  float sum = 0.f;
+  if (KIND8) {
+    if (want4) {
+      float s4 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s4 += __builtin_fabsf(z[i]);
+      own4 = ((uint32_t)s4 + 1) >> 1;
+    }
+    asm("s_nop 1\n\t"
+        ME_FRAC_BFLY(%0, %16, "[1,0,3,2]") ME_FRAC_BFLY(%1, %16, "[1,0,3,2]") ME_FRAC_BFLY(%2, %16, "[1,0,3,2]") ME_FRAC_BFLY(%3, %16, "[1,0,3,2]")
+        ME_FRAC_BFLY(%4, %16, "[1,0,3,2]") ME_FRAC_BFLY(%5, %16, "[1,0,3,2]") ME_FRAC_BFLY(%6, %16, "[1,0,3,2]") ME_FRAC_BFLY(%7, %16, "[1,0,3,2]")
+        ME_FRAC_BFLY(%8, %16, "[1,0,3,2]") ME_FRAC_BFLY(%9, %16, "[1,0,3,2]") ME_FRAC_BFLY(%10, %16, "[1,0,3,2]") ME_FRAC_BFLY(%11, %16, "[1,0,3,2]")
+        ME_FRAC_BFLY(%12, %16, "[1,0,3,2]") ME_FRAC_BFLY(%13, %16, "[1,0,3,2]") ME_FRAC_BFLY(%14, %16, "[1,0,3,2]") ME_FRAC_BFLY(%15, %16, "[1,0,3,2]")
+        ME_FRAC_BFLY(%0, %17, "[2,3,0,1]") ME_FRAC_BFLY(%1, %17, "[2,3,0,1]") ME_FRAC_BFLY(%2, %17, "[2,3,0,1]") ME_FRAC_BFLY(%3, %17, "[2,3,0,1]")
+        ME_FRAC_BFLY(%4, %17, "[2,3,0,1]") ME_FRAC_BFLY(%5, %17, "[2,3,0,1]") ME_FRAC_BFLY(%6, %17, "[2,3,0,1]") ME_FRAC_BFLY(%7, %17, "[2,3,0,1]")
+        ME_FRAC_BFLY(%8, %17, "[2,3,0,1]") ME_FRAC_BFLY(%9, %17, "[2,3,0,1]") ME_FRAC_BFLY(%10, %17, "[2,3,0,1]") ME_FRAC_BFLY(%11, %17, "[2,3,0,1]")
+        ME_FRAC_BFLY(%12, %17, "[2,3,0,1]") ME_FRAC_BFLY(%13, %17, "[2,3,0,1]") ME_FRAC_BFLY(%14, %17, "[2,3,0,1]") ME_FRAC_BFLY(%15, %17, "[2,3,0,1]")
+        : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(z[4]), "+v"(z[5]), "+v"(z[6]), "+v"(z[7]), "+v"(z[8]), "+v"(z[9]),
+          "+v"(z[10]), "+v"(z[11]), "+v"(z[12]), "+v"(z[13]), "+v"(z[14]), "+v"(z[15])
+        : "v"(s1), "v"(s2));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sum += __builtin_fabsf(z[i]);
+    sum += me_dpp_f(sum, 1);
+    sum += me_dpp_f(sum, 0);
+    return ((uint32_t)sum + 2) >> 2;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) sum += __builtin_fabsf(z[i]);
+  return ((uint32_t)sum + 1) >> 1;
+}
+#endif
+
 // The evaluation of one work item.  Stage 0 (me_frac_eval0): the nine half-pel points around the integer MV; stage 1 (me_frac_eval1):
 // the eight quarter-pel points around the slot's half-pel winner.  P: patch rows of 3 * BPS dwords, 8-bit samples XORed with 0x80
 // (signed bytes p - 128: the 128 * 64 this removes IS the -8192 offset of the first pass).  orgM: current samples + kRoundMagic.
@@ -1134,6 +1190,26 @@ __device__ __forceinline__ void me_frac_eval1(const uint32_t (&P)[kFracRows1][3 
 #pragma unroll
       for (int j = 0; j < 8; ++j) cv[j] = tab_v[(h3y * 3 + dyi) * kFracTabV + j];
       float d[16];
+#ifndef ME_FRAC_SCALAR_STAGE1   // A/B: the quarter-pel stage one sample per instruction
+      v2f dp[4][2];
+      if constexpr (!WP) {   // two columns per instruction: v_pk_fma_f32 / v_pk_add_f32
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int cp = 0; cp < 2; ++cp) {
+            v2f a = {524288.5f * sc2, 524288.5f * sc2};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const v2f t = {tmp[r + j][2 * cp], tmp[r + j][2 * cp + 1]}, cc = {cv[j], cv[j]};
+              a = __builtin_elementwise_fma(cc, t, a);
+            }
+            const v2f y = v2f{__builtin_amdgcn_fmed3f(a.x, clip_lo, maxv), __builtin_amdgcn_fmed3f(a.y, clip_lo, maxv)} + v2f{kRoundMagic, kRoundMagic};
+            const v2f dd = v2f{orgM[4 * r + 2 * cp], orgM[4 * r + 2 * cp + 1]} - y;
+            d[4 * r + 2 * cp] = dd.x; d[4 * r + 2 * cp + 1] = dd.y;
+            dp[r][cp] = dd;
+          }
+      } else
+#endif
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -1145,7 +1221,11 @@ __device__ __forceinline__ void me_frac_eval1(const uint32_t (&P)[kFracRows1][3 
           d[4 * r + c] = orgM[4 * r + c] - (WP ? __builtin_floorf(__builtin_fmaf(wp.ws, y - kRoundMagic, wp.rs)) : y);
         }
       uint32_t own4 = 0;
+#ifndef ME_FRAC_SCALAR_STAGE1
+      const uint32_t contrib = (HAD && !WP) ? me_frac_had_pk<KIND8>(dp, s1, s2, want4, own4) : me_frac_dist<HAD, KIND8>(d, s1, s2, want4, own4);
+#else
       const uint32_t contrib = me_frac_dist<HAD, KIND8>(d, s1, s2, want4, own4);
+#endif
       out[idxQ[dyi][dxi]] = contrib;
       out4[idxQ[dyi][dxi]] = own4;
     }
