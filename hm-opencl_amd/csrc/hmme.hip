@@ -604,10 +604,17 @@ int hmme_slot_rect(int slot, int* x, int* y, int* w, int* h) {
 namespace {
 int build_frac_cover(hmme_ctx* ctx);
 using frac_fn = void (*)(const RefSet, int, const RefSet, int, const MeJob*, int, uint32_t*, const uint16_t*, const int16_t*, uint32_t, int, const hmme::FracWp, int16_t*, uint32_t*);
-inline frac_fn frac_kernel(int wide, int had, int wp = 0) {
-  static const frac_fn fns[2][2] = {{hmme::me_frac_kernel<0, 1, 0>, hmme::me_frac_kernel<1, 1, 0>}, {hmme::me_frac_kernel<0, 2, 0>, hmme::me_frac_kernel<1, 2, 0>}};
+// few: the launch is at most two rounds of two workgroups per CU (jobs <= 4 x CUs: a per-CTU call, picture pairs up to 2560x1440) --
+// the 8-bit kernel then runs in its two-wave build, which keeps everything in registers; launches with more jobs take the three-wave
+// build, whose jobs take 1.27 x as long but come three to a CU (me_frac_kernel's header; profiles/r04w2_frac_waves_by_launch_size.txt)
+inline frac_fn frac_kernel(int wide, int had, int wp = 0, bool few = false) {
+  static const frac_fn fns[2][2] = {{hmme::me_frac_kernel<0, 1, 0, 3>, hmme::me_frac_kernel<1, 1, 0, 3>}, {hmme::me_frac_kernel<0, 2, 0>, hmme::me_frac_kernel<1, 2, 0>}};
+  static const frac_fn fns_few8[2] = {hmme::me_frac_kernel<0, 1, 0, 2>, hmme::me_frac_kernel<1, 1, 0, 2>};
   static const frac_fn fns_wp[2] = {hmme::me_frac_kernel<0, 2, 1>, hmme::me_frac_kernel<1, 2, 1>};   // weighted calls always stage u16 samples
-  return wp ? fns_wp[had ? 1 : 0] : fns[wide ? 1 : 0][had ? 1 : 0];
+  if (wp) return fns_wp[had ? 1 : 0];
+  static const int force = std::getenv("HMME_FRAC_WAVES") ? std::atoi(std::getenv("HMME_FRAC_WAVES")) : 0;   // A/B: 2 or 3 whatever the job count
+  if (!wide && (force == 2 || (force != 3 && few))) return fns_few8[had ? 1 : 0];
+  return fns[wide ? 1 : 0][had ? 1 : 0];
 }
 const hmme::FracWp kNoWp = {0.f, 0.f, 0.f};
 // workgroups of a refinement launch: one per job, dealt from the end of the job table (me_frac_kernel).  HMME_FRAC_GRID=<n> launches n
@@ -823,7 +830,7 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
     const int16_t* d_imv = do_search ? d_mv1 : (const int16_t*)(ctx->d_call + kCallImv);
     // weighted: the interpolated prediction is weighted sample by sample (me_frac_eval, FracWp); the current samples carry `bias`, the raw window none
     const hmme::FracWp fw = wp ? hmme::FracWp{std::ldexp((float)wp->w0, -wp->shift), std::ldexp((float)wp->round, -wp->shift), (float)(bias + wp->offset)} : kNoWp;
-    hipLaunchKernelGGL(frac_kernel(wide ? 1 : 0, refine_had ? 1 : 0, wp ? 1 : 0), dim3(1), dim3(hmme::frac_threads(bps)), hmme::frac_lds_bytes(bps), s, one_ref(ctx->d_call + kCallCtu),
+    hipLaunchKernelGGL(frac_kernel(wide ? 1 : 0, refine_had ? 1 : 0, wp ? 1 : 0, true), dim3(1), dim3(hmme::frac_threads(bps)), hmme::frac_lds_bytes(bps), s, one_ref(ctx->d_call + kCallCtu),
                        64 * bps, one_ref(ref_base), kWinPitch, (const MeJob*)(ctx->d_call + kCallFracJob), 1, (uint32_t*)nullptr, ctx->d_frac_cover, d_imv, ctx->lambda_q16,
                        p->bit_depth | ((bipred_origin && !wp) ? 0x100 : 0), fw, (int16_t*)(ctx->d_res + kResQmv), (uint32_t*)(ctx->d_res + kResCost));
     HIP_TRY(ctx, hipGetLastError());
@@ -1273,7 +1280,7 @@ int hmme_refine_pairs_device(hmme_ctx* ctx, const hmme_plane* const* curs, const
                        pl.first, pl.count, n_pairs, curs[0]->width, curs[0]->height, fp->search_range, 0, jobs, 0, counter);
     const int had = use_hadamard ? 1 : 0, wide = curs[0]->bps == 2 ? 1 : 0;
     const int grid = frac_grid(ctx, wide, had, jobs);
-    hipLaunchKernelGGL(frac_kernel(wide, had), dim3(grid), dim3(hmme::frac_threads(wide ? 2 : 1)), hmme::frac_lds_bytes(wide ? 2 : 1), s, pl.curs,
+    hipLaunchKernelGGL(frac_kernel(wide, had, 0, jobs <= 4 * ctx->num_cus), dim3(grid), dim3(hmme::frac_threads(wide ? 2 : 1)), hmme::frac_lds_bytes(wide ? 2 : 1), s, pl.curs,
                        curs[0]->pitch, pl.refs, refs[0]->pitch, (const MeJob*)ctx->d_jobs, jobs, grid < jobs ? counter : (uint32_t*)nullptr, ctx->d_frac_cover,
                        (const int16_t*)d_int_mv, ctx->lambda_q16,
                        fp->bit_depth, kNoWp, (int16_t*)d_out_qmv, (uint32_t*)d_out_cost);

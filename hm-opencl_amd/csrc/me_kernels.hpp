@@ -897,7 +897,10 @@ constexpr int kFracAccRow = 9, kFracAcc = 593 * kFracAccRow, kFracAccDw = (kFrac
 // BPS = bytes per sample of the planes (1: 8-bit video, 2: 9..12 bit)
 constexpr int frac_threads(int bps) { return 256; }
 // sums [593][9] | slot states | tap tables, counters | the two work lists | current block | cover table (uint16 [64][18] + [256][6])
-constexpr size_t frac_lds_bytes(int bps) { return (size_t)(kFracAccDw + 600 + 160 + (64 * 18 + 256 * 6) / 2 + 1024 * bps + (64 * 18 + 256 * 6) / 2) * 4; }
+#ifndef ME_FRAC_T_LDS_PAD   // timing-only: LDS bytes a workgroup asks for beyond its need (56 KiB in all = two workgroups per CU with the three-wave register budget)
+#define ME_FRAC_T_LDS_PAD 0
+#endif
+constexpr size_t frac_lds_bytes(int bps) { return (size_t)(kFracAccDw + 600 + 160 + (64 * 18 + 256 * 6) / 2 + 1024 * bps + (64 * 18 + 256 * 6) / 2) * 4 + ME_FRAC_T_LDS_PAD; }
 
 __device__ __forceinline__ uint32_t me_mv_cost_q(uint32_t lambda_q16, int vx_q, int vy_q, int pred_x, int pred_y) {
   return (lambda_q16 * (me_component_bits(vx_q - pred_x) + me_component_bits(vy_q - pred_y))) >> 16;
@@ -927,11 +930,6 @@ __host__ __device__ constexpr uint32_t me_htap_dw(int q, int c, int k) {
   }
   return w;
 }
-// waves per SIMD of the 8-bit refinement kernel: it needs 194 VGPRs; capped at 168 (three waves) it spills 19 dwords per lane but the
-// third wave hides more latency than the spills cost (measured); the u16 kernel would spill 200 and stays at two
-#ifndef ME_FRAC_WAVES8
-#define ME_FRAC_WAVES8 3
-#endif
 // Quarter-pel stage: the three offsets of a component around its half-pel winner h (-1, 0, +1 half samples) all fit ONE 8-sample
 // window: h = -1 -> q = -3..-1, integer part -1: samples -4..+3; h = 0 -> q = -1..1: samples -3..+4 (q = -1 is fraction 3 at integer
 // part -1, whose first tap is 0, so its seven live taps start at sample -3 as well); h = +1 -> q = 1..3: samples -3..+4.  The lane
@@ -1573,8 +1571,13 @@ __device__ __forceinline__ void me_frac_dedupe4(const uint32_t* st, const uint16
     if (first[j]) list[atomicAdd(counter, 1u)] = (uint16_t)(kFracPairs8 + p4 * kFracCover4 + j);
 }
 
-template <int HAD, int BPS, int WP>
-__global__ void __launch_bounds__(frac_threads(BPS), BPS == 1 ? ME_FRAC_WAVES8 : 2)
+// WAVES: waves per SIMD the register budget is cut for.  The 8-bit kernel wants 230 VGPRs.  At two waves (no scratch) a job takes
+// 1 / 1.27 of its time at three (168 VGPRs + 46 spilled dwords per lane, three workgroups sharing a CU), at three waves a CU holds
+// half as many jobs again: two waves win while the launch is a round or two of 2 x CUs workgroups (a per-CTU call, a 1080p or 1440p
+// picture pair: -9 %, -10 %), three waves from there on (2160p: 2 040 jobs = 4 rounds against 3: +5 %).  The host picks (hmme.hip
+// frac_kernel); the u16 kernel fits two waves without scratch.
+template <int HAD, int BPS, int WP, int WAVES = 2>
+__global__ void __launch_bounds__(frac_threads(BPS), WAVES)
 me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitch,
                const MeJob* __restrict__ jobs, int n_jobs, uint32_t* __restrict__ job_counter, const uint16_t* __restrict__ cover_g,
                const int16_t* __restrict__ int_mv, uint32_t lambda_q16, int bit_depth_bias, const FracWp wp, int16_t* __restrict__ out_qmv,

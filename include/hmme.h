@@ -271,6 +271,8 @@ int hmme_refine_pairs_device(hmme_ctx* ctx, const hmme_plane* const* curs, const
  *                         workgroups of the refinement kernel per CU); the TEncOpenCL host module prints its call summary in its destructor
  *   HMME_FRAC_GRID=<n>    workgroups of a refinement launch: default (0) = one per job; n > 0 = exactly n, each taking job after
  *                         job from a counter; -1 = as many of those as the chip holds at a time
+ *   HMME_FRAC_WAVES=<2|3> 8-bit refinement kernel: its two-wave (no scratch) or three-wave build whatever the launch's job count
+ *                         (default: two waves when jobs <= 4 x CUs, else three)
  *   HMME_TAIL_PARTS=<n>   pieces per job of a launch's last, partial round of workgroups: default = the planner's choice
  *                         (DESIGN.md 5 "rounds of workgroups"); 1 = no tail plan
  *   HMME_STRIPS16=<n>     16-bit search kernel: that many equal window strips per job instead of the planner's number

@@ -1129,6 +1129,13 @@ def test_refinement_launch_modes_give_the_same_tables():
     for bd in ("8", "10"):
         assert crcs[("0", bd)] == crcs[("7", bd)] == crcs[("-1", bd)], crcs
     assert crcs[("0", "8")] != crcs[("0", "10")]
+    # the 8-bit kernel's two register budgets (two waves per SIMD without scratch: launches whose jobs are all resident at once, as this
+    # one's 104 are; three waves: the others) -- forced either way
+    for waves in ("2", "3"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "refine_rate.py"), "832x480", "8", "mixed"], capture_output=True, text=True,
+                           timeout=600, env=dict(os.environ, HMME_FRAC_WAVES=waves))
+        assert r.returncode == 0, r.stderr[-1500:]
+        assert json.loads(r.stdout.strip().splitlines()[-1])["tables_crc32"] == crcs[("0", "8")], waves
 
 
 def test_sequence_driver_reads_a_yuv_file(tmp_path):
