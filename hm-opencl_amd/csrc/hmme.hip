@@ -603,20 +603,23 @@ int hmme_slot_rect(int slot, int* x, int* y, int* w, int* h) {
 // ---- per-CTU drop-in ---------------------------------------------------------------------------------
 namespace {
 int build_frac_cover(hmme_ctx* ctx);
-using frac_fn = void (*)(const RefSet, int, const RefSet, int, const MeJob*, int, uint32_t*, const uint16_t*, const int16_t*, uint32_t, int, const hmme::FracWp, int16_t*, uint32_t*);
+using frac_fn = void (*)(const RefSet, int, const RefSet, int, const MeJob*, const hmme::FracPrep, int, uint32_t*, const uint16_t*, const int16_t*, uint32_t, int, const hmme::FracWp, int16_t*, uint32_t*);
 // few: the launch is at most two rounds of two workgroups per CU (jobs <= 4 x CUs: a per-CTU call, picture pairs up to 2560x1440) --
 // the 8-bit kernel then runs in its two-wave build, which keeps everything in registers; launches with more jobs take the three-wave
 // build, whose jobs take 1.27 x as long but come three to a CU (me_frac_kernel's header; profiles/r04w2_frac_waves_by_launch_size.txt)
+inline bool frac_three_waves(int wide, int wp, bool few) {
+  static const int force = std::getenv("HMME_FRAC_WAVES") ? std::atoi(std::getenv("HMME_FRAC_WAVES")) : 0;   // A/B: 2 or 3 whatever the job count
+  return !wide && !wp && force != 2 && (force == 3 || !few);
+}
 inline frac_fn frac_kernel(int wide, int had, int wp = 0, bool few = false) {
-  static const frac_fn fns[2][2] = {{hmme::me_frac_kernel<0, 1, 0, 3>, hmme::me_frac_kernel<1, 1, 0, 3>}, {hmme::me_frac_kernel<0, 2, 0>, hmme::me_frac_kernel<1, 2, 0>}};
-  static const frac_fn fns_few8[2] = {hmme::me_frac_kernel<0, 1, 0, 2>, hmme::me_frac_kernel<1, 1, 0, 2>};
+  static const frac_fn fns[2][2] = {{hmme::me_frac_kernel<0, 1, 0, 2>, hmme::me_frac_kernel<1, 1, 0, 2>}, {hmme::me_frac_kernel<0, 2, 0>, hmme::me_frac_kernel<1, 2, 0>}};
+  static const frac_fn fns_many8[2] = {hmme::me_frac_kernel<0, 1, 0, 3>, hmme::me_frac_kernel<1, 1, 0, 3>};
   static const frac_fn fns_wp[2] = {hmme::me_frac_kernel<0, 2, 1>, hmme::me_frac_kernel<1, 2, 1>};   // weighted calls always stage u16 samples
   if (wp) return fns_wp[had ? 1 : 0];
-  static const int force = std::getenv("HMME_FRAC_WAVES") ? std::atoi(std::getenv("HMME_FRAC_WAVES")) : 0;   // A/B: 2 or 3 whatever the job count
-  if (!wide && (force == 2 || (force != 3 && few))) return fns_few8[had ? 1 : 0];
-  return fns[wide ? 1 : 0][had ? 1 : 0];
+  return frac_three_waves(wide, wp, few) ? fns_many8[had ? 1 : 0] : fns[wide ? 1 : 0][had ? 1 : 0];
 }
 const hmme::FracWp kNoWp = {0.f, 0.f, 0.f};
+const hmme::FracPrep kNoPrep = {nullptr, 1u << 16, 0, 0};
 // workgroups of a refinement launch: one per job, dealt from the end of the job table (me_frac_kernel).  HMME_FRAC_GRID=<n> launches n
 // workgroups that take job after job from a counter instead, HMME_FRAC_GRID=-1 as many of those as the chip holds at a time (the
 // runtime's occupancy figure for this kernel with its LDS block x the CUs): round 4's intermediate launch, kept for A/B runs -- once
@@ -831,7 +834,7 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
     // weighted: the interpolated prediction is weighted sample by sample (me_frac_eval, FracWp); the current samples carry `bias`, the raw window none
     const hmme::FracWp fw = wp ? hmme::FracWp{std::ldexp((float)wp->w0, -wp->shift), std::ldexp((float)wp->round, -wp->shift), (float)(bias + wp->offset)} : kNoWp;
     hipLaunchKernelGGL(frac_kernel(wide ? 1 : 0, refine_had ? 1 : 0, wp ? 1 : 0, true), dim3(1), dim3(hmme::frac_threads(bps)), hmme::frac_lds_bytes(bps), s, one_ref(ctx->d_call + kCallCtu),
-                       64 * bps, one_ref(ref_base), kWinPitch, (const MeJob*)(ctx->d_call + kCallFracJob), 1, (uint32_t*)nullptr, ctx->d_frac_cover, d_imv, ctx->lambda_q16,
+                       64 * bps, one_ref(ref_base), kWinPitch, (const MeJob*)(ctx->d_call + kCallFracJob), kNoPrep, 1, (uint32_t*)nullptr, ctx->d_frac_cover, d_imv, ctx->lambda_q16,
                        p->bit_depth | ((bipred_origin && !wp) ? 0x100 : 0), fw, (int16_t*)(ctx->d_res + kResQmv), (uint32_t*)(ctx->d_res + kResCost));
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(hmme::me_publish_kernel, dim3(1), dim3(1), 0, s, (volatile uint32_t*)(ctx->d_res + kResDone2), seq);
@@ -1276,12 +1279,21 @@ int hmme_refine_pairs_device(hmme_ctx* ctx, const hmme_plane* const* curs, const
   }
   if (rc == HMME_OK) {
     uint32_t* counter = (uint32_t*)((uint8_t*)ctx->d_jobs + ((sizeof(MeJob) * (size_t)jobs + 15) & ~(size_t)15));
-    hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, dim3((jobs + 255) / 256), dim3(256), 0, s, (MeJob*)ctx->d_jobs, (const int16_t*)d_pred_q,
-                       pl.first, pl.count, n_pairs, curs[0]->width, curs[0]->height, fp->search_range, 0, jobs, 0, counter);
     const int had = use_hadamard ? 1 : 0, wide = curs[0]->bps == 2 ? 1 : 0;
     const int grid = frac_grid(ctx, wide, had, jobs);
-    hipLaunchKernelGGL(frac_kernel(wide, had, 0, jobs <= 4 * ctx->num_cus), dim3(grid), dim3(hmme::frac_threads(wide ? 2 : 1)), hmme::frac_lds_bytes(wide ? 2 : 1), s, pl.curs,
-                       curs[0]->pitch, pl.refs, refs[0]->pitch, (const MeJob*)ctx->d_jobs, jobs, grid < jobs ? counter : (uint32_t*)nullptr, ctx->d_frac_cover,
+    // one workgroup per job (the default) on the two-wave builds: every workgroup derives its job itself (FracPrep) -- no job table, no
+    // launch in front of this one (1080p: 0.095 -> 0.090 ms).  The three-wave build reads a table (me_frac_kernel), and so does the
+    // job-walking launch of HMME_FRAC_GRID: its prep kernel is also what resets the job counter
+    if (pl.count > 0xffff || pl.first > 0xffff) return pairs_end(ctx, curs, refs, n_pairs, s, fail(ctx, HMME_ERR_UNSUPPORTED, "refinement launch: more than 65 535 CTUs per picture"));
+    const hmme::FracPrep prep = {(const int16_t*)d_pred_q, (uint32_t)pl.first | (uint32_t)pl.count << 16, (uint32_t)curs[0]->width | (uint32_t)curs[0]->height << 16, fp->search_range};
+    static const bool table = std::getenv("HMME_FRAC_JOB_TABLE") != nullptr;   // A/B: the job table and its kernel as before
+    const bool walk = grid < jobs, few = jobs <= 4 * ctx->num_cus;
+    const bool need_table = walk || table || frac_three_waves(wide, 0, few);
+    if (need_table)
+      hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, dim3((jobs + 255) / 256), dim3(256), 0, s, (MeJob*)ctx->d_jobs, (const int16_t*)d_pred_q,
+                         pl.first, pl.count, n_pairs, curs[0]->width, curs[0]->height, fp->search_range, 0, jobs, 0, counter);
+    hipLaunchKernelGGL(frac_kernel(wide, had, 0, few), dim3(grid), dim3(hmme::frac_threads(wide ? 2 : 1)), hmme::frac_lds_bytes(wide ? 2 : 1), s, pl.curs,
+                       curs[0]->pitch, pl.refs, refs[0]->pitch, need_table ? (const MeJob*)ctx->d_jobs : (const MeJob*)nullptr, prep, jobs, walk ? counter : (uint32_t*)nullptr, ctx->d_frac_cover,
                        (const int16_t*)d_int_mv, ctx->lambda_q16,
                        fp->bit_depth, kNoWp, (int16_t*)d_out_qmv, (uint32_t*)d_out_cost);
     const hipError_t e = hipGetLastError();

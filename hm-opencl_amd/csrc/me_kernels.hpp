@@ -1104,6 +1104,9 @@ __device__ __forceinline__ uint32_t me_frac_had_pk(const v2f (&P)[4][2], float s
 // ws = w0 * 2^-shift, rs = round * 2^-shift: fma(ws, p, rs) IS (w0 * p + round) / 2^shift exactly (|w0 * p + round| < 2^24), v_floor_f32
 // the shift; org_sub = what to take off a staged current sample: its staging bias + offset.  WP = 0: none of this is compiled in.
 struct FracWp { float ws, rs, org_sub; };
+// a whole-picture launch derives each job's window itself (what me_prep_jobs_kernel writes into a job table: pair, CTU, predictor,
+// xSetSearchRange + clipMv) -- one kernel launch less per refinement; the per-CTU call hands over the job the host prepared
+struct FracPrep { const int16_t* pred_q; uint32_t ctus, dims; int sr; };   // ctus: ctu_first | ctu_count << 16; dims: width | height << 16 (few scalar registers: they stay live across the kernel)
 constexpr float kRoundMagic = 12582912.0f;   // 1.5 * 2^23: x + magic rounds x to the nearest integer (ties to even)
 // First pass on 8-bit planes without v_cvt_f32_i32: the dot-product chain of a filtered sample starts from the BIT PATTERN of
 // kRoundMagic (0x4B400000; ulp 1, so adding an integer k, |k| < 2^22, to the pattern gives the pattern of kRoundMagic + k -- here
@@ -1579,7 +1582,7 @@ __device__ __forceinline__ void me_frac_dedupe4(const uint32_t* st, const uint16
 template <int HAD, int BPS, int WP, int WAVES = 2>
 __global__ void __launch_bounds__(frac_threads(BPS), WAVES)
 me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitch,
-               const MeJob* __restrict__ jobs, int n_jobs, uint32_t* __restrict__ job_counter, const uint16_t* __restrict__ cover_g,
+               const MeJob* __restrict__ jobs, const FracPrep prep, int n_jobs, uint32_t* __restrict__ job_counter, const uint16_t* __restrict__ cover_g,
                const int16_t* __restrict__ int_mv, uint32_t lambda_q16, int bit_depth_bias, const FracWp wp, int16_t* __restrict__ out_qmv,
                uint32_t* __restrict__ out_cost) {
   // bit_depth_bias: bit depth in the low 8 bits; bit 8 set = block and window carry the bias 2^bitDepth of a bi-prediction origin
@@ -1640,7 +1643,25 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
 #else
 #define ME_FRAC_STAMP()
 #endif
-  MeJob job = jobs[jb];
+  MeJob job;
+  // (the three-wave build always reads a table: the few registers the derivation holds across the kernel cost it 48 B more scratch per
+  // lane and 3 % of its time -- more than the launch it saves, hmme.hip hmme_refine_pairs_device)
+  if (WAVES == 3 || jobs) {
+    job = jobs[jb];
+  } else {   // job jb = pair jb / ctu_count, CTU ctu_first + jb % ctu_count
+    const int ctu_first = (int)(prep.ctus & 0xffff), ctu_count = (int)(prep.ctus >> 16), pic_w = (int)(prep.dims & 0xffff), pic_h = (int)(prep.dims >> 16);
+    const int r = jb / ctu_count;
+    const int ctus_x = (pic_w + 63) >> 6, n_ctu = ctus_x * ((pic_h + 63) >> 6);
+    const int ctu = ctu_first + (jb - r * ctu_count);
+    const int cu_x = (ctu % ctus_x) * 64, cu_y = (ctu / ctus_x) * 64;
+    const long pq = 2 * ((long)r * n_ctu + ctu);
+    const int px = prep.pred_q ? prep.pred_q[pq] : 0, py = prep.pred_q ? prep.pred_q[pq + 1] : 0;
+    int ltx, lty, rbx, rby;
+    set_search_range(px, py, prep.sr, cu_x, cu_y, pic_w, pic_h, ltx, lty, rbx, rby);
+    job.ctu_x = (int16_t)(cu_x | r); job.ctu_y = (int16_t)cu_y;
+    job.lt_x = (int16_t)ltx; job.lt_y = (int16_t)lty; job.rb_x = (int16_t)rbx; job.rb_y = (int16_t)rby;
+    job.pred_x = (int16_t)px; job.pred_y = (int16_t)py;
+  }
   const uint8_t* __restrict__ ref_base = refs.base[job.ctu_x & 63];
   const uint8_t* __restrict__ cur_base = curs.base[job.ctu_x & 63];
   job.ctu_x &= ~63;

@@ -273,6 +273,8 @@ int hmme_refine_pairs_device(hmme_ctx* ctx, const hmme_plane* const* curs, const
  *                         job from a counter; -1 = as many of those as the chip holds at a time
  *   HMME_FRAC_WAVES=<2|3> 8-bit refinement kernel: its two-wave (no scratch) or three-wave build whatever the launch's job count
  *                         (default: two waves when jobs <= 4 x CUs, else three)
+ *   HMME_FRAC_JOB_TABLE=1 whole-picture refinement launches: job table written by a kernel in front of the launch (as before round 4's
+ *                         end) instead of every workgroup deriving its job itself
  *   HMME_TAIL_PARTS=<n>   pieces per job of a launch's last, partial round of workgroups: default = the planner's choice
  *                         (DESIGN.md 5 "rounds of workgroups"); 1 = no tail plan
  *   HMME_STRIPS16=<n>     16-bit search kernel: that many equal window strips per job instead of the planner's number
