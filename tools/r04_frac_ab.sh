@@ -5,7 +5,7 @@ TAG=${1:-r04b}; shift; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 V=$PWD/hm-opencl_amd/csrc/build/variants
 one() {   # lib-variant grid size bit-depth content
   local L=""; [ $1 = default ] || L="HMME_LIB=$V/libhmme_$1.so"
-  local G=""; [ $2 = auto ] || G="HMME_FRAC_GRID=$2"
+  local G=""; [ $2 = auto ] && G="HMME_FRAC_GRID=-1" || G="HMME_FRAC_GRID=$2"   # auto = as many job-walking workgroups as the chip holds (the default when this was written; now -1)
   echo -n "$1 grid=$2 $3 $4-bit $5: "
   env $L $G HMME_TRACE=1 python tools/refine_rate.py $3 $4 $5 2> $OUT/err.txt | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['refine_ms'])"
   grep -h "workgroups per CU" $OUT/err.txt | sort -u | tr '\n' ' '; echo

@@ -3,7 +3,7 @@
 #   bash tools/r04_frac_grid_u16.sh <tag>
 TAG=${1:-r04g}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 one() {   # grid size bit-depth content
-  local G=""; [ $1 = auto ] || G="HMME_FRAC_GRID=$1"
+  local G=""; [ $1 = auto ] && G="HMME_FRAC_GRID=-1" || G="HMME_FRAC_GRID=$1"   # auto = as many job-walking workgroups as the chip holds (the default when this was written; now -1)
   echo -n "grid=$1 $2 $3-bit $4: "
   env $G python tools/refine_rate.py $2 $3 $4 2> $OUT/err.txt | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['refine_ms'])"
 }
