@@ -1337,20 +1337,28 @@ __device__ __forceinline__ void me_frac_eval0(const uint32_t (&P)[12][3 * BPS], 
   }
   // ---- integer columns
 #ifndef ME_FRAC_CVT_FIRST_PASS
-  if constexpr (BPS == 1) {
-    // the first pass of an integer column is 64 * p - 8192: the sample itself goes into the vertical filter (v_cvt_f32_ubyteN of the
-    // raw byte), the taps carry the 64 and the constant the -8192 -- the same real number, exact in fp32 like the general form.  The
-    // integer-position sample needs neither filter nor clip (8-bit planes carry no bi-prediction bias: clip_lo = 0)
+  if constexpr (!WP) {
+    // the first pass of an integer column is (64 * p - (8192 << sh1)) >> sh1 = p * 2^(6 - sh1) - 8192: the sample itself goes into the
+    // vertical filter (v_cvt_f32_ubyteN of the raw byte / a conversion of the 16-bit half), the taps carry the 2^(6 - sh1) and the
+    // constant the -8192 -- the same real number, exact in fp32 like the general form.  The integer-position sample needs neither
+    // filter nor clip: it is a sample of the window (with the window's bias, if any), inside [clip_lo, maxv] as it stands.  Weighted
+    // calls take the general form below: their integer-position prediction is weighted like the others
     float V0[12][4];
 #pragma unroll
     for (int r = 0; r < 12; ++r) {
-      const uint32_t raw = P[r][1] ^ 0x80808080u;   // patch columns 4..7 = block columns 0..3
+      if constexpr (BPS == 1) {
+        const uint32_t raw = P[r][1] ^ 0x80808080u;   // patch columns 4..7 = block columns 0..3
 #pragma unroll
-      for (int c = 0; c < 4; ++c) V0[r][c] = (float)((raw >> (8 * c)) & 0xff);
+        for (int c = 0; c < 4; ++c) V0[r][c] = (float)((raw >> (8 * c)) & 0xff);
+      } else {
+        V0[r][0] = (float)(P[r][2] & 0xffff); V0[r][1] = (float)(P[r][2] >> 16);
+        V0[r][2] = (float)(P[r][3] & 0xffff); V0[r][3] = (float)(P[r][3] >> 16);
+      }
     }
+    const float up = (float)(64 >> sh1);
     float cw[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) cw[t] = cv[t] * 64.f;
+    for (int t = 0; t < 8; ++t) cw[t] = cv[t] * up;
     const float init_i = init - 8192.f * 64.f * sc2;
     float yG[5][4], yZ[4][4];
 #pragma unroll
