@@ -103,6 +103,23 @@ struct hmme_ctx {
   // frame path scratch (grown on demand)
   void* d_jobs = nullptr;         // MeJob[] or MeJob16[]
   size_t jobs_bytes = 0;
+  // A job table is a function of the picture size, the search range, the CTU range, the number of pairs and the predictors.  Launches
+  // WITHOUT predictors (d_pred_q == null: the zero predictor of the reference's own call) of the same geometry on the same stream find
+  // the table of the launch before still in place and skip the kernels that write it -- one kernel launch less per search step
+  // (HMME_NO_TABLE_CACHE=1: always rebuild).  `buf` / `buf2`: the allocations the table lives in (a reallocation invalidates it)
+  struct TableTag {
+    bool valid = false;
+    int w = 0, h = 0, bit_depth = 0, sr = 0, first = 0, count = 0, pairs = 0;
+    const void* buf = nullptr; const void* buf2 = nullptr; void* stream = nullptr;
+    bool same(const TableTag& o) const {
+      return valid && o.valid && w == o.w && h == o.h && bit_depth == o.bit_depth && sr == o.sr && first == o.first && count == o.count && pairs == o.pairs &&
+             buf == o.buf && buf2 == o.buf2 && stream == o.stream;
+    }
+  };
+  TableTag jobs_tag;              // what d_jobs / d_first_strip hold (searches)
+  void* d_frac_jobs = nullptr;    // MeJob[] of the refinement launches that read a table (+ the job counter of the job-walking mode)
+  size_t frac_jobs_bytes = 0;
+  TableTag frac_jobs_tag;
   int wg_slots = 512;     // search workgroups resident at once: 2 per CU (VGPRs of the search kernels, LDS of the 16-bit one)
   int* d_first_strip = nullptr;
   int first_strip_cap = 0;
@@ -460,7 +477,7 @@ void hmme_destroy(hmme_ctx* ctx) {
   if (ctx->stream) { hipStreamSynchronize(ctx->stream); hipStreamDestroy(ctx->stream); }
   if (ctx->scratch_done) hipEventDestroy(ctx->scratch_done);
   hipFree(ctx->d_call);
-  hipFree(ctx->d_jobs); hipFree(ctx->d_first_strip); hipFree(ctx->d_best);
+  hipFree(ctx->d_jobs); hipFree(ctx->d_frac_jobs); hipFree(ctx->d_first_strip); hipFree(ctx->d_best);
   hipFree(ctx->d_pred); hipFree(ctx->d_mv); hipFree(ctx->d_sad); hipFree(ctx->d_flag);
   hipFree(ctx->d_wwin); hipFree(ctx->d_frac_cover); hipFree(ctx->d_imv); hipFree(ctx->d_qmv); hipFree(ctx->d_fcost);
   if (ctx->h_call) hipHostFree(ctx->h_call);
@@ -1077,14 +1094,24 @@ static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_para
   size_t cap = ctx->jobs_bytes;
   const size_t per_ref = n_refs > 0 ? (need + n_refs - 1) / n_refs : need;   // what kMaxRefs pairs of this picture size would ask for
   int rc = ensure(ctx, (uint8_t**)&ctx->d_jobs, &cap, need, per_ref * hmme::kMaxRefs + 4096);
+  if (cap != ctx->jobs_bytes) ctx->jobs_tag.valid = false;   // reallocated: whatever the table was, it is gone
   ctx->jobs_bytes = cap;
   if (rc) return rc;
   if (wide || pl->tile8 || n_tail) {
     size_t fcap = (size_t)ctx->first_strip_cap * sizeof(int);
+    const size_t fcap0 = fcap;
     rc = ensure(ctx, &ctx->d_first_strip, &fcap, sizeof(int) * (size_t)jobs, sizeof(int) * (size_t)(jobs / (n_refs > 0 ? n_refs : 1) + 1) * hmme::kMaxRefs);
+    if (fcap != fcap0) ctx->jobs_tag.valid = false;
     ctx->first_strip_cap = (int)(fcap / sizeof(int));
     if (rc) return rc;
   }
+  static const bool no_cache = std::getenv("HMME_NO_TABLE_CACHE") != nullptr;
+  hmme_ctx::TableTag tag;
+  tag.valid = !d_pred_q && !no_cache;
+  tag.w = cur->width; tag.h = cur->height; tag.bit_depth = fp->bit_depth; tag.sr = fp->search_range; tag.first = first; tag.count = count; tag.pairs = n_refs;
+  tag.buf = ctx->d_jobs; tag.buf2 = (wide || pl->tile8 || n_tail) ? ctx->d_first_strip : nullptr; tag.stream = (void*)s;
+  if (tag.same(ctx->jobs_tag)) return HMME_OK;   // the table of the launch before is this launch's table
+  ctx->jobs_tag.valid = false;
   const dim3 block(256);
   auto grid = [](int n) { return dim3((n + 255) / 256); };
   if (pl->tile8)
@@ -1103,6 +1130,7 @@ static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_para
                          (const int16_t*)d_pred_q, first, count, n_refs, cur->width, cur->height, fp->search_range, pl->tail_parts, head, n_tail);
   }
   HIP_TRY(ctx, hipGetLastError());
+  ctx->jobs_tag = tag;
   return HMME_OK;
 }
 
@@ -1272,13 +1300,14 @@ int hmme_refine_pairs_device(hmme_ctx* ctx, const hmme_plane* const* curs, const
   const int jobs = pl.count * n_pairs;
   rc = build_frac_cover(ctx);
   if (rc == HMME_OK) {
-    size_t cap = ctx->jobs_bytes;
-    rc = ensure(ctx, (uint8_t**)&ctx->d_jobs, &cap, sizeof(MeJob) * (size_t)jobs + 64,   // + the launch's job counter behind the table
+    size_t cap = ctx->frac_jobs_bytes;
+    rc = ensure(ctx, (uint8_t**)&ctx->d_frac_jobs, &cap, sizeof(MeJob) * (size_t)jobs + 64,   // + the launch's job counter behind the table
                 sizeof(MeJob) * (size_t)pl.count * hmme::kMaxRefs + 4096);
-    ctx->jobs_bytes = cap;
+    if (cap != ctx->frac_jobs_bytes) ctx->frac_jobs_tag.valid = false;
+    ctx->frac_jobs_bytes = cap;
   }
   if (rc == HMME_OK) {
-    uint32_t* counter = (uint32_t*)((uint8_t*)ctx->d_jobs + ((sizeof(MeJob) * (size_t)jobs + 15) & ~(size_t)15));
+    uint32_t* counter = (uint32_t*)((uint8_t*)ctx->d_frac_jobs + ((sizeof(MeJob) * (size_t)jobs + 15) & ~(size_t)15));
     const int had = use_hadamard ? 1 : 0, wide = curs[0]->bps == 2 ? 1 : 0;
     const int grid = frac_grid(ctx, wide, had, jobs);
     // one workgroup per job (the default) on the two-wave builds: every workgroup derives its job itself (FracPrep) -- no job table, no
@@ -1289,11 +1318,18 @@ int hmme_refine_pairs_device(hmme_ctx* ctx, const hmme_plane* const* curs, const
     static const bool table = std::getenv("HMME_FRAC_JOB_TABLE") != nullptr;   // A/B: the job table and its kernel as before
     const bool walk = grid < jobs, few = jobs <= 4 * ctx->num_cus;
     const bool need_table = walk || table || frac_three_waves(wide, 0, few);
-    if (need_table)
-      hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, dim3((jobs + 255) / 256), dim3(256), 0, s, (MeJob*)ctx->d_jobs, (const int16_t*)d_pred_q,
+    static const bool no_cache = std::getenv("HMME_NO_TABLE_CACHE") != nullptr;
+    hmme_ctx::TableTag tag;
+    tag.valid = !d_pred_q && !no_cache && !walk;   // (the job-walking mode's prep kernel also resets the job counter: every launch)
+    tag.w = curs[0]->width; tag.h = curs[0]->height; tag.bit_depth = fp->bit_depth; tag.sr = fp->search_range; tag.first = pl.first; tag.count = pl.count;
+    tag.pairs = n_pairs; tag.buf = ctx->d_frac_jobs; tag.stream = (void*)s;
+    const bool have_table = need_table && tag.same(ctx->frac_jobs_tag);
+    if (need_table && !have_table) ctx->frac_jobs_tag = tag;
+    if (need_table && !have_table)
+      hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, dim3((jobs + 255) / 256), dim3(256), 0, s, (MeJob*)ctx->d_frac_jobs, (const int16_t*)d_pred_q,
                          pl.first, pl.count, n_pairs, curs[0]->width, curs[0]->height, fp->search_range, 0, jobs, 0, counter);
     hipLaunchKernelGGL(frac_kernel(wide, had, 0, few), dim3(grid), dim3(hmme::frac_threads(wide ? 2 : 1)), hmme::frac_lds_bytes(wide ? 2 : 1), s, pl.curs,
-                       curs[0]->pitch, pl.refs, refs[0]->pitch, need_table ? (const MeJob*)ctx->d_jobs : (const MeJob*)nullptr, prep, jobs, walk ? counter : (uint32_t*)nullptr, ctx->d_frac_cover,
+                       curs[0]->pitch, pl.refs, refs[0]->pitch, need_table ? (const MeJob*)ctx->d_frac_jobs : (const MeJob*)nullptr, prep, jobs, walk ? counter : (uint32_t*)nullptr, ctx->d_frac_cover,
                        (const int16_t*)d_int_mv, ctx->lambda_q16,
                        fp->bit_depth, kNoWp, (int16_t*)d_out_qmv, (uint32_t*)d_out_cost);
     const hipError_t e = hipGetLastError();

@@ -275,6 +275,8 @@ int hmme_refine_pairs_device(hmme_ctx* ctx, const hmme_plane* const* curs, const
  *                         (default: two waves when jobs <= 4 x CUs, else three)
  *   HMME_FRAC_JOB_TABLE=1 whole-picture refinement launches: job table written by a kernel in front of the launch (as before round 4's
  *                         end) instead of every workgroup deriving its job itself
+ *   HMME_NO_TABLE_CACHE=1 launches without predictors: rebuild the job table every time (default: a launch of the same geometry on the
+ *                         same stream as the one before it reuses the table that is still in place)
  *   HMME_TAIL_PARTS=<n>   pieces per job of a launch's last, partial round of workgroups: default = the planner's choice
  *                         (DESIGN.md 5 "rounds of workgroups"); 1 = no tail plan
  *   HMME_STRIPS16=<n>     16-bit search kernel: that many equal window strips per job instead of the planner's number

@@ -1111,6 +1111,60 @@ def test_profiling_tooling_produces_a_counter_summary(tmp_path):
             os.remove(os.path.join(ROOT, "profiles", f))
 
 
+def test_job_table_cache_is_invisible():
+    """launches without predictors keep their job table for the next launch of the same geometry (hmme.hip TableTag): a sequence that
+    revisits geometries, slips launches WITH predictors in between (they overwrite the table) and changes the CTU range gives, call
+    by call, what a fresh context gives for that call alone -- search tables (8-bit whole jobs with a tail plan, 10-bit strips) and
+    the table of the refinement's three-wave build (2160p: 2 040 jobs)"""
+    from hmme import api, synth
+    m = synth.MARGIN
+
+    def planes(eng, w, h, bd, seed):
+        cur, ref, _ = synth.make_pair(w, h, seed=seed, bit_depth=bd, max_mv=6, region=64)
+        pc, pr = eng.plane(w, h, bd), eng.plane(w, h, bd)
+        pc.upload_pel(cur, (m, m)); pr.upload_pel(ref, (m, m))
+        return pc, pr
+
+    def call(eng, pl, sr, pred, first, count, refine):
+        eng.set_lambda(57.9)
+        mv, sad = eng.search_frame(pl[0], pl[1], sr, pred, ctu_first=first, ctu_count=count)
+        if not refine:
+            return mv, sad
+        q, c = eng.refine_frame(pl[0], pl[1], sr, mv, pred) if (first, count) == (0, -1) else (mv, sad)
+        return mv, sad, q, c
+
+    geoms = {"A": (320, 192, 8, 16), "B": (256, 136, 10, 24), "C": (704, 576, 8, 64)}   # C: 99 jobs on 512 places -> all tail (split kernel + first-strip table)
+    seq = [("A", None, 0, -1), ("A", None, 0, -1), ("A", "p", 0, -1), ("A", None, 0, -1), ("B", None, 0, -1), ("A", None, 0, -1), ("A", None, 2, 5),
+           ("A", None, 0, -1), ("C", None, 0, -1), ("C", None, 0, -1), ("B", "p", 0, -1), ("B", None, 0, -1), ("C", "p", 0, -1), ("C", None, 0, -1)]
+    eng = api.Engine(0, 128)
+    held = {k: planes(eng, *g[:3], seed=40 + i) for i, (k, g) in enumerate(geoms.items())}
+    for step, (k, pk, first, count) in enumerate(seq):
+        w, h, bd, sr = geoms[k]
+        n = api.load().hmme_num_ctus(w, h)
+        pred = synth.random_predictors(n, seed=step, max_pel=6) if pk else None
+        got = call(eng, held[k], sr, pred, first, count, True)
+        fresh = api.Engine(0, 128)
+        want = call(fresh, planes(fresh, w, h, bd, seed=40 + list(geoms).index(k)), sr, pred, first, count, True)
+        fresh.close()
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b), (step, k, pk, first, count)
+    # the refinement's own table (three-wave build): 2160p, without / with / without predictors
+    w, h, sr = 3840, 2160, 16
+    big = planes(eng, w, h, 8, seed=77)
+    n = api.load().hmme_num_ctus(w, h)
+    mv, _ = eng.search_frame(big[0], big[1], sr)
+    for step, pk in enumerate((None, None, "p", None)):
+        pred = synth.random_predictors(n, seed=90 + step, max_pel=6) if pk else None
+        q, c = eng.refine_frame(big[0], big[1], sr, mv, pred)
+        other = api.Engine(0, 128)
+        other.set_lambda(57.9)
+        ob = planes(other, w, h, 8, seed=77)
+        q1, c1 = other.refine_frame(ob[0], ob[1], sr, mv, pred)
+        other.close()
+        assert np.array_equal(q, q1) and np.array_equal(c, c1), (step, pk)
+    eng.close()
+
+
 def test_refinement_launch_modes_give_the_same_tables():
     """HMME_FRAC_GRID: one workgroup per job (the default, whole-frame == oracle elsewhere in this file), n workgroups that take job
     after job from the launch's counter, and as many of those as the chip holds -- the same tables, whoever evaluates a job"""
