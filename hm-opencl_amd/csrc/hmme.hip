@@ -1313,11 +1313,11 @@ int hmme_refine_pairs_device(hmme_ctx* ctx, const hmme_plane* const* curs, const
     // one workgroup per job (the default) on the two-wave builds: every workgroup derives its job itself (FracPrep) -- no job table, no
     // launch in front of this one (1080p: 0.095 -> 0.090 ms).  The three-wave build reads a table (me_frac_kernel), and so does the
     // job-walking launch of HMME_FRAC_GRID: its prep kernel is also what resets the job counter
-    if (pl.count > 0xffff || pl.first > 0xffff) return pairs_end(ctx, curs, refs, n_pairs, s, fail(ctx, HMME_ERR_UNSUPPORTED, "refinement launch: more than 65 535 CTUs per picture"));
     const hmme::FracPrep prep = {(const int16_t*)d_pred_q, (uint32_t)pl.first | (uint32_t)pl.count << 16, (uint32_t)curs[0]->width | (uint32_t)curs[0]->height << 16, fp->search_range};
     static const bool table = std::getenv("HMME_FRAC_JOB_TABLE") != nullptr;   // A/B: the job table and its kernel as before
     const bool walk = grid < jobs, few = jobs <= 4 * ctx->num_cus;
-    const bool need_table = walk || table || frac_three_waves(wide, 0, few);
+    const bool packable = pl.count <= 0xffff && pl.first <= 0xffff;   // FracPrep packs the CTU range into 16 + 16 bits (a 16384 x 16384 picture has 65 536 CTUs)
+    const bool need_table = walk || table || !packable || frac_three_waves(wide, 0, few);
     static const bool no_cache = std::getenv("HMME_NO_TABLE_CACHE") != nullptr;
     hmme_ctx::TableTag tag;
     tag.valid = !d_pred_q && !no_cache && !walk;   // (the job-walking mode's prep kernel also resets the job counter: every launch)
