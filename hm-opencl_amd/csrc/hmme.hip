@@ -708,7 +708,7 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
   const bool wide = p->bit_depth > 8 || bipred_origin || wp;
   int bias = bipred_origin ? (1 << p->bit_depth) : 0;
   // xPatternSearchFracDIF on 2*org - pred_other (the bBi pass, TEncSearch.cpp:3798 with bBi): the refinement kernel runs on the same
-  // biased u16 staging as the search; the bias passes HM's interpolation exactly and shifts its clip bounds (me_frac_eval)
+  // biased u16 staging as the search; the bias passes HM's interpolation exactly and shifts its clip bounds (me_kernels.hpp, the evaluation of one work item)
   const int shift_bd = p->shift_free ? 8 : p->bit_depth;   // the kernels shift by (this - 8)
   const int sr_cap = ctx->sr_max;
   if (wx < 1 || wy < 1 || wx > 2 * sr_cap + 1 || wy > 2 * sr_cap + 1)
@@ -848,7 +848,7 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
     rc = build_frac_cover(ctx);
     if (rc) return rc;
     const int16_t* d_imv = do_search ? d_mv1 : (const int16_t*)(ctx->d_call + kCallImv);
-    // weighted: the interpolated prediction is weighted sample by sample (me_frac_eval, FracWp); the current samples carry `bias`, the raw window none
+    // weighted: the interpolated prediction is weighted sample by sample (me_frac_eval0 / me_frac_eval1, FracWp); the current samples carry `bias`, the raw window none
     const hmme::FracWp fw = wp ? hmme::FracWp{std::ldexp((float)wp->w0, -wp->shift), std::ldexp((float)wp->round, -wp->shift), (float)(bias + wp->offset)} : kNoWp;
     hipLaunchKernelGGL(frac_kernel(wide ? 1 : 0, refine_had ? 1 : 0, wp ? 1 : 0, true), dim3(1), dim3(hmme::frac_threads(bps)), hmme::frac_lds_bytes(bps), s, one_ref(ctx->d_call + kCallCtu),
                        64 * bps, one_ref(ref_base), kWinPitch, (const MeJob*)(ctx->d_call + kCallFracJob), kNoPrep, 1, (uint32_t*)nullptr, ctx->d_frac_cover, d_imv, ctx->lambda_q16,

@@ -1621,10 +1621,9 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
   }
   for (int i = tid; i < (kFracPairs8 + kFracPairs4) / 8; i += NT) ((uint4*)cover)[i] = ((const uint4*)cover_g)[i];
 
-  // The host launches as many workgroups as the chip holds at a time and each takes job after job from a counter (a job lives ~60 us;
-  // launched one workgroup per job, the slots stood empty between a workgroup's end and its successor's first instruction for a good
-  // part of that).  The counter deals the jobs out as workgroups become free, like the dispatcher would: jobs differ in
-  // length with the content.  job_counter == null (the per-CTU call: one job): blockIdx.x, blockIdx.x + gridDim.x, ...
+  // One workgroup per job is the default launch (job_counter == null: workgroup b takes job n_jobs - 1 - b).  With a counter
+  // (HMME_FRAC_GRID: fewer workgroups than jobs, each taking job after job as it becomes free) the loop below runs more than once;
+  // measured, that launch is the slower one once both deal the jobs last-first.
   uint32_t* next_job = counter + 2;     // LDS word: the job this workgroup works on
 #pragma unroll 1
   for (int turn = blockIdx.x;; turn += gridDim.x) {
