@@ -887,11 +887,11 @@ __global__ void me_prep_jobs_tile_kernel(MeJob16* jobs, int* first_strip_of_job,
 // The step after the path: TEncSearch::xPatternSearchFracDIF (reference TEncSearch.cpp:4294-4331) for all 593
 // slots of a CTU -- half-pel then quarter-pel refinement around each slot's integer MV with HM's 8-tap luma
 // interpolation (TComInterpolationFilter.cpp:57-63, :170-260) and Hadamard (xGetHADs, TComRdCost.cpp:1537-1604)
-// or SAD distortion.  Work item = one 4x4 sub-block of one slot (6 144 per CTU); one lane per item.  An 8x8
-// Hadamard is assembled from the four 4x4 transforms of its quadrants (H8 = [[H4, H4], [H4, -H4]]) with two
-// quad_perm DPP butterflies, so slots whose size is a multiple of 8 (8x8 Hadamard blocks) and the others (4x4
-// blocks) run the same code.  Per-slot distortions accumulate in LDS (ds_add_u32); 593 threads then add the MV cost
-// and pick the winner in HM's point order (strict '<', tables TEncSearch.cpp:51-75).
+// or SAD distortion.  Work item = one 4x4 block of one DISTINCT (position, MV) pair of the CTU ("Work sharing" below: at most 6 144
+// per CTU and stage, far fewer where slots share their motion); one lane per item.  An 8x8 Hadamard is assembled from the four 4x4
+// transforms of its quadrants (H8 = [[H4, H4], [H4, -H4]]) with two quad_perm DPP butterflies, so slots whose size is a multiple of 8
+// (8x8 Hadamard blocks) and the others (4x4 blocks) run the same code.  Per-slot distortions accumulate in LDS (ds_add_u32); 593
+// threads then add the MV cost and pick the winner in HM's point order (strict '<', tables TEncSearch.cpp:51-75).
 // per-slot distortion sums of the nine refinement points
 constexpr int kFracAccRow = 9, kFracAcc = 593 * kFracAccRow, kFracAccDw = (kFracAcc + 15) & ~15;
 // BPS = bytes per sample of the planes (1: 8-bit video, 2: 9..12 bit)
@@ -1244,7 +1244,7 @@ constexpr int kFracCover8 = 18, kFracCover4 = 6, kFracPairs8 = 64 * kFracCover8,
 // slot state word: (mx - lt_x) | (my - lt_y) << 9 | (half_x + 1) << 18 | (half_y + 1) << 20; the sharing key of a stage
 constexpr uint32_t kFracKey0 = 0x3ffffu, kFracKey1 = 0x3fffffu;
 
-// `src`: window sample (-4,-4) of this CTU in the reference plane, `gpitch` bytes per row.  The 12x12 patch comes straight
+// `src`: window sample (-4,-4) of this CTU in the reference plane, `gpitch` bytes per row.  The 12x12 patch (11x11 in the quarter-pel stage) comes straight
 // from global memory: the windows of neighbouring CTUs overlap and stay in L2, and an LDS copy of the window (tried first)
 // was no faster while it capped the search range at 64 and the occupancy at one 16-bit workgroup per CU.
 // STAGE 0 (the nine half-pel points) with the filters SHARED between the points that use them.  The half-pel sample to the right of
