@@ -89,7 +89,14 @@ struct hmme_ctx {
   hipStream_t stream = nullptr;   // private stream of the synchronous entry points
   // frame-path scratch (job tables, merge table, cover table) is shared by every call of the context: a call on another stream
   // than the previous one first waits (stream-side) for that one's last use
-  hipEvent_t scratch_done = nullptr;
+  // ONE event is recorded behind the kernels of a launch (ring of kLaunchEvents, launch_end): it marks the scratch's last use and the last
+  // read of every plane the launch took (hmme_plane::read_done points into the ring).  A ring entry that has been recorded again
+  // since stands for a LATER point of the same chain of launches -- every launch of a context is ordered behind the one before it
+  // through the scratch -- so a waiter on a recycled entry waits longer than it had to, never too little.
+  static constexpr int kLaunchEvents = 64;
+  hipEvent_t launch_ev[kLaunchEvents] = {};
+  unsigned launch_seq = 0;
+  hipEvent_t scratch_done = nullptr;   // the ring entry of the last launch
   hipStream_t scratch_stream = nullptr;
   bool scratch_used = false;
   // per-CTU path: one device block and its pinned host mirror -- jobs, first-strip index, merge table preset, current
@@ -154,8 +161,8 @@ struct hmme_plane {
   hipEvent_t filled = nullptr;      // recorded after the last fill; readers on another stream wait for it
   hipStream_t fill_stream = nullptr;
   bool fill_pending = false;
-  // recorded after the last search / refinement that reads the plane; a refill on another stream waits for it (write after read).
-  // mutable: reading a plane does not change what it holds
+  // the event of the last launch that reads the plane (an entry of the context's ring, hmme_ctx::launch_ev: not owned); a refill on
+  // another stream waits for it (write after read).  mutable: reading a plane does not change what it holds
   mutable hipEvent_t read_done = nullptr;
   mutable hipStream_t read_stream = nullptr;
   mutable bool read_pending = false;
@@ -200,9 +207,10 @@ int scratch_acquire(hmme_ctx* ctx, hipStream_t s) {
   if (ctx->scratch_used && ctx->scratch_stream != s) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->scratch_done, 0));
   return HMME_OK;
 }
-int scratch_release(hmme_ctx* ctx, hipStream_t s) {
-  HIP_TRY(ctx, hipEventRecord(ctx->scratch_done, s));
-  ctx->scratch_stream = s; ctx->scratch_used = true;
+int launch_end(hmme_ctx* ctx, hipStream_t s) {
+  hipEvent_t ev = ctx->launch_ev[ctx->launch_seq++ % hmme_ctx::kLaunchEvents];
+  HIP_TRY(ctx, hipEventRecord(ev, s));
+  ctx->scratch_done = ev; ctx->scratch_stream = s; ctx->scratch_used = true;
   return HMME_OK;
 }
 int plane_wait(hmme_ctx* ctx, const hmme_plane* pl, hipStream_t s) {
@@ -210,12 +218,14 @@ int plane_wait(hmme_ctx* ctx, const hmme_plane* pl, hipStream_t s) {
   return HMME_OK;
 }
 // a search / refinement on `s` has been enqueued that reads `pl`.  One event holds the LAST read only, so a read on a new stream
-// first makes that stream wait for the previous reader: the event then covers both.
-int plane_read_mark(hmme_ctx* ctx, const hmme_plane* pl, hipStream_t s) {
+// first makes that stream wait for the previous reader (plane_read_chain, before the launch's event is recorded): the event then
+// covers both.  plane_read_mark: the launch's event (launch_end) is the plane's last read
+int plane_read_chain(hmme_ctx* ctx, const hmme_plane* pl, hipStream_t s) {
   if (pl->read_pending && pl->read_stream != s) HIP_TRY(ctx, hipStreamWaitEvent(s, pl->read_done, 0));
-  HIP_TRY(ctx, hipEventRecord(pl->read_done, s));
-  pl->read_stream = s; pl->read_pending = true;
   return HMME_OK;
+}
+void plane_read_mark(hmme_ctx* ctx, const hmme_plane* pl, hipStream_t s) {
+  pl->read_done = ctx->scratch_done; pl->read_stream = s; pl->read_pending = true;
 }
 // before `s` overwrites the plane (or its staging buffer): the last fill and the last reader, if they ran on other streams
 int plane_write_wait(hmme_ctx* ctx, const hmme_plane* pl, hipStream_t s) {
@@ -233,15 +243,27 @@ RefSet one_ref(const uint8_t* base) {
   return r;
 }
 
+// Progress-based wave priorities of the search kernels (me_search_kernel, ME_FAIR_PRIO): the kernel whose workgroups are whole CTU
+// searches always runs with them (+8 % on a single-round 1080p launch, +2 % at 2160p: the lonely ends of each CU's last workgroups);
+// the launches of many small workgroups -- split tasks, window tiles, 16-bit strips -- only while the launch is a few rounds of the
+// chip's workgroup slots (720p +5 %, 1080p 10-bit +5 %; config 5's 16 rounds of strips lost 0.8 % with them:
+// profiles/r05d_fair_priority_ab.txt).  HMME_FAIR_PRIO=0|1 forces one for A/B runs.
+int fair_prio(const hmme_ctx* ctx, int workgroups, bool whole_jobs) {
+  static const int force = std::getenv("HMME_FAIR_PRIO") ? std::atoi(std::getenv("HMME_FAIR_PRIO")) : -1;
+  if (force >= 0) return force ? 1 : 0;
+  return (whole_jobs || workgroups <= 4 * ctx->wg_slots) ? 1 : 0;
+}
+
 int launch_search8(hmme_ctx* ctx, const RefSet& cur, int cur_pitch, const RefSet& ref, int ref_pitch, const MeJob* d_jobs,
                    int n_jobs, int fen, int16_t* d_mv, uint32_t* d_sad, hipStream_t stream) {
   if (n_jobs <= 0) return HMME_OK;
+  const int fair = fair_prio(ctx, n_jobs, true);
   if (fen)
     hipLaunchKernelGGL((hmme::me_search_kernel<1, 0>), dim3(n_jobs), dim3(hmme::kThreads), 0, stream, cur, cur_pitch, ref,
-                       ref_pitch, (const void*)d_jobs, ctx->lambda_q16, d_mv, d_sad, (unsigned long long*)nullptr);
+                       ref_pitch, (const void*)d_jobs, ctx->lambda_q16, d_mv, d_sad, (unsigned long long*)nullptr, fair);
   else
     hipLaunchKernelGGL((hmme::me_search_kernel<0, 0>), dim3(n_jobs), dim3(hmme::kThreads), 0, stream, cur, cur_pitch, ref,
-                       ref_pitch, (const void*)d_jobs, ctx->lambda_q16, d_mv, d_sad, (unsigned long long*)nullptr);
+                       ref_pitch, (const void*)d_jobs, ctx->lambda_q16, d_mv, d_sad, (unsigned long long*)nullptr, fair);
   HIP_TRY(ctx, hipGetLastError());
   return HMME_OK;
 }
@@ -270,12 +292,13 @@ int launch_search8_split(hmme_ctx* ctx, const RefSet& cur, int cur_pitch, const 
   unsigned long long* best = nullptr;
   int rc = merge_table(ctx, n_jobs, preset_best, stream, &best);
   if (rc) return rc;
+  const int fair = fair_prio(ctx, n_jobs * n_split, false);
   if (fen)
     hipLaunchKernelGGL((hmme::me_search_kernel<1, 1>), dim3(n_jobs * n_split), dim3(hmme::kThreads), 0, stream, cur, cur_pitch,
-                       ref, ref_pitch, (const void*)d_jobs, ctx->lambda_q16, (int16_t*)nullptr, (uint32_t*)nullptr, best);
+                       ref, ref_pitch, (const void*)d_jobs, ctx->lambda_q16, (int16_t*)nullptr, (uint32_t*)nullptr, best, fair);
   else
     hipLaunchKernelGGL((hmme::me_search_kernel<0, 1>), dim3(n_jobs * n_split), dim3(hmme::kThreads), 0, stream, cur, cur_pitch,
-                       ref, ref_pitch, (const void*)d_jobs, ctx->lambda_q16, (int16_t*)nullptr, (uint32_t*)nullptr, best);
+                       ref, ref_pitch, (const void*)d_jobs, ctx->lambda_q16, (int16_t*)nullptr, (uint32_t*)nullptr, best, fair);
   HIP_TRY(ctx, hipGetLastError());
   return finalize ? finalize_best(ctx, best, d_jobs, d_first_strip, n_jobs, d_mv, d_sad, stream) : HMME_OK;
 }
@@ -307,7 +330,7 @@ int launch16_t(hmme_ctx* ctx, const RefSet& cur, int cur_pitch, const RefSet& re
     attr_set = true;
   }
   hipLaunchKernelGGL((hmme::me_search16_kernel<FEN, PDW>), dim3(n_wg), dim3(hmme::kThreads16), lds, stream, cur, cur_pitch, ref,
-                     ref_pitch, d_jobs, ctx->lambda_q16, sh, d_best);
+                     ref_pitch, d_jobs, ctx->lambda_q16, sh, d_best, fair_prio(ctx, n_wg, false));
   HIP_TRY(ctx, hipGetLastError());
   return HMME_OK;
 }
@@ -455,7 +478,7 @@ int hmme_create(int device, int sr_max, unsigned flags, hmme_ctx** out) {
     if (e_ != hipSuccess) { int rc = fail(nullptr, HMME_ERR_NOMEM, "hmme_create: %s -> %s", #call, hipGetErrorString(e_)); hmme_destroy(ctx); return rc; } \
   } while (0)
   CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-  CREATE_TRY(hipEventCreateWithFlags(&ctx->scratch_done, hipEventDisableTiming));
+  for (int i = 0; i < hmme_ctx::kLaunchEvents; ++i) CREATE_TRY(hipEventCreateWithFlags(&ctx->launch_ev[i], hipEventDisableTiming));
   CREATE_TRY(hipMalloc(&ctx->d_call, kCallWin + win_bytes));
   CREATE_TRY(hipHostMalloc(&ctx->h_call, kCallWin + win_bytes, hipHostMallocMapped));
   CREATE_TRY(hipHostGetDevicePointer((void**)&ctx->h_call_dev, ctx->h_call, 0));
@@ -475,7 +498,8 @@ void hmme_destroy(hmme_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   if (ctx->stream) { hipStreamSynchronize(ctx->stream); hipStreamDestroy(ctx->stream); }
-  if (ctx->scratch_done) hipEventDestroy(ctx->scratch_done);
+  for (int i = 0; i < hmme_ctx::kLaunchEvents; ++i)
+    if (ctx->launch_ev[i]) hipEventDestroy(ctx->launch_ev[i]);
   hipFree(ctx->d_call);
   hipFree(ctx->d_jobs); hipFree(ctx->d_frac_jobs); hipFree(ctx->d_first_strip); hipFree(ctx->d_best);
   hipFree(ctx->d_pred); hipFree(ctx->d_mv); hipFree(ctx->d_sad); hipFree(ctx->d_flag);
@@ -922,7 +946,6 @@ int hmme_plane_create_ex(hmme_ctx* ctx, int width, int height, int bit_depth, hm
   pl->rows = height + 2 * kMarginY;
   hipError_t e = hipMalloc(&pl->d_data, (size_t)pl->pitch * (pl->rows + 1));
   if (e == hipSuccess && (e = hipEventCreateWithFlags(&pl->filled, hipEventDisableTiming)) != hipSuccess) hipFree(pl->d_data);
-  if (e == hipSuccess && (e = hipEventCreateWithFlags(&pl->read_done, hipEventDisableTiming)) != hipSuccess) { hipEventDestroy(pl->filled); hipFree(pl->d_data); }
   if (e != hipSuccess) { delete pl; return fail(ctx, HMME_ERR_NOMEM, "plane allocation: %s", hipGetErrorString(e)); }
   *out = pl;
   return HMME_OK;
@@ -935,7 +958,6 @@ void hmme_plane_destroy(hmme_plane* pl) {
   if (pl->fill_pending) hipEventSynchronize(pl->filled);   // a fill or a search still in flight must not outlive the buffer
   if (pl->read_pending) hipEventSynchronize(pl->read_done);
   if (pl->filled) hipEventDestroy(pl->filled);
-  if (pl->read_done) hipEventDestroy(pl->read_done);
   hipFree(pl->d_data);
   hipFree(pl->d_stage);
   delete pl;
@@ -1181,11 +1203,14 @@ int pairs_begin(hmme_ctx* ctx, const hmme_plane* const* curs, const hmme_plane* 
 // after the kernels are enqueued (or an enqueue failed): the planes have a reader on `s`, the scratch a user
 int pairs_end(hmme_ctx* ctx, const hmme_plane* const* curs, const hmme_plane* const* refs, int n_pairs, hipStream_t s, int rc) {
   for (int r = 0; r < n_pairs; ++r) {
-    int r2 = (r == 0 || curs[r] != curs[r - 1]) ? plane_read_mark(ctx, curs[r], s) : HMME_OK;
-    if (r2 == HMME_OK) r2 = plane_read_mark(ctx, refs[r], s);
+    int r2 = (r == 0 || curs[r] != curs[r - 1]) ? plane_read_chain(ctx, curs[r], s) : HMME_OK;
+    if (r2 == HMME_OK) r2 = plane_read_chain(ctx, refs[r], s);
     if (rc == HMME_OK) rc = r2;
   }
-  const int r3 = scratch_release(ctx, s);
+  // one event for the whole launch (it was one per plane and one for the scratch: 3 .. 33 packets between two kernels of a stream)
+  const int r3 = launch_end(ctx, s);
+  if (r3 == HMME_OK)
+    for (int r = 0; r < n_pairs; ++r) { plane_read_mark(ctx, curs[r], s); plane_read_mark(ctx, refs[r], s); }
   return rc ? rc : r3;
 }
 }  // namespace

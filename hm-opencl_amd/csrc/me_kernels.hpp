@@ -41,6 +41,9 @@ constexpr int kGroups = 10;
 #ifndef ME_GUIDED_TASKS
 #define ME_GUIDED_TASKS 1
 #endif
+#ifndef ME_FAIR_PRIO   // A/B: 0 = every wave at the dispatch priority (the SIMD then favours its oldest wave)
+#define ME_FAIR_PRIO 1
+#endif
 constexpr int kIterPerTask = ME_ITER_PER_TASK;
 constexpr int kIterPerTaskSplit = ME_ITER_PER_TASK_SPLIT;
 static_assert(ME_ITER_PER_TASK <= 4 && (!ME_GUIDED_TASKS || ME_ITER_PER_TASK == 4), "2 iteration bits in the key; the guided schedule deals 4 / 2 / 1");
@@ -311,13 +314,19 @@ template <int FEN, int SPLIT>
 __global__ void __launch_bounds__(kThreads, 2)
 me_search_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitch,
                  const void* __restrict__ jobs_v, uint32_t lambda_q16, int16_t* __restrict__ out_mv,
-                 uint32_t* __restrict__ out_sad, unsigned long long* __restrict__ g_best) {
+                 uint32_t* __restrict__ out_sad, unsigned long long* __restrict__ g_best, int fair_prio) {
   __shared__ uint32_t win[kWinRowsMax * kPDW];
   __shared__ unsigned long long best64[kParts];
   __shared__ int task_ctr;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
+#ifdef ME_SEARCH_T_TIMELINE   // timing-only build (results are overwritten): when each workgroup starts, has its window staged, runs dry, ends (100 MHz wall clock)
+  const unsigned long long tl_start = wall_clock64();
+#endif
+#if ME_FAIR_PRIO
+  if (fair_prio) __builtin_amdgcn_s_setprio(3);   // a new workgroup comes first: its window loads go out at once, its first tasks run ahead of the older workgroup's last
+#endif
   MeJob job;
   int t_first = 0, t_end = 0x7fffffff, out_job = blockIdx.x;
   unsigned long long tile_off = 0;   // SPLIT, tiled windows: (y, x) of this tile's first candidate in the CTU's whole window
@@ -354,6 +363,9 @@ me_search_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pi
     me_stage_window<kPDW, kThreads>(win, src_al, pitch_dw, n, mis, tid);
   }
   __syncthreads();
+#ifdef ME_SEARCH_T_TIMELINE
+  const unsigned long long tl_staged = wall_clock64();
+#endif
 
   // -- 2. task list: the ceil(wx/4) candidate quads of a row are split into power-of-two parts
   //       (129 -> 32 + 1); part k lays a wave out as 2^k quads x (64 >> k) rows per iteration.
@@ -367,12 +379,41 @@ me_search_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pi
   const uint32_t mult_a = 1u << kIdxBits;
   const uint32_t mult_e = FEN ? (2u << kIdxBits) : (1u << kIdxBits);
   const bool rb1 = lane & 2, rb0 = lane & 1;
+#if ME_FAIR_PRIO
+  // Wave priority falls with the wave's progress (s_setprio 3 .. 0 over its expected share of the workgroup's lane-iterations).  A SIMD
+  // holds one wave of each of the CU's two workgroups and issues from the OLDER one whenever it can: of two workgroups that start
+  // together the older ran at full speed and the younger in its gaps (a fifth of the rate), then alone -- one wave per SIMD issues at
+  // ~0.8 of what two do -- for the rest of its life (profiles/r05b_search_timeline.txt: lifetimes 415 / 675 us in a single-round 1080p
+  // launch).  With the wave that is behind given the SIMD first, the two stay within a quarter of their work of each other and end
+  // together; in a launch of several rounds the same rule shortens the lonely ends of each CU's last workgroups.
+  // state: lane-iterations left at the current level << 2 | level (0..3 = s_setprio 3..0); without priorities the first level never ends
+  int prio_quarter = 0x0fffffff;
+  if (fair_prio) {
+    if constexpr (!SPLIT) {
+      int total = 0;
+      for (int kk = 5; kk >= 0; --kk)
+        if (quads & (1 << kk)) total += ((kk == 5 ? wy : wy_low) + (64 >> kk) - 1) / (64 >> kk);
+      prio_quarter = max(1, (total + 15) >> 4);   // a quarter of a wave's share (four waves)
+    } else {
+      prio_quarter = max(1, ((n_tasks - t_first) * kIt + 15) >> 4);   // this workgroup's slice of the CTU's tasks
+    }
+  }
+  int prio_state = prio_quarter << 2;
+#endif
 
   while (true) {
     int t = 0;
     if (lane == 0) t = atomicAdd(&task_ctr, 1);
     t = __builtin_amdgcn_readfirstlane(t);
     if (t >= n_tasks) break;
+#if ME_FAIR_PRIO
+    if (prio_state < 4 && (prio_state & 3) < 3) {   // the level's share is used up: one step down
+      prio_state += (prio_quarter << 2) + 1;
+      if ((prio_state & 3) == 1) __builtin_amdgcn_s_setprio(2);
+      else if ((prio_state & 3) == 2) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
+#endif
     // decode task t -> (x0, k, first iteration)
     int x0 = 0, k = 0, it0 = 0, n_it = 0;
     {
@@ -408,6 +449,9 @@ me_search_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pi
     uint32_t b0 = ME_MAXKEY, b1 = ME_MAXKEY, b2 = ME_MAXKEY, b3 = ME_MAXKEY, b4 = ME_MAXKEY, b5 = ME_MAXKEY,
              b6 = ME_MAXKEY, b7 = ME_MAXKEY, b8 = ME_MAXKEY, b9 = ME_MAXKEY;
 
+#if ME_FAIR_PRIO
+    prio_state -= n_it << 2;
+#endif
     for (int it = 0; it < n_it; ++it) {
       int cx = x0 + 4 * lx, cy = (it0 + it) * ty + ly;
       if (fold_part && cy == wy) { cx += 128; cy = wy - 1; }   // idle second row of the last iteration: leftover quads of the last row
@@ -468,7 +512,13 @@ me_search_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pi
     ME_FLUSH(5, b5) ME_FLUSH(6, b6) ME_FLUSH(7, b7) ME_FLUSH(8, b8) ME_FLUSH(9, b9)
 #undef ME_FLUSH
   }
+#ifdef ME_SEARCH_T_TIMELINE
+  const unsigned long long tl_dry = wall_clock64();   // this wave found the task counter dry
+#endif
   __syncthreads();
+#ifdef ME_SEARCH_T_TIMELINE
+  const unsigned long long tl_all = wall_clock64();
+#endif
 
   // -- 4. results: integer MV (TComMv layout) and the pure SAD at the arg-min (ruiSAD, reference
   //       TEncSearch.cpp:3895: best - getCost(best))
@@ -488,6 +538,23 @@ me_search_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pi
     out_mv[2 * o + 1] = (int16_t)mvy;
     out_sad[o] = cost - me_mv_cost(lambda_q16, mvx, mvy, job.pred_x, job.pred_y);
   }
+#ifdef ME_SEARCH_T_TIMELINE
+  __syncthreads();
+  if (lane == 0) {
+    uint32_t* o = out_sad + (long)out_job * kParts;
+    const int wv = tid >> 6;
+    if (wv == 0) {
+      const unsigned long long t1 = wall_clock64();
+      uint32_t hw_id;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+      uint32_t xcc_id;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+      o[0] = (uint32_t)tl_start; o[1] = (uint32_t)(tl_start >> 32); o[2] = (uint32_t)(tl_staged - tl_start); o[3] = (uint32_t)(tl_all - tl_start);
+      o[4] = (uint32_t)(t1 - tl_start); o[5] = hw_id; o[6] = xcc_id; o[7] = blockIdx.x;
+    }
+    o[8 + wv] = (uint32_t)(tl_dry - tl_start);
+  }
+#endif
 }
 
 // ---- frame helpers ---------------------------------------------------------------------------------
@@ -592,7 +659,7 @@ __device__ __forceinline__ uint32_t me_keymin3(uint32_t s0, uint32_t s1, uint32_
 template <int FEN, int PDW>
 __global__ void __launch_bounds__(kThreads16, 2)
 me_search16_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitch,
-                   const MeJob16* __restrict__ jobs, uint32_t lambda_q16, int sh, unsigned long long* __restrict__ g_best) {
+                   const MeJob16* __restrict__ jobs, uint32_t lambda_q16, int sh, unsigned long long* __restrict__ g_best, int fair_prio) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   unsigned long long* best64 = (unsigned long long*)smem;              // [593] (+1 pad)
   int* task_ctr = (int*)(smem + 2 * 594);
@@ -600,6 +667,9 @@ me_search16_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
+#if ME_FAIR_PRIO
+  if (fair_prio) __builtin_amdgcn_s_setprio(3);   // wave priority falls with the wave's progress: me_search_kernel
+#endif
   const MeJob16 jb = jobs[blockIdx.x];
   MeJob job = jb.j;
   const uint8_t* __restrict__ ref_base = refs.base[job.ctu_x & 63];
@@ -607,6 +677,11 @@ me_search16_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_
   job.ctu_x &= ~63;
   const int wx = job.rb_x - job.lt_x + 1;
   const int ny = jb.y1 - jb.y0;                                        // candidate rows of this strip
+#if ME_FAIR_PRIO
+  // lane-iterations of the two passes (even, odd columns), a quarter of one wave's share of them; state as in me_search_kernel
+  const int prio_quarter = fair_prio ? max(1, (((ny * ((((wx + 1) >> 1) + 2) / 3) + 63) >> 6) + ((ny * (((wx >> 1) + 2) / 3) + 63) >> 6) + 15) >> 4) : 0x0fffffff;
+  int prio_state = prio_quarter << 2;
+#endif
 
   for (int s = tid; s < kParts; s += kThreads16) best64[s] = ~0ull;
   // key = ((sum & mask) << lsh) + c  ==  (((sum << fen_shift) >> sh) << kIdxBits16) + c
@@ -665,6 +740,15 @@ me_search16_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_
     if (t >= n_tasks) break;
     const int it0 = t;
     constexpr int n_it = 1;
+#if ME_FAIR_PRIO
+    if (prio_state < 4 && (prio_state & 3) < 3) {
+      prio_state += (prio_quarter << 2) + 1;
+      if ((prio_state & 3) == 1) __builtin_amdgcn_s_setprio(2);
+      else if ((prio_state & 3) == 2) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
+    prio_state -= n_it << 2;
+#endif
     uint32_t b0 = ME_MAXKEY, b1 = ME_MAXKEY, b2 = ME_MAXKEY, b3 = ME_MAXKEY, b4 = ME_MAXKEY, b5 = ME_MAXKEY,
              b6 = ME_MAXKEY, b7 = ME_MAXKEY, b8 = ME_MAXKEY, b9 = ME_MAXKEY;
     for (int it = 0; it < n_it; ++it) {
