@@ -51,16 +51,27 @@ HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: HB
 LAMBDA = 57.9                                          # fixed, recorded
 
 
-def work_4x4_sads(api, w, h, sr):
+def work_4x4_sads(api, w, h, sr, pred=None):
     """4x4-block SAD evaluations of one picture search: sum over CTUs of (in-picture 4x4 blocks) x
-    (candidates of the CTU's clipped window)"""
+    (candidates of the CTU's window: xSetSearchRange around the CTU's predictor, clipped by clipMv -- the candidates actually searched)"""
     total = 0
+    ctu = 0
     for cy in range(0, h, 64):
         for cx in range(0, w, 64):
-            ltx, lty, rbx, rby = api.set_search_range(0, 0, sr, cx, cy, w, h)
+            px, py = (int(pred[ctu, 0]), int(pred[ctu, 1])) if pred is not None else (0, 0)
+            ltx, lty, rbx, rby = api.set_search_range(px, py, sr, cx, cy, w, h)
             blocks = (min(64, w - cx) // 4) * (min(64, h - cy) // 4)
             total += blocks * (rbx - ltx + 1) * (rby - lty + 1)
+            ctu += 1
     return total
+
+
+def warm_clock(eng, planes, fp, buf, stream, launches=24):
+    """untimed launches in front of a timed leg: the power management takes ~10 launches (tens of ms of load) to bring a GPU that idled
+    through the host work before the leg (picture synthesis, oracle checks) back to its sustained clock; a leg of a few short launches
+    would otherwise be timed on the way up (the same set-up as the headline's, main())"""
+    for _ in range(launches):
+        eng.search_pairs_device([planes[0]], [planes[1]], fp, None, buf[0].data_ptr(), buf[1].data_ptr(), stream)
 
 
 def library_build_id():
@@ -92,11 +103,12 @@ LIVE_PASSES = ("FETCH_SIZE", "WRITE_SIZE",
                "GRBM_GUI_ACTIVE GRBM_COUNT")
 
 
-def live_pmc(extra_args, kernel_name, budget_s=150.0):
+def live_pmc(extra_args, kernel_names, budget_s=150.0):
     """The counters of THIS run: after the timed region the benchmark starts `rocprofv3 --kernel-trace --pmc <one pass>` over a short
     headline-only run of itself (child processes; each counter group in a pass of its own, never combined with other trace domains, as
-    MI355X_MICROARCH.md prescribes) and condenses the per-dispatch means of the search kernel.  {} when rocprofv3 is not there or a
-    pass fails -- the line then falls back to the committed summary of the same library (pmc_profile)."""
+    MI355X_MICROARCH.md prescribes) and condenses the per-dispatch means of the kernels named (the search kernel; the refinement kernel
+    of the `refine` leg of the same child run).  {} when rocprofv3 is not there or a pass fails -- the line then falls back to the
+    committed summary of the same library (pmc_profile).  -> {kernel name: figures}"""
     import collections
     import csv
     import glob
@@ -107,7 +119,9 @@ def live_pmc(extra_args, kernel_name, budget_s=150.0):
         return {}
     tmp = tempfile.mkdtemp(prefix="hmme_pmc_")
     env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
-    means, kns = {}, {}
+    means = {k: {} for k in kernel_names}
+    kns = {k: {} for k in kernel_names}
+    scratch = {}
     t0 = time.time()
     try:
         for i, group in enumerate(LIVE_PASSES):
@@ -120,30 +134,48 @@ def live_pmc(extra_args, kernel_name, budget_s=150.0):
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return {}
-            acc, dur = collections.defaultdict(list), {}
+            acc = {k: collections.defaultdict(list) for k in kernel_names}
+            dur = {k: {} for k in kernel_names}
             for row in csv.DictReader(open(files[0])):
-                if kernel_name + "<" not in row["Kernel_Name"]:
-                    continue
-                acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
-                dur[row["Dispatch_Id"]] = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
-            if not acc:
+                for k in kernel_names:
+                    if k + "<" in row["Kernel_Name"]:
+                        acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                        dur[k][row["Dispatch_Id"]] = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+                        for col in ("Scratch_Size", "Private_Segment_Size", "Scratch_Memory_Size"):
+                            if row.get(col) not in (None, ""):
+                                scratch[k] = max(scratch.get(k, 0), int(float(row[col])))
+            if not acc[kernel_names[0]]:
                 return {}
-            for c, v in acc.items():
-                means[c] = sum(v) / len(v)
-                kns[c] = sum(dur.values()) / len(dur)
+            for k in kernel_names:
+                for c, v in acc[k].items():
+                    means[k][c] = sum(v) / len(v)
+                    kns[k][c] = sum(dur[k].values()) / len(dur[k])
     except (OSError, subprocess.SubprocessError, KeyError, ValueError):
         return {}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    d = {"seconds": round(time.time() - t0, 1), "passes": list(LIVE_PASSES)}
-    if "FETCH_SIZE" in means and "WRITE_SIZE" in means:   # KiB; on gfx950 FETCH_SIZE reports half of a coalesced stream (the guide's correction)
-        d["hbm_traffic_bytes_per_launch"] = means["FETCH_SIZE"] * 1024 * 2 + means["WRITE_SIZE"] * 1024
-    if "SQ_INSTS_VALU" in means and "GRBM_GUI_ACTIVE" in means:
-        clk = means["GRBM_GUI_ACTIVE"] / 8 / kns["GRBM_GUI_ACTIVE"]          # GHz: the counter sums over the 8 XCDs
-        d.update({"valu_wave_instructions_per_launch": means["SQ_INSTS_VALU"], "effective_clock_ghz": clk,
-                  "valu_busy_frac": means["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * kns["SQ_INSTS_VALU"] * clk),
-                  "avg_waves_per_simd": means["SQ_WAVE_CYCLES"] * 4 / (1024 * kns["SQ_INSTS_VALU"] * clk)})
-    return d
+    res = {}
+    for k in kernel_names:
+        m, n = means[k], kns[k]
+        if not m:
+            continue
+        d = {"seconds": round(time.time() - t0, 1), "passes": list(LIVE_PASSES)}
+        if k in scratch:
+            d["scratch_bytes_per_lane"] = scratch[k]
+        if "FETCH_SIZE" in m and "WRITE_SIZE" in m:   # KiB; on gfx950 FETCH_SIZE reports half of a coalesced stream (the guide's correction)
+            d["hbm_traffic_bytes_per_launch"] = m["FETCH_SIZE"] * 1024 * 2 + m["WRITE_SIZE"] * 1024
+            d["hbm_write_bytes_per_launch"] = m["WRITE_SIZE"] * 1024
+        if "SQ_INSTS_VALU" in m and "GRBM_GUI_ACTIVE" in m:
+            clk = m["GRBM_GUI_ACTIVE"] / 8 / n["GRBM_GUI_ACTIVE"]          # GHz: the counter sums over the 8 XCDs
+            d.update({"valu_wave_instructions_per_launch": m["SQ_INSTS_VALU"], "effective_clock_ghz": clk,
+                      "valu_busy_frac": m["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * n["SQ_INSTS_VALU"] * clk),
+                      "avg_waves_per_simd": m["SQ_WAVE_CYCLES"] * 4 / (1024 * n["SQ_INSTS_VALU"] * clk)})
+            if "SQ_LDS_IDX_ACTIVE" in m:   # the LDS leg (tools/summarize_profile.py computes the same figures for the committed summaries)
+                d.update({"lds_idx_active_frac_of_cu_cycles": m["SQ_LDS_IDX_ACTIVE"] / (256 * n["SQ_INSTS_VALU"] * clk),
+                          "lds_bank_conflict_frac": m.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(m["SQ_LDS_IDX_ACTIVE"], 1),
+                          "lds_wave_instructions_per_launch": m.get("SQ_INSTS_LDS"), "kernel_ns_in_sq_pass": n["SQ_INSTS_VALU"]})
+        res[k] = d
+    return res
 
 
 def usable_cores():
@@ -165,23 +197,25 @@ def usable_cores():
     return n
 
 
-def verify_against_oracle(res, cur, ref, w, h, sr, lq, bd, what="tables of the timed step"):
+def verify_against_oracle(res, cur, ref, w, h, sr, lq, bd, what="tables of the timed step", pred=None, sample=None):
     """res: int32 [2, n_refs, n_ctu, 593] (TComMv words, SADs) of the last timed step; reference 0 is checked bit-exactly
-    against the oracle's exhaustive search on four CTUs (corner, interior, partial bottom row).  Raises SystemExit on a mismatch."""
+    against the oracle's exhaustive search on a sample of CTUs (default: corner, interior, partial bottom row).  pred: the per-CTU
+    quarter-pel predictors the step searched around.  Raises SystemExit on a mismatch."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
     from hmme import synth
     m = synth.MARGIN
     ctus_x, ctus_y = (w + 63) // 64, (h + 63) // 64
-    sample = sorted({0, ctus_x * (ctus_y // 2) + ctus_x // 3, ctus_x * ctus_y - 1, ctus_x * (ctus_y - 1) + ctus_x // 2})
+    if sample is None:
+        sample = sorted({0, ctus_x * (ctus_y // 2) + ctus_x // 3, ctus_x * ctus_y - 1, ctus_x * (ctus_y - 1) + ctus_x // 2})
     mv = np.ascontiguousarray(res[0, 0]).view(np.int16).reshape(res.shape[2], 593, 2)
     sad = res[1, 0].view(np.uint32)
     t0 = time.time()
     for ctu in sample:
-        ox, oy, osad = O.search_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, bd, ctu, 1, 1)
+        ox, oy, osad = O.search_frame(cur, ref, (m, m), w, h, sr, pred, lq, 1, bd, ctu, 1, 1)
         if not (np.array_equal(mv[ctu, :, 0], ox[0]) and np.array_equal(mv[ctu, :, 1], oy[0]) and np.array_equal(sad[ctu], osad[0])):
             raise SystemExit(f"bench.py: {what} differ from the CPU oracle at CTU {ctu}: nothing reported")
-    return {"ctus": sample, "slots": 593 * len(sample), "against": "oracle exhaustive search (bit-exact)", "seconds": round(time.time() - t0, 2)}
+    return {"ctus": [int(c) for c in sample], "slots": 593 * len(sample), "against": "oracle exhaustive search (bit-exact)", "seconds": round(time.time() - t0, 2)}
 
 
 def cpu_baseline(cur, ref, w, h, sr, lq, bd=8, budget_s=14.0):
@@ -327,9 +361,11 @@ def size_of(args_size):
     return SIZES[args_size] if args_size in SIZES else tuple(int(v) for v in args_size.lower().split("x"))
 
 
-def time_search_config(torch, api, synth, eng, dev, w, h, bd, sr, steps, seed, label):
-    """one other BASELINE configuration on this GPU, timed with HIP events on the launch stream and checked against the oracle;
-    reported beside the headline, never part of `value`"""
+def time_search_config(torch, api, synth, eng, dev, w, h, bd, sr, steps, seed, label, pred=None):
+    """one other configuration on this GPU, timed with HIP events on the launch stream and checked against the oracle;
+    reported beside the headline, never part of `value`.  pred: int16 [n_ctu, 2] quarter-pel predictors -- every CTU's window is
+    centred on its own predictor (xSetSearchRange, TEncSearch.cpp:3814-3830) and the MV cost is priced against it, as the encoder's
+    caller does (TEncSearch.cpp:3732-3737); the job table is then rebuilt by every launch (a table without predictors is cached)"""
     cur, ref, _ = synth.make_pair(w, h, seed=seed, bit_depth=bd)
     m = synth.MARGIN
     pc, pr = eng.plane(w, h, bd), eng.plane(w, h, bd)
@@ -337,30 +373,45 @@ def time_search_config(torch, api, synth, eng, dev, w, h, bd, sr, steps, seed, l
     n_ctu = api.load().hmme_num_ctus(w, h)
     fp = api.FrameParams(sr, 1, bd, 0, n_ctu)
     buf = torch.zeros((2, 1, n_ctu, api.NUM_PARTS), dtype=torch.int32, device=dev)
+    d_pred = torch.from_numpy(np.ascontiguousarray(pred)).to(dev) if pred is not None else None
     stream = torch.cuda.current_stream().cuda_stream
+    warm_clock(eng, (pc, pr), fp, buf, stream)
     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     for i in range(steps + 2):
         if i == 2:
             ev[0].record()
-        eng.search_pairs_device([pc], [pr], fp, None, buf[0].data_ptr(), buf[1].data_ptr(), stream)
+        eng.search_pairs_device([pc], [pr], fp, d_pred.data_ptr() if d_pred is not None else None, buf[0].data_ptr(), buf[1].data_ptr(), stream)
     ev[1].record()
     torch.cuda.synchronize()
     ms = ev[0].elapsed_time(ev[1]) / steps
-    sads = work_4x4_sads(api, w, h, sr)
+    sads = work_4x4_sads(api, w, h, sr, pred)
     algo = algo_bytes_per_ctu(sr, bd) * n_ctu
+    ctus_x, ctus_y = (w + 63) // 64, (h + 63) // 64
+    # with predictors the windows of the picture's edge CTUs are the ones clipMv cuts: two corners, a left-edge, a right-edge, a top and a
+    # (partial) bottom-row CTU and one interior CTU
+    sample = None if pred is None else sorted({0, ctus_x - 1, ctus_x * (ctus_y // 2), ctus_x * (ctus_y // 2 + 1) - 1, ctus_x // 2,
+                                                ctus_x * (ctus_y - 1) + ctus_x // 3, ctus_x * ctus_y - 1, ctus_x * (ctus_y // 3) + ctus_x // 2})
     out = {"workload": label, "steps": steps, "ms_per_step": round(ms, 4), "gsad_per_s": round(sads / (ms * 1e-3) / 1e9, 1),
-           "ctus_per_s": round(n_ctu / (ms * 1e-3), 1), "dtype": "u8" if bd == 8 else "u16",
+           "ctus_per_s": round(n_ctu / (ms * 1e-3), 1), "dtype": "u8" if bd == 8 else "u16", "sads_4x4_per_frame": sads,
            "roofline": {"bound": "hbm", "achieved": round(algo / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": algo},
-           "verified": verify_against_oracle(buf.cpu().numpy(), cur, ref, w, h, sr, eng.lambda_q16, bd, what=f"tables of {label}")}
+           "verified": verify_against_oracle(buf.cpu().numpy(), cur, ref, w, h, sr, eng.lambda_q16, bd, what=f"tables of {label}", pred=pred, sample=sample)}
+    if pred is not None:
+        full = work_4x4_sads(api, w, h, sr)
+        out["predictors"] = {"what": "synth.random_predictors(n_ctu, seed=4242, max_pel=16): seeded quarter-pel AMVP predictors, |component| <= 16 pel (SURVEY 8d)",
+                             "work_vs_zero_predictors": round(sads / full, 4),
+                             "work_is": "the candidates actually searched: each CTU's window after xSetSearchRange + clipMv around its predictor",
+                             "job_table": "rebuilt by every launch (me_prep_jobs_kernel: device-side xSetSearchRange + clipMv); inside the timed region"}
     pc.close(); pr.close()
     return out
 
 
-def time_sequence_config(torch, api, synth, eng, dev):
+def time_sequence_config(torch, api, synth, eng, dev, refine=False):
     """BASELINE config 4 on THIS one GPU: 3840x2160, 64 pictures, the (current, reference) pairs of encoder_randomaccess_main.cfg
     (124 pairs), pictures streamed through a ring of plane slots while the GPU searches (hmme/sequence.py); wall clock around the
-    whole pass, uploads included.  One CTU row of the first and the last pair is checked against the oracle."""
+    whole pass, uploads included.  One CTU row of the first and the last pair is checked against the oracle.  refine: every pair's
+    integer search is followed by the fractional refinement of its 593 x 2 040 winners on the same stream (what HM does per CTU:
+    xMotionEstimation's search, TEncSearch.cpp:3749, then xPatternSearchFracDIF, :3798); refined slots of the same CTUs are checked too."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
     from hmme import sequence, shard
@@ -370,12 +421,13 @@ def time_sequence_config(torch, api, synth, eng, dev):
     res = None
     for _ in range(2):   # the first pass includes allocations
         res = None
-        res = sequence.run_rank(eng, src, pairs, w, h, 8, sr, stream_mode=True, pairs_per_launch=1, device=dev)
+        res = sequence.run_rank(eng, src, pairs, w, h, 8, sr, stream_mode=True, pairs_per_launch=1, device=dev, refine=refine)
     dt = res["seconds"]
     n_ctu = api.load().hmme_num_ctus(w, h)
     ctus_x = (w + 63) // 64
     t0 = time.time()
     checked = []
+    n_refined = 0
     for pi in (0, len(pairs) - 1):
         c, r = pairs[pi]
         first = ctus_x * 17
@@ -385,15 +437,48 @@ def time_sequence_config(torch, api, synth, eng, dev):
         sad = res["sad"][pi, first:first + 8].cpu().numpy().view(np.uint32)
         if not (np.array_equal(mv[:, :, 0], ox) and np.array_equal(mv[:, :, 1], oy) and np.array_equal(sad, osad)):
             raise SystemExit(f"bench.py: config 4 tables of pair {pairs[pi]} differ from the CPU oracle: nothing reported")
+        if refine:
+            n_refined += check_refined_slots(O, src.padded(c), src.padded(r), w, h, 8, mv, res["qmv"][pi, first:first + 8].cpu().numpy(),
+                                             res["cost"][pi, first:first + 8].cpu().numpy().view(np.uint32), range(first, first + 8, 3), eng.lambda_q16,
+                                             f"config 4 with refinement, pair {pairs[pi]}", ctu_base=first)
         checked.append(list(pairs[pi]))
     sads = work_4x4_sads(api, w, h, sr)
-    return {"workload": "3840x2160 8-bit, 64 pictures, encoder_randomaccess_main GOP: 124 (current, reference) pairs, SearchRange=64, "
-                        "streamed through ONE GPU (reader thread -> copy stream || compute stream)",
-            "pairs": len(pairs), "seconds": round(dt, 4), "pairs_per_s": round(len(pairs) / dt, 1),
-            "gsad_per_s": round(len(pairs) * sads / dt / 1e9, 1), "ctus_per_s": round(len(pairs) * n_ctu / dt, 1),
-            "plane_slots": res["plane_slots"], "uploads": res["uploads"], "stages": res["stages"],
-            "verified": {"pairs": checked, "ctus": [ctus_x * 17, 8], "slots": 2 * 8 * 593, "against": "oracle exhaustive search (bit-exact)",
-                         "seconds": round(time.time() - t0, 2)}}
+    out = {"workload": "3840x2160 8-bit, 64 pictures, encoder_randomaccess_main GOP: 124 (current, reference) pairs, SearchRange=64, "
+                       "streamed through ONE GPU (reader thread -> copy stream || compute stream)" +
+                       (", every search followed by the fractional refinement (Hadamard) of its 593 x 2 040 winners" if refine else ""),
+           "pairs": len(pairs), "seconds": round(dt, 4), "pairs_per_s": round(len(pairs) / dt, 1),
+           "gsad_per_s": round(len(pairs) * sads / dt / 1e9, 1), "ctus_per_s": round(len(pairs) * n_ctu / dt, 1),
+           "plane_slots": res["plane_slots"], "uploads": res["uploads"], "stages": res["stages"],
+           "verified": {"pairs": checked, "ctus": [ctus_x * 17, 8], "slots": 2 * 8 * 593, "against": "oracle exhaustive search (bit-exact)",
+                        "seconds": round(time.time() - t0, 2)}}
+    if refine:
+        out["verified"]["refined_slots"] = n_refined
+        out["verified"]["against"] += "; refined slots against the oracle's xPatternSearchFracDIF restatement"
+    return out
+
+
+def check_refined_slots(O, cur, ref, w, h, bd, mv, qmv, cost, ctus, lq, what, ctu_base=0, n_random=20, seed=11):
+    """refined tables (quarter-pel MV, cost) of the CTUs `ctus` against the oracle's xPatternSearchFracDIF restatement, on a seeded sample of
+    slots per CTU plus the largest ones; mv / qmv / cost are indexed by (ctu - ctu_base).  Returns the number of slots checked."""
+    from hmme import synth
+    m = synth.MARGIN
+    table = O.slot_table()
+    ctus_x = (w + 63) // 64
+    rs = np.random.default_rng(seed)
+    n = 0
+    for ctu in ctus:
+        cx, cy = (ctu % ctus_x) * 64, (ctu // ctus_x) * 64
+        k = ctu - ctu_base
+        for s in list(rs.choice(593, size=n_random, replace=False)) + [592, 588, 0]:
+            x, y, bw, bh = (int(v) for v in table[s])
+            if cx + x + bw > w or cy + y + bh > h:
+                continue   # slots beyond the picture edge: defined on the padding, not looked up by HM
+            imv = (int(mv[k, s, 0]), int(mv[k, s, 1]))
+            hx, hy, qx, qy, c = O.frac_refine(cur, (m + cx + x, m + cy + y), ref, (m + cx + x, m + cy + y), bw, bh, imv, (0, 0), lq, 1, bd)
+            if (int(qmv[k, s, 0]), int(qmv[k, s, 1]), int(cost[k, s])) != (4 * imv[0] + 2 * hx + qx, 4 * imv[1] + 2 * hy + qy, c):
+                raise SystemExit(f"bench.py: refinement of CTU {ctu} slot {s} ({what}) differs from the CPU oracle: nothing reported")
+            n += 1
+    return n
 
 
 def time_refine_contents(torch, api, synth, eng, dev, w, h, bd, sr):
@@ -423,15 +508,25 @@ def time_refine_contents(torch, api, synth, eng, dev, w, h, bd, sr):
             ref = synth.pad_plane(rng.integers(0, 1 << bd, size=(h, w)))
         pc, pr = eng.plane(w, h, bd), eng.plane(w, h, bd)
         pc.upload_pel(cur, (m, m)); pr.upload_pel(ref, (m, m))
+        warm_clock(eng, (pc, pr), fp, (d_mv, d_sad), stream)   # the GPU idled through the synthesis of this content
         eng.search_frame_device(pc, pr, fp, None, d_mv.data_ptr(), d_sad.data_ptr(), stream)
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        for i in range(5):
+        for i in range(7):
             if i == 2:
                 ev[0].record()
             eng.refine_frame_multi_device(pc, [pr], fp, None, d_mv.data_ptr(), 1, d_q.data_ptr(), d_c.data_ptr(), stream)
         ev[1].record()
         torch.cuda.synchronize()
-        ms = ev[0].elapsed_time(ev[1]) / 3
+        ms = ev[0].elapsed_time(ev[1]) / 5
+        # what HM does per CTU, per picture pair here: the integer search, then the refinement of its winners, back to back on one stream
+        for i in range(7):
+            if i == 2:
+                ev[0].record()
+            eng.search_frame_device(pc, pr, fp, None, d_mv.data_ptr(), d_sad.data_ptr(), stream)
+            eng.refine_frame_multi_device(pc, [pr], fp, None, d_mv.data_ptr(), 1, d_q.data_ptr(), d_c.data_ptr(), stream)
+        ev[1].record()
+        torch.cuda.synchronize()
+        ms_both = ev[0].elapsed_time(ev[1]) / 5
         # the same pair four times in ONE launch (what a picture with four references asks for): the launch's tail -- it ends one job
         # time after its last job started -- is paid once
         mv4 = d_mv.unsqueeze(0).repeat(4, 1, 1, 1).contiguous()
@@ -446,21 +541,16 @@ def time_refine_contents(torch, api, synth, eng, dev, w, h, bd, sr):
         if not (torch.equal(q4[3], d_q) and torch.equal(c4[3], d_c) and torch.equal(q4[0], d_q)):
             raise SystemExit(f"bench.py: refinement of four pairs in one launch differs from the single launches ({content} content): nothing reported")
         mv, qmv, cost = d_mv.cpu().numpy(), d_q.cpu().numpy(), d_c.cpu().numpy().view(np.uint32)
-        rs = np.random.default_rng(11)
-        n_checked = 0
-        for ctu in (0, ctus_x * 16 + 29, n_ctu - 1):
-            cx, cy = (ctu % ctus_x) * 64, (ctu // ctus_x) * 64
-            for s in list(rs.choice(593, size=20, replace=False)) + [592, 588, 0]:
-                x, y, bw, bh = (int(v) for v in table[s])
-                if cx + x + bw > w or cy + y + bh > h:
-                    continue   # slots beyond the picture edge: defined on the padding, not looked up by HM
-                imv = (int(mv[ctu, s, 0]), int(mv[ctu, s, 1]))
-                hx, hy, qx, qy, c = O.frac_refine(cur, (m + cx + x, m + cy + y), ref, (m + cx + x, m + cy + y), bw, bh, imv, (0, 0), eng.lambda_q16, 1, bd)
-                if (int(qmv[ctu, s, 0]), int(qmv[ctu, s, 1]), int(cost[ctu, s])) != (4 * imv[0] + 2 * hx + qx, 4 * imv[1] + 2 * hy + qy, c):
-                    raise SystemExit(f"bench.py: refinement of CTU {ctu} slot {s} ({content} content) differs from the CPU oracle: nothing reported")
-                n_checked += 1
+        n_checked = check_refined_slots(O, cur, ref, w, h, bd, mv, qmv, cost, (0, ctus_x * 16 + 29, n_ctu - 1), eng.lambda_q16, f"{content} content")
+        # the integer tables the refinement started from are the back-to-back loop's: four CTUs of them against the oracle
+        res = np.stack([d_mv.view(torch.int32).cpu().numpy().reshape(1, n_ctu, api.NUM_PARTS), d_sad.cpu().numpy().reshape(1, n_ctu, api.NUM_PARTS)])
+        v_int = verify_against_oracle(res, cur, ref, w, h, sr, eng.lambda_q16, bd, what=f"integer tables of the search + refinement loop ({content} content)")
         out[content] = {"ms_per_step": round(ms, 4), "slots_per_s": round(n_ctu * api.NUM_PARTS / (ms * 1e-3)), "slots_verified": n_checked,
-                        "ms_per_pair_at_four_pairs_per_launch": round(ms4 / 4, 4)}
+                        "ms_per_pair_at_four_pairs_per_launch": round(ms4 / 4, 4),
+                        "search_plus_refine": {"ms_per_pair": round(ms_both, 4), "pairs_per_s": round(1e3 / ms_both, 1), "ctus_per_s": round(n_ctu / (ms_both * 1e-3), 1),
+                                               "refine_share": round(ms / ms_both, 3),
+                                               "verified": {"integer_ctus": v_int["ctus"], "integer_slots": v_int["slots"], "refined_slots": n_checked,
+                                                            "against": "oracle exhaustive search + oracle xPatternSearchFracDIF restatement (bit-exact)"}}}
         pc.close(); pr.close()
     return out
 
@@ -623,10 +713,11 @@ def main():
         kprof = prof.get("kernels", {}).get(search_kernel, {})
         # counters of THIS run where the profiler is at hand (N = 1, the full default-style run): child rocprofv3 passes of this very
         # command; otherwise the committed summary taken on the library with the same build id
-        live = {}
+        live, live_all = {}, {}
         if world == 1 and n_refs == 1 and not args.no_cpu_baseline and not args.no_live_pmc:
             passthrough = ["--size", args.size, "--search-range", str(sr), "--bit-depth", str(bd)]
-            live = live_pmc(passthrough, search_kernel)
+            live_all = live_pmc(passthrough, [search_kernel, "me_frac_kernel"])
+            live = live_all.get(search_kernel, {})
             if live.get("hbm_traffic_bytes_per_launch") is not None:
                 kprof = dict(kprof, **live)
         same_run = live.get("hbm_traffic_bytes_per_launch") is not None
@@ -688,19 +779,35 @@ def main():
                                               "same build id: %s)" % (profile_label(args.size, sr, bd), library_build_id())}
             if kprof.get("avg_waves_per_simd") is not None:
                 out["valu_roofline"]["avg_waves_per_simd"] = round(kprof["avg_waves_per_simd"], 3)
+            # inside `roofline` as well, so that the parsed block alone says what binds: `bound` / `frac` stay the contract's HBM figure
+            out["roofline"]["binding"] = "valu-issue"
+            out["roofline"]["valu_busy_frac"] = out["valu_roofline"]["valu_busy_frac"]
+            out["roofline"]["frac_of_sad_only_ceiling"] = out["valu_roofline"]["frac_of_sad_only_ceiling"]
+            if kprof.get("lds_idx_active_frac_of_cu_cycles") is not None and kprof.get("lds_wave_instructions_per_launch"):
+                # SURVEY 8d's LDS leg: bytes the kernel's LDS reads deliver per second against the chip's ~150 TB/s (256 CUs x 128 B/clk x
+                # ~2.4 GHz x 2 ports, MI355X_MICROARCH.md).  Nearly every LDS instruction of the kernel is the ds_read2_b32 that feeds one
+                # v_qsad_pk_u16_u8: 8 window bytes per lane
+                lds_bytes = kprof["lds_wave_instructions_per_launch"] * 64 * 8
+                out["roofline"]["lds"] = {"lds_idx_active_frac_of_cu_cycles": round(kprof["lds_idx_active_frac_of_cu_cycles"], 4),
+                                          "lds_bank_conflict_frac": round(kprof.get("lds_bank_conflict_frac", 0.0), 4),
+                                          "lds_wave_instructions_per_launch": int(kprof["lds_wave_instructions_per_launch"]),
+                                          "tb_per_s": round(lds_bytes / (kernel_ms * 1e-3) / 1e12, 2), "peak_tb_per_s": 150.0,
+                                          "frac_of_peak": round(lds_bytes / (kernel_ms * 1e-3) / 1e12 / 150.0, 4)}
         # the step after the path, reported beside the headline, never part of `value`
         d_q = torch.zeros((n_refs, n_ctu, api.NUM_PARTS, 2), dtype=torch.int16, device=dev)
         d_c = torch.zeros((n_refs, n_ctu, api.NUM_PARTS), dtype=torch.int32, device=dev)
         last = pipe.last_local
         d_mv16 = last[0].view(torch.int16).contiguous()   # TComMv words -> int16 (x, y) pairs
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        for i in range(4):
-            if i == 1:
+        scratch_tables = torch.zeros((2, n_ctu, api.NUM_PARTS), dtype=torch.int32, device=dev)
+        warm_clock(eng, (pc, pr), fp, scratch_tables, stream, launches=12)   # this process left the GPU to the counter passes above
+        for i in range(7):
+            if i == 2:
                 ev[0].record()
             eng.refine_pairs_device(cur_planes, ref_planes, fp, None, d_mv16.data_ptr(), 1, d_q.data_ptr(), d_c.data_ptr(), stream)
         ev[1].record()
         torch.cuda.synchronize()
-        r_ms = ev[0].elapsed_time(ev[1]) / 3
+        r_ms = ev[0].elapsed_time(ev[1]) / 5
         out["refine"] = {"what": "xPatternSearchFracDIF (half + quarter-pel, Hadamard) for all 593 slots of every CTU, on the integer winners",
                          "kernel": "me_frac_kernel<1, %d>" % (1 if bd == 8 else 2), "ms_per_step": round(r_ms, 4),
                          "slots_per_s": round(n_ctu * n_refs * api.NUM_PARTS / (r_ms * 1e-3)),
@@ -730,10 +837,20 @@ def main():
                                                  "ctus_per_s": round(4 * n_ctu / (ms4 * 1e-3), 1)}
             for pl in refs4[1:]:
                 pl.close()
-        fprof = prof.get("kernels", {}).get("me_frac_kernel", {})
-        if fprof.get("hbm_traffic_bytes_per_launch") is not None:
+        fprof = live_all.get("me_frac_kernel") or prof.get("kernels", {}).get("me_frac_kernel", {})
+        if fprof.get("hbm_traffic_bytes_per_launch") is not None:   # counters of the refinement launches of the same child runs as the search kernel's
+            out["refine"]["counters_same_run"] = "me_frac_kernel" in live_all
             out["refine"]["hbm_traffic_bytes_per_launch"] = int(fprof["hbm_traffic_bytes_per_launch"])
+            if fprof.get("hbm_write_bytes_per_launch") is not None:
+                out["refine"]["hbm_write_bytes_per_launch"] = int(fprof["hbm_write_bytes_per_launch"])
+                out["refine"]["result_bytes_per_launch"] = n_ctu * n_refs * api.NUM_PARTS * 8
+            if fprof.get("scratch_bytes_per_lane") is not None:
+                out["refine"]["scratch_bytes_per_lane"] = int(fprof["scratch_bytes_per_lane"])
             out["refine"]["valu_busy_frac"] = round(fprof.get("valu_busy_frac", 0.0), 4)
+            if fprof.get("avg_waves_per_simd") is not None:
+                out["refine"]["avg_waves_per_simd"] = round(fprof["avg_waves_per_simd"], 3)
+            if fprof.get("lds_bank_conflict_frac") is not None:
+                out["refine"]["lds_bank_conflict_frac"] = round(fprof["lds_bank_conflict_frac"], 4)
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only: the other ranks would wait on it
             # what was timed is what is reported: tables of the LAST timed step against the CPU oracle on a CTU sample
             # (corner, interior, partial bottom row); a mismatch fails the run
@@ -749,9 +866,19 @@ def main():
                                                          "1920x1080 8-bit, SearchRange=64 (BASELINE config 2), one reference per launch"),
                 "config5_2160p_10bit_sr128": time_search_config(torch, api, synth, eng, dev, 3840, 2160, 10, 128, 5, 1234,
                                                                 "3840x2160 10-bit, SearchRange=128, packed-u16 SAD path (BASELINE config 5)"),
+                # SURVEY 8d's second measurement: the headline workload with every CTU's window centred on a seeded predictor of up
+                # to +-16 pel, as the encoder's caller centres it on the AMVP predictor
+                "with_random_predictors": time_search_config(torch, api, synth, eng, dev, 3840, 2160, 8, 64, 10, 1234,
+                                                             "3840x2160 8-bit, SearchRange=64, per-CTU random predictors <= +-16 pel (SURVEY 8d)",
+                                                             pred=synth.random_predictors(n_ctu, seed=4242, max_pel=16)),
                 "config4_2160p_randomaccess_64_pictures_one_gpu": time_sequence_config(torch, api, synth, eng, dev),
+                "config4_with_refinement": time_sequence_config(torch, api, synth, eng, dev, refine=True),
             }
             out["configs"]["seconds"] = round(time.time() - t_x, 1)
+            # the end-to-end figure an encoder integrator needs: integer search + fractional refinement of a 2160p pair, per content
+            out["search_plus_refine"] = {"what": "hmme_search_frame_device then hmme_refine_frame_multi_device (Hadamard) of the same 2160p pair, back to back on one stream "
+                                                 "(TEncSearch.cpp:3749 then :3798 for every PU of every CTU)",
+                                         "by_content": {k: v["search_plus_refine"] for k, v in out["refine"]["by_content"].items()}}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cur, ref, w, h, sr, lq, bd)
         print(json.dumps(out), flush=True)

@@ -41,6 +41,9 @@ constexpr int kGroups = 10;
 #ifndef ME_GUIDED_TASKS
 #define ME_GUIDED_TASKS 1
 #endif
+#ifndef ME_FRAC_PRIO   // A/B: 0 = the refinement kernel's waves all at the dispatch priority
+#define ME_FRAC_PRIO 1
+#endif
 #ifndef ME_FAIR_PRIO   // A/B: 0 = every wave at the dispatch priority (the SIMD then favours its oldest wave)
 #define ME_FAIR_PRIO 1
 #endif
@@ -1696,6 +1699,14 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
 
   const int tid = threadIdx.x;
   const int bd = BPS == 1 ? 8 : bit_depth;
+#if ME_FRAC_PRIO
+  // The short phases of a job -- set-up, work lists, winners: chains of dependent LDS round trips and compares, a few hundred
+  // instructions -- run at wave priority 3, the items (thousands of VALU instructions per lane, no waiting) at 0.  A SIMD issues from its
+  // oldest ready wave: next to another workgroup's items a short phase got the issue slots those left over and took five times its
+  // stand-alone time, half of a job on content whose slots share their motion.  With the priorities the short phases run at their own
+  // latency and the items fill every slot they leave, which is nearly all of them.
+  __builtin_amdgcn_s_setprio(3);
+#endif
   // tables that do not depend on the job
   static_assert(9 * (kFracTabH + kFracTabV) <= 152, "me_frac_kernel: the tap tables end where the list counters start");
   if (tid < 9 * kFracTabH) tab_h[tid] = (tid & 7) < 2 * BPS ? me_htap8_dw<BPS>((tid >> 3) / 3, (tid >> 3) % 3, tid & 7) : 0u;
@@ -1728,6 +1739,7 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
   if (jb >= n_jobs || jb < 0) break;
 #ifdef ME_FRAC_T_TIMELINE   // timing-only build: when does each job start and end (100 MHz wall clock), in which workgroup, and its phases
   const unsigned long long t_job0 = wall_clock64();
+  const unsigned long long c_job0 = clock64();   // shader clock: cycles / wall time = the clock the job ran at
   unsigned long long t_ph[7];   // set-up | per stage: lists, items, winners
   int n_ph = 0;
 #define ME_FRAC_STAMP() t_ph[n_ph++] = wall_clock64()
@@ -1802,8 +1814,14 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
     ME_FRAC_STAMP();
     const int n8 = 4 * (int)counter[0], n4 = (int)counter[1];
 #ifndef ME_FRAC_T_NOITEMS
+#if ME_FRAC_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if (stage == 0) me_frac_stage_items<0, HAD, BPS, WP>(src, ref_pitch, curl, st, cover, list8, n8, list4, n4, tid, bd, clip_lo, wp, tab_h, tab_v, acc);
     else me_frac_stage_items<1, HAD, BPS, WP>(src, ref_pitch, curl, st, cover, list8, n8, list4, n4, tid, bd, clip_lo, wp, tab_h, tab_v, acc);
+#if ME_FRAC_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
 #endif
     __syncthreads();
     ME_FRAC_STAMP();
@@ -1848,6 +1866,7 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
     uint32_t* o = out_cost + (long)jb * kParts;
     o[0] = (uint32_t)t_job0; o[1] = (uint32_t)(t_job0 >> 32); o[2] = (uint32_t)t1; o[3] = (uint32_t)(t1 >> 32); o[4] = blockIdx.x;
     for (int i = 0; i < 7; ++i) o[5 + i] = (uint32_t)(t_ph[i] - (i ? t_ph[i - 1] : t_job0));   // phase durations, 10 ns units
+    o[12] = (uint32_t)(clock64() - c_job0);
   }
   __syncthreads();
 #endif
