@@ -139,6 +139,7 @@ struct hmme_ctx {
   int* d_flag = nullptr;
   bool lds_optin[8] = {false, false, false, false, false, false, false, false};
   int num_cus = 0;
+  bool frac_lds_optin[3][2] = {{false, false}, {false, false}, {false, false}};   // [8-bit | u16 | u16 weighted][hadamard]
   int frac_wg_per_cu[2][2] = {{0, 0}, {0, 0}};   // [wide][hadamard] workgroups of me_frac_kernel a CU holds (runtime occupancy query, first use)
   uint8_t* d_wwin = nullptr;          // per-CTU calls with weighted prediction: the weighted copy of the staged window (the search's)
   uint16_t* d_frac_cover = nullptr;   // fractional refinement: slots covering each 8x8 / 4x4 position, same for every CTU
@@ -645,19 +646,26 @@ int hmme_slot_rect(int slot, int* x, int* y, int* w, int* h) {
 namespace {
 int build_frac_cover(hmme_ctx* ctx);
 using frac_fn = void (*)(const RefSet, int, const RefSet, int, const MeJob*, const hmme::FracPrep, int, uint32_t*, const uint16_t*, const int16_t*, uint32_t, int, const hmme::FracWp, int16_t*, uint32_t*);
-// few: the launch is at most two rounds of two workgroups per CU (jobs <= 4 x CUs: a per-CTU call, picture pairs up to 2560x1440) --
-// the 8-bit kernel then runs in its two-wave build, which keeps everything in registers; launches with more jobs take the three-wave
-// build, whose jobs take 1.27 x as long but come three to a CU (me_frac_kernel's header; profiles/r04w2_frac_waves_by_launch_size.txt)
-inline bool frac_three_waves(int wide, int wp, bool few) {
-  static const int force = std::getenv("HMME_FRAC_WAVES") ? std::atoi(std::getenv("HMME_FRAC_WAVES")) : 0;   // A/B: 2 or 3 whatever the job count
-  return !wide && !wp && force != 2 && (force == 3 || !few);
-}
-inline frac_fn frac_kernel(int wide, int had, int wp = 0, bool few = false) {
+// The 8-bit kernel runs at two waves per SIMD (249..256 VGPRs, no scratch) and two workgroups per CU: each workgroup's LDS block holds
+// the patch rows of every lane's next item (LDS-DMA, me_frac_stage).  Round 4's three-wave build (168 VGPRs + 50 spilled dwords per
+// lane: 104 MB of scratch writes per 2160p launch) is gone.
+inline frac_fn frac_kernel(int wide, int had, int wp = 0) {
   static const frac_fn fns[2][2] = {{hmme::me_frac_kernel<0, 1, 0, 2>, hmme::me_frac_kernel<1, 1, 0, 2>}, {hmme::me_frac_kernel<0, 2, 0>, hmme::me_frac_kernel<1, 2, 0>}};
-  static const frac_fn fns_many8[2] = {hmme::me_frac_kernel<0, 1, 0, 3>, hmme::me_frac_kernel<1, 1, 0, 3>};
   static const frac_fn fns_wp[2] = {hmme::me_frac_kernel<0, 2, 1>, hmme::me_frac_kernel<1, 2, 1>};   // weighted calls always stage u16 samples
   if (wp) return fns_wp[had ? 1 : 0];
-  return frac_three_waves(wide, wp, few) ? fns_many8[had ? 1 : 0] : fns[wide ? 1 : 0][had ? 1 : 0];
+  return fns[wide ? 1 : 0][had ? 1 : 0];
+}
+// more than 64 KiB of dynamic LDS: opt in once per kernel and context
+int frac_lds_optin(hmme_ctx* ctx, int wide, int had, int wp) {
+  bool& done = ctx->frac_lds_optin[wp ? 2 : (wide ? 1 : 0)][had ? 1 : 0];
+  if (done) return HMME_OK;
+  const size_t bytes = hmme::frac_lds_bytes(wide ? 2 : 1);
+  if (bytes > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute((const void*)frac_kernel(wide, had, wp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return fail(ctx, HMME_ERR_DEVICE, "hipFuncSetAttribute(me_frac_kernel, %zu bytes of LDS) -> %s", bytes, hipGetErrorString(e));
+  }
+  done = true;
+  return HMME_OK;
 }
 const hmme::FracWp kNoWp = {0.f, 0.f, 0.f};
 const hmme::FracPrep kNoPrep = {nullptr, 1u << 16, 0, 0};
@@ -874,7 +882,9 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
     const int16_t* d_imv = do_search ? d_mv1 : (const int16_t*)(ctx->d_call + kCallImv);
     // weighted: the interpolated prediction is weighted sample by sample (me_frac_eval0 / me_frac_eval1, FracWp); the current samples carry `bias`, the raw window none
     const hmme::FracWp fw = wp ? hmme::FracWp{std::ldexp((float)wp->w0, -wp->shift), std::ldexp((float)wp->round, -wp->shift), (float)(bias + wp->offset)} : kNoWp;
-    hipLaunchKernelGGL(frac_kernel(wide ? 1 : 0, refine_had ? 1 : 0, wp ? 1 : 0, true), dim3(1), dim3(hmme::frac_threads(bps)), hmme::frac_lds_bytes(bps), s, one_ref(ctx->d_call + kCallCtu),
+    rc = frac_lds_optin(ctx, wide ? 1 : 0, refine_had ? 1 : 0, wp ? 1 : 0);
+    if (rc) return rc;
+    hipLaunchKernelGGL(frac_kernel(wide ? 1 : 0, refine_had ? 1 : 0, wp ? 1 : 0), dim3(1), dim3(hmme::frac_threads(bps)), hmme::frac_lds_bytes(bps), s, one_ref(ctx->d_call + kCallCtu),
                        64 * bps, one_ref(ref_base), kWinPitch, (const MeJob*)(ctx->d_call + kCallFracJob), kNoPrep, 1, (uint32_t*)nullptr, ctx->d_frac_cover, d_imv, ctx->lambda_q16,
                        p->bit_depth | ((bipred_origin && !wp) ? 0x100 : 0), fw, (int16_t*)(ctx->d_res + kResQmv), (uint32_t*)(ctx->d_res + kResCost));
     HIP_TRY(ctx, hipGetLastError());
@@ -1340,9 +1350,9 @@ int hmme_refine_pairs_device(hmme_ctx* ctx, const hmme_plane* const* curs, const
     // job-walking launch of HMME_FRAC_GRID: its prep kernel is also what resets the job counter
     const hmme::FracPrep prep = {(const int16_t*)d_pred_q, (uint32_t)pl.first | (uint32_t)pl.count << 16, (uint32_t)curs[0]->width | (uint32_t)curs[0]->height << 16, fp->search_range};
     static const bool table = std::getenv("HMME_FRAC_JOB_TABLE") != nullptr;   // A/B: the job table and its kernel as before
-    const bool walk = grid < jobs, few = jobs <= 4 * ctx->num_cus;
+    const bool walk = grid < jobs;
     const bool packable = pl.count <= 0xffff && pl.first <= 0xffff;   // FracPrep packs the CTU range into 16 + 16 bits (a 16384 x 16384 picture has 65 536 CTUs)
-    const bool need_table = walk || table || !packable || frac_three_waves(wide, 0, few);
+    const bool need_table = walk || table || !packable;
     static const bool no_cache = std::getenv("HMME_NO_TABLE_CACHE") != nullptr;
     hmme_ctx::TableTag tag;
     tag.valid = !d_pred_q && !no_cache && !walk;   // (the job-walking mode's prep kernel also resets the job counter: every launch)
@@ -1353,7 +1363,9 @@ int hmme_refine_pairs_device(hmme_ctx* ctx, const hmme_plane* const* curs, const
     if (need_table && !have_table)
       hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, dim3((jobs + 255) / 256), dim3(256), 0, s, (MeJob*)ctx->d_frac_jobs, (const int16_t*)d_pred_q,
                          pl.first, pl.count, n_pairs, curs[0]->width, curs[0]->height, fp->search_range, 0, jobs, 0, counter);
-    hipLaunchKernelGGL(frac_kernel(wide, had, 0, few), dim3(grid), dim3(hmme::frac_threads(wide ? 2 : 1)), hmme::frac_lds_bytes(wide ? 2 : 1), s, pl.curs,
+    rc = frac_lds_optin(ctx, wide, had, 0);
+    if (rc != HMME_OK) return pairs_end(ctx, curs, refs, n_pairs, s, rc);
+    hipLaunchKernelGGL(frac_kernel(wide, had, 0), dim3(grid), dim3(hmme::frac_threads(wide ? 2 : 1)), hmme::frac_lds_bytes(wide ? 2 : 1), s, pl.curs,
                        curs[0]->pitch, pl.refs, refs[0]->pitch, need_table ? (const MeJob*)ctx->d_frac_jobs : (const MeJob*)nullptr, prep, jobs, walk ? counter : (uint32_t*)nullptr, ctx->d_frac_cover,
                        (const int16_t*)d_int_mv, ctx->lambda_q16,
                        fp->bit_depth, kNoWp, (int16_t*)d_out_qmv, (uint32_t*)d_out_cost);

@@ -980,14 +980,32 @@ __global__ void me_prep_jobs_tile_kernel(MeJob16* jobs, int* first_strip_of_job,
 // (8x8 Hadamard blocks) and the others (4x4 blocks) run the same code.  Per-slot distortions accumulate in LDS (ds_add_u32); 593
 // threads then add the MV cost and pick the winner in HM's point order (strict '<', tables TEncSearch.cpp:51-75).
 // per-slot distortion sums of the nine refinement points
-constexpr int kFracAccRow = 9, kFracAcc = 593 * kFracAccRow, kFracAccDw = (kFracAcc + 15) & ~15;
 // BPS = bytes per sample of the planes (1: 8-bit video, 2: 9..12 bit)
+// 8-bit planes: the nine sums of a slot are three 64-bit words of three 21-bit fields each (points 3k, 3k + 1, 3k + 2 of word k), added
+// with ds_add_u64 -- a third of the LDS atomics, which on content whose slots share their motion were 40 % of an item's time (up to sixteen
+// lanes of a wave add to the same large slot: profiles/r05g_frac_phases.txt).  A field never carries into the next: the largest sum is the
+// 64x64 slot's, 64 8x8 Hadamard blocks of at most 8 * 64 * 255 / 4 = 32 640 each (Parseval) = 2 088 960 < 2^21; SAD 64 * 64 * 255.
+// Wider samples (and the biased ones of bi-prediction origins) keep nine 32-bit sums.
+#ifndef ME_FRAC_PACK3
+#define ME_FRAC_PACK3 1
+#endif
+constexpr bool frac_pack3(int bps) { return ME_FRAC_PACK3 && bps == 1; }
+constexpr int frac_acc_row(int bps) { return frac_pack3(bps) ? 6 : 9; }   // dwords per slot
+constexpr int frac_acc_dw(int bps) { return (593 * frac_acc_row(bps) + 15) & ~15; }
+static_assert(64 * 32640 < (1 << 21) && 4096 * 255 < (1 << 21), "me_frac_kernel: a packed sum field holds the largest 8-bit slot sum");
 constexpr int frac_threads(int bps) { return 256; }
 // sums [593][9] | slot states | tap tables, counters | the two work lists | current block | cover table (uint16 [64][18] + [256][6])
 #ifndef ME_FRAC_T_LDS_PAD   // timing-only: LDS bytes a workgroup asks for beyond its need (56 KiB in all = two workgroups per CU with the three-wave register budget)
 #define ME_FRAC_T_LDS_PAD 0
 #endif
-constexpr size_t frac_lds_bytes(int bps) { return (size_t)(kFracAccDw + 600 + 160 + (64 * 18 + 256 * 6) / 2 + 1024 * bps + (64 * 18 + 256 * 6) / 2) * 4 + ME_FRAC_T_LDS_PAD; }
+// 8-bit planes: + the patch rows of each lane's NEXT item, written by LDS-DMA while the current item is evaluated (me_frac_stage):
+// 12 rows x 16 B x 256 lanes = 48 KiB.  80 KiB a workgroup, two workgroups a CU -- which is what the kernel's registers allow anyway
+#ifndef ME_FRAC_GLDS   // measured: no faster than plain loads on any content (profiles/r05j_frac_glds_ab.txt) -- the items do not wait for their rows
+#define ME_FRAC_GLDS 0
+#endif
+constexpr bool frac_glds(int bps) { return ME_FRAC_GLDS && bps == 1; }
+constexpr int frac_pf_dw(int bps) { return frac_glds(bps) ? 12 * 4 * 256 : 0; }
+constexpr size_t frac_lds_bytes(int bps) { return (size_t)(frac_acc_dw(bps) + 600 + 160 + (64 * 18 + 256 * 6) / 2 + 1024 * bps + (64 * 18 + 256 * 6) / 2 + frac_pf_dw(bps)) * 4 + ME_FRAC_T_LDS_PAD; }
 
 __device__ __forceinline__ uint32_t me_mv_cost_q(uint32_t lambda_q16, int vx_q, int vy_q, int pred_x, int pred_y) {
   return (lambda_q16 * (me_component_bits(vx_q - pred_x) + me_component_bits(vy_q - pred_y))) >> 16;
@@ -1498,6 +1516,49 @@ struct FracRaw {
   uint32_t o;       // byte offset of the patch inside its first dword
 };
 
+// LDS-DMA form of me_frac_fetch (8-bit planes): the rows of the item go from the plane straight into the wave's LDS block
+// (global_load_lds_dwordx4: lane l's 16 bytes of row r land at block + r * 1 KiB + l * 16), no register holds them while they travel.
+// Returns what me_frac_take needs beside the rows: the item's state word and the byte offset of the patch inside its first dword.
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+template <int STAGE, int KIND8>
+__device__ __forceinline__ uint32_t me_frac_prefetch(const uint8_t* __restrict__ src, int gpitch, const uint32_t* st, const uint16_t* cover, int pair, int role,
+                                                     uint32_t* pf_wave) {
+  constexpr int NCOV = KIND8 ? kFracCover8 : kFracCover4;
+  const int q = KIND8 ? pair : pair - kFracPairs8;
+  const int pos = q / NCOV;
+  const uint32_t sv = st[cover[pair]];
+  const int bx = KIND8 ? 2 * (pos & 7) + (role & 1) : (pos & 15), by = KIND8 ? 2 * (pos >> 3) + (role >> 1) : (pos >> 4);
+  const int skip_x = STAGE ? 4 + me_win8_first((int)((sv >> 18) & 3)) : 0, skip_y = STAGE ? 4 + me_win8_first((int)((sv >> 20) & 3)) : 0;
+  const int prow = by * 4 + (int)((sv >> 9) & 0x1ff) + skip_y, pcol = bx * 4 + (int)(sv & 0x1ff) + skip_x;
+  const uint8_t* a = src + (long)prow * gpitch + pcol;
+  const uint32_t o = (uint32_t)(uintptr_t)a & 3u;
+  const uint8_t* rowp = a - o;
+  constexpr int ROWS = STAGE ? kFracRows1 : 12;
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+    __builtin_amdgcn_global_load_lds((const void*)(rowp + (long)r * gpitch), (lds_u32_t*)(pf_wave + r * 256), 16, 0, 0);
+  return (sv & kFracKey1) | o << 30;
+}
+// the rows of the item me_frac_prefetch asked for, out of the wave's LDS block into registers; returns once they are THERE, so the block
+// may be overwritten by the next request
+template <int STAGE>
+__device__ __forceinline__ void me_frac_take(const uint32_t* pf_wave, int lane, uint32_t meta, FracRaw<1>& R) {
+  constexpr int ROWS = STAGE ? kFracRows1 : 12;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA completion is counted with the vector-memory operations
+#pragma unroll
+  for (int r = 0; r < 12; ++r) {
+    if (r < ROWS) {
+      const uint4 v = *(const uint4*)(pf_wave + r * 256 + lane * 4);
+      R.w[r][0] = v.x; R.w[r][1] = v.y; R.w[r][2] = v.z; R.w[r][3] = v.w;
+    } else {
+      R.w[r][0] = R.w[r][1] = R.w[r][2] = R.w[r][3] = 0u;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  R.sv = meta & kFracKey1;
+  R.o = meta >> 30;
+}
+
 template <int STAGE, int BPS, int KIND8>
 __device__ __forceinline__ void me_frac_fetch(const uint8_t* __restrict__ src, int gpitch, const uint32_t* st, const uint16_t* cover, int pair, int role,
                                               FracRaw<BPS>& R) {
@@ -1571,14 +1632,29 @@ __device__ __forceinline__ void me_frac_compute(const FracRaw<BPS>& R, const uin
     me_frac_eval1<HAD, BPS, KIND8, WP>(P, orgM, (int)((sv >> 18) & 3), (int)((sv >> 20) & 3), role, bd, clip_lo, tab_h, tab_v, want4, wp, dist, dist4);
   }
 #ifndef ME_FRAC_T_NOATOMICS   // timing-only builds (tools/r04_frac_breakdown.sh; results are wrong by design): ME_FRAC_T_NOATOMICS, ME_FRAC_T_NOITEMS
+  // the nine (stage 1: eight, point 0 is carried over, not evaluated -- its distortion here is 0) distortions as they are added to a slot
+  unsigned long long pk[3], pk4[3];
+  if constexpr (frac_pack3(BPS)) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      pk[k] = (unsigned long long)(dist[3 * k] | dist[3 * k + 1] << 21) | (unsigned long long)(dist[3 * k + 1] >> 11 | dist[3 * k + 2] << 10) << 32;
+      pk4[k] = (unsigned long long)(dist4[3 * k] | dist4[3 * k + 1] << 21) | (unsigned long long)(dist4[3 * k + 1] >> 11 | dist4[3 * k + 2] << 10) << 32;
+    }
+  }
+  auto add_to = [&](int slot, const uint32_t (&d)[9], const unsigned long long (&p)[3]) {
+    if constexpr (frac_pack3(BPS)) {
+      unsigned long long* a = (unsigned long long*)acc + slot * 3;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) atomicAdd(&a[k], p[k]);
+    } else {
+#pragma unroll
+      for (int i = STAGE; i < 9; ++i) atomicAdd(&acc[slot * 9 + i], d[i]);
+    }
+  };
   if (KIND8 && want4) {
 #pragma unroll
     for (int k = 0; k < kFracCover4; ++k)
-      if (match4 >> k & 1) {
-        const int s4 = cov4[k];
-#pragma unroll
-        for (int i = STAGE; i < 9; ++i) atomicAdd(&acc[s4 * kFracAccRow + i], dist4[i]);
-      }
+      if (match4 >> k & 1) add_to(cov4[k], dist4, pk4);
   }
   // Every slot of this position with the same key takes the distortions; the quad's lanes split the slot list.
   // (Round 3 tried to relieve these adds -- the large slots cover many positions, so lanes of one wave often add to the same address:
@@ -1586,57 +1662,36 @@ __device__ __forceinline__ void me_frac_compute(const FracRaw<BPS>& R, const uin
   // and its LDS waits by 90 %, and changed its time by -2 % .. +3 %: LDS is busy 10 % of the CU cycles here.  profiles/archive/r03d_frac_ab.txt)
   for (int j2 = j + (KIND8 ? role : 0); j2 < NCOV; j2 += KIND8 ? 4 : 1) {
     const int s2 = cov[j2];
-    if (j2 == j || ((st[s2] ^ sv) & keymask) == 0) {
-#pragma unroll
-      for (int i = STAGE; i < 9; ++i) atomicAdd(&acc[s2 * kFracAccRow + i], dist[i]);   // stage 1: point 0 is carried over, not evaluated
-    }
+    if (j2 == j || ((st[s2] ^ sv) & keymask) == 0) add_to(s2, dist, pk);
   }
 #else   // every distortion still computed, ONE atomic per item: the difference to the product build is what the accumulation costs
   {
     uint32_t t = 0;
 #pragma unroll
     for (int i = 0; i < 9; ++i) t += dist[i] + (KIND8 ? dist4[i] & match4 : 0u);
-    atomicAdd(&acc[(cov[j] * kFracAccRow + (t & 7)) % kFracAcc], t);
+    atomicAdd(&acc[(cov[j] * frac_acc_row(BPS) + (t & 3)) % (593 * frac_acc_row(BPS))], t);
   }
 #endif
 }
 
-// a lane's items of one stage: kind-8 items (whole quads: n8 and the thread count are multiples of 4), then kind-4 items.  (Round 4 also
-// built this walk software-pipelined -- the next item's 12 patch rows requested before the current item is evaluated, at 2 waves per
-// SIMD and 255 VGPRs without spills, as VERDICT r3 proposed: slower on every content, profiles/r04a_frac_pipelined_vs_plain_ab.txt.)
-template <int STAGE, int HAD, int BPS, int WP>
-__device__ __forceinline__ void me_frac_stage_items(const uint8_t* __restrict__ src, int gpitch, const uint32_t* curl, const uint32_t* st, const uint16_t* cover,
-                                                    const uint16_t* list8, int n8, const uint16_t* list4, int n4, int tid, int bd, float clip_lo,
-                                                    const FracWp wp, const uint32_t* tab_h, const float* tab_v, uint32_t* acc) {
-  constexpr int NT = frac_threads(BPS);
-  const int role = tid & 3;
-  FracRaw<BPS> R;
-#pragma unroll 1
-  for (int i8 = tid; i8 < n8; i8 += NT) {
-    const int pair = list8[i8 >> 2];
-    me_frac_fetch<STAGE, BPS, 1>(src, gpitch, st, cover, pair, role, R);
-    me_frac_compute<STAGE, HAD, BPS, 1, WP>(R, curl, st, cover, pair, role, bd, clip_lo, wp, tab_h, tab_v, acc);
-  }
-#pragma unroll 1
-  for (int i4 = tid; i4 < n4; i4 += NT) {
-    const int pair = list4[i4];
-    me_frac_fetch<STAGE, BPS, 0>(src, gpitch, st, cover, pair, 0, R);
-    me_frac_compute<STAGE, HAD, BPS, 0, WP>(R, curl, st, cover, pair, 0, bd, clip_lo, wp, tab_h, tab_v, acc);
-  }
-}
-
 // distinct (position, key) pairs of one stage -> work lists; the first slot (lowest index in the cover list) with a given key is the one
-// evaluated.  PARTS waves share a position's list: part PART decides entries PART, PART + PARTS, ... (an 8x8 position's 18 entries are
+// evaluated.  Entry 0 of a position's list -- its 8x8 slot -- is always a first: it is the position's IMPLICIT item (me_frac_stage) and never
+// listed.  PARTS waves share a position's list: part PART decides entries PART, PART + PARTS, ... (an 8x8 position's 18 entries are
 // 153 compares: one wave per part -- the part is wave-uniform, so each wave runs only its own 32..45 compares -- keeps the four
-// waves of the workgroup equally busy; with one thread per position wave 0 did all 64 positions while the others waited at the barrier)
+// waves of the workgroup equally busy).  A wave whose 64 positions each have ONE key (slots that share their motion: most of a real
+// picture) has nothing to list and skips the compares.
 template <int NCOV, int PARTS, int PART>
 __device__ __forceinline__ void me_frac_dedupe(const uint32_t* st, const uint16_t* cov, uint32_t keymask, int pair0,
                                                uint32_t* counter, uint16_t* list) {
   uint32_t key[NCOV];
 #pragma unroll
   for (int j = 0; j < NCOV; ++j) key[j] = st[cov[j]] & keymask;
+  uint32_t differ = 0;
 #pragma unroll
-  for (int j = PART; j < NCOV; j += PARTS) {
+  for (int j = 1; j < NCOV; ++j) differ |= key[j] ^ key[0];
+  if (__all(differ == 0)) return;
+#pragma unroll
+  for (int j = PART ? PART : PARTS; j < NCOV; j += PARTS) {
     bool first = true;
 #pragma unroll
     for (int k = 0; k < j; ++k) first = first && key[k] != key[j];
@@ -1651,15 +1706,22 @@ __device__ __forceinline__ void me_frac_dedupe4(const uint32_t* st, const uint16
   const uint16_t* cov8 = cover + (((p4 >> 4) >> 1) * 8 + ((p4 & 15) >> 1)) * kFracCover8;   // the 8x8 position that holds block (p4 & 15, p4 >> 4)
   uint32_t key[kFracCover4];
   bool first[kFracCover4];
+  const uint32_t k80 = st[cov8[0]] & keymask;
+  uint32_t differ = 0;
 #pragma unroll
   for (int j = 0; j < kFracCover4; ++j) {
     key[j] = st[cov[j]] & keymask;
-    first[j] = true;
+    differ |= key[j] ^ k80;
+  }
+  if (__all(differ == 0)) return;   // every 4x4-kind slot of the wave's positions rides on its position's implicit 8x8 item
+#pragma unroll
+  for (int j = 0; j < kFracCover4; ++j) {
+    first[j] = key[j] != k80;
 #pragma unroll
     for (int k = 0; k < j; ++k) first[j] = first[j] && key[k] != key[j];
   }
 #pragma unroll
-  for (int k = 0; k < kFracCover8; ++k) {
+  for (int k = 1; k < kFracCover8; ++k) {
     const uint32_t k8 = st[cov8[k]] & keymask;
 #pragma unroll
     for (int j = 0; j < kFracCover4; ++j) first[j] = first[j] && key[j] != k8;
@@ -1667,6 +1729,154 @@ __device__ __forceinline__ void me_frac_dedupe4(const uint32_t* st, const uint16
 #pragma unroll
   for (int j = 0; j < kFracCover4; ++j)
     if (first[j]) list[atomicAdd(counter, 1u)] = (uint16_t)(kFracPairs8 + p4 * kFracCover4 + j);
+}
+
+// One stage's items.  Every 8x8 position has an item that needs no list: entry 0 of its cover list (the 8x8 slot itself) with that slot's
+// key -- 64 positions x 4 quadrants = one item for each of the 256 lanes.  A lane requests that item's patch rows FIRST, builds its share
+// of the work lists (the remaining distinct (position, key) pairs) while the rows are on their way, evaluates the item, and only then meets
+// the other waves at the barrier that completes the lists.  On content whose slots share their motion the lists stay empty and a stage is
+// one item per lane; the list phase used to be a barrier-separated 2.5 .. 3.5 us of dependent LDS round trips in front of every stage's
+// items (profiles/r05g_frac_phases.txt).  The listed items follow: kind-8 items (whole quads), then kind-4 items.  (Round 4 built the walk
+// over the listed items software-pipelined -- the next item's rows requested before the current item is evaluated -- slower on every content,
+// profiles/r04a_frac_pipelined_vs_plain_ab.txt.)
+template <int STAGE, int HAD, int BPS, int WP>
+__device__ __forceinline__ void me_frac_stage(const uint8_t* __restrict__ src, int gpitch, const uint32_t* curl, const uint32_t* st, const uint16_t* cover,
+                                              uint16_t* list8, uint16_t* list4, uint32_t* counter, uint32_t* pf, int tid, int bd, float clip_lo,
+                                              const FracWp wp, const uint32_t* tab_h, const float* tab_v, uint32_t* acc) {
+  constexpr int NT = frac_threads(BPS);
+  static_assert(NT == 256, "me_frac_stage: one implicit item per lane (64 positions x 4 quadrants), the work-list pass on 4 waves");
+  constexpr uint32_t keymask = STAGE ? kFracKey1 : kFracKey0;
+  const int role = tid & 3;
+  // the work lists: 64 8x8 positions x 4 waves (wave w decides entries w, w + 4, ... of each position's list), then 256 4x4 positions
+  auto lists = [&]() {
+    const int p8 = tid & 63;
+    const uint16_t* c8 = cover + p8 * kFracCover8;
+    switch (__builtin_amdgcn_readfirstlane(tid >> 6)) {
+      case 0: me_frac_dedupe<kFracCover8, 4, 0>(st, c8, keymask, p8 * kFracCover8, &counter[0], list8); break;
+      case 1: me_frac_dedupe<kFracCover8, 4, 1>(st, c8, keymask, p8 * kFracCover8, &counter[0], list8); break;
+      case 2: me_frac_dedupe<kFracCover8, 4, 2>(st, c8, keymask, p8 * kFracCover8, &counter[0], list8); break;
+      default: me_frac_dedupe<kFracCover8, 4, 3>(st, c8, keymask, p8 * kFracCover8, &counter[0], list8); break;
+    }
+    me_frac_dedupe4(st, cover, tid, keymask, &counter[1], list4);
+  };
+  if constexpr (frac_glds(BPS)) {
+    // 8-bit planes: a lane's NEXT item is requested (LDS-DMA into the wave's block of `pf`) before the current one is evaluated -- the
+    // registers that would have to hold rows in flight do not exist here (round 4's register-pipelined walk was slower on every
+    // content), an LDS block nobody else wants does: the kernel's registers allow two workgroups a CU, which leaves each 80 KiB.
+    uint32_t* pf_wave = pf + (tid >> 6) * (12 * 256);
+    const int lane = tid & 63;
+    int pair = (tid >> 2) * kFracCover8;
+    uint32_t meta = me_frac_prefetch<STAGE, 1>(src, gpitch, st, cover, pair, role, pf_wave);
+    lists();
+    __syncthreads();   // the work lists are complete (the rows asked for have landed as well: the barrier's fence waits for them)
+#if ME_FRAC_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    const int n8 = 4 * (int)counter[0], n4 = (int)counter[1];
+    int i8 = tid - NT;
+#pragma unroll 1
+    for (;;) {
+      FracRaw<BPS> R;
+      me_frac_take<STAGE>(pf_wave, lane, meta, R);
+      const int cur = pair;
+      i8 += NT;
+      const bool more = i8 < n8;
+      if (more) {
+        pair = list8[i8 >> 2];
+        meta = me_frac_prefetch<STAGE, 1>(src, gpitch, st, cover, pair, role, pf_wave);
+      }
+#ifndef ME_FRAC_T_NOITEMS
+      me_frac_compute<STAGE, HAD, BPS, 1, WP>(R, curl, st, cover, cur, role, bd, clip_lo, wp, tab_h, tab_v, acc);
+#endif
+      if (!more) break;
+    }
+    int i4 = tid;
+    if (i4 < n4) {
+      pair = list4[i4];
+      meta = me_frac_prefetch<STAGE, 0>(src, gpitch, st, cover, pair, 0, pf_wave);
+#pragma unroll 1
+      for (;;) {
+        FracRaw<BPS> R;
+        me_frac_take<STAGE>(pf_wave, lane, meta, R);
+        const int cur = pair;
+        i4 += NT;
+        const bool more = i4 < n4;
+        if (more) {
+          pair = list4[i4];
+          meta = me_frac_prefetch<STAGE, 0>(src, gpitch, st, cover, pair, 0, pf_wave);
+        }
+#ifndef ME_FRAC_T_NOITEMS
+        me_frac_compute<STAGE, HAD, BPS, 0, WP>(R, curl, st, cover, cur, 0, bd, clip_lo, wp, tab_h, tab_v, acc);
+#endif
+        if (!more) break;
+      }
+    }
+  } else {
+    int n8 = 0;
+#pragma unroll 1
+    for (int i8 = tid - NT;; i8 += NT) {   // first turn (i8 < 0 in every lane): the implicit item
+      int pair = (tid >> 2) * kFracCover8;
+      if (i8 >= 0) {
+        if (i8 >= n8) break;
+        pair = list8[i8 >> 2];
+      }
+      FracRaw<BPS> R;
+      me_frac_fetch<STAGE, BPS, 1>(src, gpitch, st, cover, pair, role, R);
+      if (i8 < 0) {   // the work lists, while the implicit item's rows are on their way
+        lists();
+#if ME_FRAC_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+      }
+#ifndef ME_FRAC_T_NOITEMS
+      me_frac_compute<STAGE, HAD, BPS, 1, WP>(R, curl, st, cover, pair, role, bd, clip_lo, wp, tab_h, tab_v, acc);
+#endif
+      if (i8 < 0) {
+        __syncthreads();   // the work lists are complete
+        n8 = 4 * (int)counter[0];
+      }
+    }
+    const int n4 = (int)counter[1];
+#ifndef ME_FRAC_T_NOITEMS
+#pragma unroll 1
+    for (int i4 = tid; i4 < n4; i4 += NT) {
+      const int pair = list4[i4];
+      FracRaw<BPS> R;
+      me_frac_fetch<STAGE, BPS, 0>(src, gpitch, st, cover, pair, 0, R);
+      me_frac_compute<STAGE, HAD, BPS, 0, WP>(R, curl, st, cover, pair, 0, bd, clip_lo, wp, tab_h, tab_v, acc);
+    }
+#endif
+  }
+#if ME_FRAC_PRIO
+  __builtin_amdgcn_s_setprio(3);
+#endif
+}
+
+// Which job the k-th workgroup (or the k-th draw from the job counter) takes.  A launch ends one job time after its last job STARTS, and
+// the CTUs on the picture's edge are the slow ones: their slots reach into the padding (a partial bottom row most of all: 2160 = 33 x 64
+// + 48), find MVs of their own there and share little -- 2-3 x the time of an interior CTU (profiles/r04k_frac_timeline.txt: the bottom
+// row dealt last kept a 2160p launch alive for an extra job time; profiles/r05j_frac_phases.txt: so did the TOP row once the table
+// was simply dealt from its end).  So the edge CTUs of every pair go first -- bottom row, top row, left and right column -- then the
+// interiors.  Launches over a CTU sub-range (and pictures less than three CTUs wide or high) keep the plain last-first order.
+__device__ __forceinline__ int me_frac_deal(int k, int n_jobs, const FracPrep& prep) {
+  const int first = (int)(prep.ctus & 0xffff), count = (int)(prep.ctus >> 16);
+  const int X = ((int)(prep.dims & 0xffff) + 63) >> 6, Y = ((int)(prep.dims >> 16) + 63) >> 6, n_ctu = X * Y;
+  if (first != 0 || count != n_ctu || X < 3 || Y < 3 || n_jobs % n_ctu) return n_jobs - 1 - k;
+  const int E = 2 * X + 2 * (Y - 2), I = n_ctu - E, pairs = n_jobs / n_ctu;
+  int pair, ctu;
+  if (k < pairs * E) {
+    pair = k / E;
+    int e = k - pair * E;
+    if (e < X) ctu = (Y - 1) * X + e;
+    else if (e < 2 * X) ctu = e - X;
+    else { e -= 2 * X; ctu = (1 + (e >> 1)) * X + ((e & 1) ? X - 1 : 0); }
+  } else {
+    const int m = k - pairs * E;
+    pair = m / I;
+    const int i = m - pair * I;
+    ctu = (1 + i / (X - 2)) * X + 1 + i % (X - 2);
+  }
+  return pair * n_ctu + ctu;
 }
 
 // WAVES: waves per SIMD the register budget is cut for.  The 8-bit kernel wants 230 VGPRs.  At two waves (no scratch) a job takes
@@ -1687,8 +1897,8 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
   const float clip_lo = (BPS == 2 && (bit_depth_bias & 0x100)) ? (float)(1 << bit_depth) : 0.f;
   constexpr int NT = frac_threads(BPS);
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  uint32_t* acc = smem;                 // [593][kFracAccRow] distortion sums of the current stage
-  uint32_t* st = smem + kFracAccDw;     // [593] slot state: (mx - lt_x) | (my - lt_y) << 9 | (half_x + 1) << 18 | (half_y + 1) << 20
+  uint32_t* acc = smem;                 // [593][frac_acc_row(BPS)] distortion sums of the current stage (8-bit planes: three packed 64-bit words per slot)
+  uint32_t* st = smem + frac_acc_dw(BPS);   // [593] slot state: (mx - lt_x) | (my - lt_y) << 9 | (half_x + 1) << 18 | (half_y + 1) << 20
   uint32_t* tab_h = st + 600;           // [9][kFracTabH] packed horizontal taps of the quarter-pel stage: row = (half-pel winner + 1) * 3 + (offset + 1), me_tap8
   float* tab_v = (float*)(tab_h + 9 * kFracTabH);   // [9][kFracTabV] vertical taps, same rows
   uint32_t* counter = tab_h + 152;      // [2] lengths of the two work lists
@@ -1696,6 +1906,7 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
   uint16_t* list4 = (uint16_t*)(tab_h + 160 + kFracPairs8 / 2);   // distinct (4x4 position, key) pairs
   uint32_t* curl = tab_h + 160 + (kFracPairs8 + kFracPairs4) / 2;   // 64 x 64 current block
   uint16_t* cover = (uint16_t*)(curl + 1024 * BPS);   // the cover table (uint16 [64][18] then [256][6]): read per item and per dedupe, so it lives here
+  uint32_t* pf = (uint32_t*)(cover + kFracPairs8 + kFracPairs4);   // 8-bit planes: [4 waves][12 rows][64 lanes][16 B] patch rows in flight (me_frac_stage)
 
   const int tid = threadIdx.x;
   const int bd = BPS == 1 ? 8 : bit_depth;
@@ -1722,21 +1933,18 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
   uint32_t* next_job = counter + 2;     // LDS word: the job this workgroup works on
 #pragma unroll 1
   for (int turn = blockIdx.x;; turn += gridDim.x) {
-  int jb = n_jobs - 1 - turn;           // without a counter: blockIdx.x, blockIdx.x + gridDim.x, ... -- counted from the end of the table as well
+  int deal = turn;                      // without a counter: blockIdx.x, blockIdx.x + gridDim.x, ...
   if (job_counter) {
     if (tid == 0) *next_job = atomicAdd(job_counter, 1u);
     __syncthreads();                    // (the barrier that ends the previous job's last stage keeps this write behind every read of it)
-    // last jobs first: the jobs at the end of the table are the bottom CTU row of a picture, which is partial whenever the height is
-    // not a multiple of 64 (2160, 1080) -- its slots reach into the padding, find MVs of their own and share little, so such a job
-    // runs 2-3 x as long as its neighbours; dealt last, 60 of them kept the launch alive for a whole extra job time
-    // (profiles/r04k_frac_timeline.txt)
-#ifndef ME_FRAC_FORWARD
-    jb = n_jobs - 1 - (int)*next_job;
-#else
-    jb = (int)*next_job;
-#endif
+    deal = (int)*next_job;
   }
-  if (jb >= n_jobs || jb < 0) break;
+  if (deal >= n_jobs || deal < 0) break;
+#ifndef ME_FRAC_FORWARD
+  const int jb = me_frac_deal(deal, n_jobs, prep);
+#else
+  const int jb = deal;
+#endif
 #ifdef ME_FRAC_T_TIMELINE   // timing-only build: when does each job start and end (100 MHz wall clock), in which workgroup, and its phases
   const unsigned long long t_job0 = wall_clock64();
   const unsigned long long c_job0 = clock64();   // shader clock: cycles / wall time = the clock the job ran at
@@ -1778,12 +1986,13 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
     uint32_t w[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) w[k] = tid + k * NT < kParts ? mvw[tid + k * NT] : 0u;
-    for (int i = tid; i < kFracAccDw / 4; i += NT) ((uint4*)acc)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < frac_acc_dw(BPS) / 4; i += NT) ((uint4*)acc)[i] = make_uint4(0, 0, 0, 0);
+    const int ltx = job.lt_x, lty = job.lt_y, rbx = job.rb_x, rby = job.rb_y;   // ints: min / max of an int and an int16_t resolve to the double overloads
 #pragma unroll
     for (int k = 0; k < 3; ++k)
       if (tid + k * NT < kParts) {
-        const int mx = min(max((int)(int16_t)(w[k] & 0xffff), job.lt_x), job.rb_x), my = min(max((int)(int16_t)(w[k] >> 16), job.lt_y), job.rb_y);
-        st[tid + k * NT] = (uint32_t)(mx - job.lt_x) | (uint32_t)(my - job.lt_y) << 9 | 1u << 18 | 1u << 20;
+        const int mx = min(max((int)(int16_t)(w[k] & 0xffff), ltx), rbx), my = min(max((int)(int16_t)(w[k] >> 16), lty), rby);
+        st[tid + k * NT] = (uint32_t)(mx - ltx) | (uint32_t)(my - lty) << 9 | 1u << 18 | 1u << 20;
       }
   }
   if (tid < 2) counter[tid] = 0;
@@ -1797,59 +2006,67 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
 
 #pragma unroll 1
   for (int stage = 0; stage < 2; ++stage) {
-    const uint32_t keymask = stage ? kFracKey1 : kFracKey0;
-    {   // 64 8x8 positions x 4 waves (NT = 256: wave w decides entries w, w + 4, ... of each position's list), then 256 4x4 positions
-      static_assert(NT == 256, "me_frac_kernel: the work-list pass assumes 4 waves");
-      const int p8 = tid & 63;
-      const uint16_t* c8 = cover + p8 * kFracCover8;
-      switch (__builtin_amdgcn_readfirstlane(tid >> 6)) {
-        case 0: me_frac_dedupe<kFracCover8, 4, 0>(st, c8, keymask, p8 * kFracCover8, &counter[0], list8); break;
-        case 1: me_frac_dedupe<kFracCover8, 4, 1>(st, c8, keymask, p8 * kFracCover8, &counter[0], list8); break;
-        case 2: me_frac_dedupe<kFracCover8, 4, 2>(st, c8, keymask, p8 * kFracCover8, &counter[0], list8); break;
-        default: me_frac_dedupe<kFracCover8, 4, 3>(st, c8, keymask, p8 * kFracCover8, &counter[0], list8); break;
-      }
-      me_frac_dedupe4(st, cover, tid, keymask, &counter[1], list4);
-    }
-    __syncthreads();
-    ME_FRAC_STAMP();
-    const int n8 = 4 * (int)counter[0], n4 = (int)counter[1];
-#ifndef ME_FRAC_T_NOITEMS
-#if ME_FRAC_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
-    if (stage == 0) me_frac_stage_items<0, HAD, BPS, WP>(src, ref_pitch, curl, st, cover, list8, n8, list4, n4, tid, bd, clip_lo, wp, tab_h, tab_v, acc);
-    else me_frac_stage_items<1, HAD, BPS, WP>(src, ref_pitch, curl, st, cover, list8, n8, list4, n4, tid, bd, clip_lo, wp, tab_h, tab_v, acc);
-#if ME_FRAC_PRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
-#endif
+    ME_FRAC_STAMP();   // (timeline builds: the list phase is no phase of its own any more -- its stamp is the stage's start)
+    if (stage == 0) me_frac_stage<0, HAD, BPS, WP>(src, ref_pitch, curl, st, cover, list8, list4, counter, pf, tid, bd, clip_lo, wp, tab_h, tab_v, acc);
+    else me_frac_stage<1, HAD, BPS, WP>(src, ref_pitch, curl, st, cover, list8, list4, counter, pf, tid, bd, clip_lo, wp, tab_h, tab_v, acc);
     __syncthreads();
     ME_FRAC_STAMP();
     if (tid < 2) counter[tid] = 0;
-    for (int s = tid; s < kParts; s += NT) {
+    // winners (a rolled loop on purpose: with the three slots of a thread unrolled the kernel's register demand rises past 256)
+    constexpr int ph[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};
+    constexpr int pq[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {1, 1}};
+#pragma unroll 1
+    for (int k = 0; k < 3; ++k) {
+      const int s = tid + k * NT;
+      if (s >= kParts) break;
       const uint32_t sv = st[s];
+      uint32_t sums1[9];
+      if constexpr (frac_pack3(BPS)) {
+        const unsigned long long* a = (const unsigned long long*)acc + s * 3;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const unsigned long long v = a[q];
+          sums1[3 * q] = (uint32_t)v & 0x1fffffu; sums1[3 * q + 1] = (uint32_t)(v >> 21) & 0x1fffffu; sums1[3 * q + 2] = (uint32_t)(v >> 42);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) sums1[i] = acc[s * 9 + i];
+      }
       const int mx = (int)(sv & 0x1ff) + job.lt_x, my = (int)((sv >> 9) & 0x1ff) + job.lt_y;
       const int hx = stage ? (int)((sv >> 18) & 3) - 1 : 0, hy = stage ? (int)((sv >> 20) & 3) - 1 : 0;
       const int bxq = 4 * mx + 2 * hx, byq = 4 * my + 2 * hy;   // centre of this stage in quarter units
-      constexpr int ph[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};
-      constexpr int pq[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {1, 1}};
       uint32_t best = 0xffffffffu, best_acc = 0;
       int bi = 0;
+      // the nine points are three x- and three y-offsets: six xGetComponentBits instead of eighteen
+      const int step = stage ? 1 : 2;
+      uint32_t bits_x[3], bits_y[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        bits_x[t] = me_component_bits(bxq + (t - 1) * step - job.pred_x);
+        bits_y[t] = me_component_bits(byq + (t - 1) * step - job.pred_y);
+      }
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
-        const int ox = stage ? pq[i][0] : 2 * ph[i][0], oy = stage ? pq[i][1] : 2 * ph[i][1];
-        // whole-PU distortion >> (bitDepth - 8) (TComRdCost.cpp:520-521, :1604), then the MV cost
-        const uint32_t a = acc[s * kFracAccRow + i];
-        const uint32_t d = (a >> (bd - 8)) + me_mv_cost_q(lambda_q16, bxq + ox, byq + oy, job.pred_x, job.pred_y);
+        // the point orders of the two stages differ in entries 3..6 (s_acMvRefineH / s_acMvRefineQ, TEncSearch.cpp:51-75)
+        const uint32_t bx_h = bits_x[ph[i][0] + 1], by_h = bits_y[ph[i][1] + 1], bx_q = bits_x[pq[i][0] + 1], by_q = bits_y[pq[i][1] + 1];
+        const uint32_t bits = (ph[i][0] == pq[i][0] && ph[i][1] == pq[i][1]) ? bx_h + by_h : (stage ? bx_q + by_q : bx_h + by_h);
+        // whole-PU distortion >> (bitDepth - 8) (TComRdCost.cpp:520-521, :1604), then the MV cost (getCost: uint32 product >> 16)
+        const uint32_t a = sums1[i];
+        const uint32_t d = (a >> (bd - 8)) + ((lambda_q16 * bits) >> 16);
         if (d < best) { best = d; bi = i; best_acc = a; }
       }
       if (stage == 0) {
         st[s] = (sv & kFracKey0) | (uint32_t)(ph[bi][0] + 1) << 18 | (uint32_t)(ph[bi][1] + 1) << 20;
         // this thread owns row s of acc between the two barriers around this loop: it leaves the row as stage 1 needs it -- point 0 (the
         // centre of the quarter-pel stage IS the half-pel winner: nothing adds to it in stage 1) carried over, the other eight cleared
-        acc[s * kFracAccRow] = best_acc;
+        if constexpr (frac_pack3(BPS)) {
+          unsigned long long* a = (unsigned long long*)acc + s * 3;
+          a[0] = best_acc; a[1] = 0; a[2] = 0;
+        } else {
+          acc[s * 9] = best_acc;
 #pragma unroll
-        for (int i = 1; i < 9; ++i) acc[s * kFracAccRow + i] = 0;
+          for (int i = 1; i < 9; ++i) acc[s * 9 + i] = 0;
+        }
       } else {
         const long o = (long)jb * kParts + s;
         out_qmv[2 * o] = (int16_t)(bxq + pq[bi][0]);

@@ -58,6 +58,8 @@ if os.environ.get("HMME_TIMELINE"):   # a library built with -DME_FRAC_T_TIMELIN
                        "last_start_us": round(float(s_us.max()), 1), "longest_jobs": [int(v) for v in np.argsort(-dur)[:12]],
                        "mean_us_bottom_ctu_row": round(float(dur[-((w + 63) // 64):].mean()), 1),
                        "shader_clock_ghz_mean_min_max": [round(float(v), 3) for v in ((c[:, 12] / (dur * 1000.0)).mean(), (c[:, 12] / (dur * 1000.0)).min(), (c[:, 12] / (dur * 1000.0)).max())],
+                       "latest_ends(job,start_us,dur_us,end_us)": [[int(j), round(float(s_us[j]), 1), round(float(dur[j]), 1), round(float(e_us[j]), 1)] for j in np.argsort(-e_us)[:8]],
+                       "starts_histogram_10us": np.histogram(s_us, bins=np.arange(0, float(e_us.max()) + 10, 10))[0].tolist(),
                        "busy_share": round(float(dur.sum() / (e_us.max() * (per_wg > 0).sum())), 3),
                        "phase_us_mean": dict(zip(("setup", "lists0", "items0", "winners0", "lists1", "items1", "winners1"), (round(float(c[:, 5 + i].mean()) / 100.0, 2) for i in range(7))))}
 frac = (d_q.to(torch.int32) - 4 * d_mv.to(torch.int32)).abs().amax().item()
