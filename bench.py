@@ -307,6 +307,12 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-gpu: rehearse the N > 1 code path on a one-GPU box (not a measurement)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
+    ap.add_argument("--rank-timeout", type=float, default=240.0,
+                    help="N > 1: seconds a rank may take from its start to the end of its first barrier (rendezvous, RCCL communicator) before it "
+                         "gives up with exit code 3, naming itself and the stage it hung in; 0 = no limit")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="`python bench.py --gpus N` started without a launcher: seconds the parent lets the ranks it started run before it ends "
+                         "their process group and exits 124")
     args = ap.parse_args(argv)
     if args.size not in SIZES:
         try:
@@ -323,28 +329,68 @@ def parse_args(argv=None):
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as a child torch.distributed.run (one
     process per GPU, rendezvous on 127.0.0.1) and relay rank 0's JSON line and the exit code.  Nothing in THIS process has touched
-    the GPU (torch is not even imported yet): a process that has initialised the GPU must not be replaced or forked on this pool."""
+    the GPU (torch is not even imported yet): a process that has initialised the GPU must not be replaced or forked on this pool.
+    The child runs in a process group of its own; every rank leaves a file per start-up stage in a status directory.  When a rank's own
+    watchdog ends it (exit code 3, --rank-timeout) torch.distributed.run takes the others down; should the launcher itself sit still past
+    --launch-timeout, the parent ends the CHILD group (SIGTERM, then SIGKILL: the exact group it started, nothing matched by name),
+    says which ranks never reached which stage, and exits 124."""
+    import shutil
+    import signal
     import socket
     import subprocess
+    import tempfile
+    import threading
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), HMME_BENCH_SELF_LAUNCHED="1")
+    status = tempfile.mkdtemp(prefix="hmme_bench_status_")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), HMME_BENCH_SELF_LAUNCHED="1",
+               HMME_BENCH_STATUS_DIR=status)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    line = None
-    for ln in child.stdout:                      # rank 0's line goes to stdout as the only line; everything else is diagnostics
-        if ln.startswith('{"metric"'):
-            line = ln
-        else:
-            sys.stderr.write(ln)
-    rc = child.wait()
-    if rc == 0 and line is None:
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    line = [None]
+
+    def relay():
+        for ln in child.stdout:                  # rank 0's line goes to stdout as the only line; everything else is diagnostics
+            if ln.startswith('{"metric"'):
+                line[0] = ln
+            else:
+                sys.stderr.write(ln)
+
+    reader = threading.Thread(target=relay, daemon=True)
+    reader.start()
+    timed_out = False
+    try:
+        rc = child.wait(timeout=args.launch_timeout if args.launch_timeout > 0 else None)
+    except subprocess.TimeoutExpired:
+        timed_out = True
+        reached = sorted(os.listdir(status))
+        missing = [r for r in range(args.gpus) if f"rank{r}.first_barrier" not in reached]
+        sys.stderr.write(f"bench.py: the {args.gpus} ranks did not finish within {args.launch_timeout:.0f} s; ranks that never passed their first barrier: "
+                         f"{missing or 'none'}; stages reached: {reached}: ending the child process group {child.pid}\n")
+        for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 10.0)):
+            try:
+                os.killpg(child.pid, sig)        # the session started above: exactly the launcher and the ranks it spawned
+            except ProcessLookupError:
+                break
+            try:
+                child.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        rc = 124
+    reader.join(timeout=5.0)
+    if rc != 0 and not timed_out:
+        reached = sorted(os.listdir(status))
+        missing = [r for r in range(args.gpus) if f"rank{r}.first_barrier" not in reached]
+        sys.stderr.write(f"bench.py: the ranks exited with code {rc}; ranks that never passed their first barrier: {missing or 'none'}\n")
+    shutil.rmtree(status, ignore_errors=True)
+    if rc == 0 and line[0] is None:
         sys.stderr.write("bench.py: the ranks exited without a result line\n")
         rc = 1
-    if line is not None and rc == 0:
-        sys.stdout.write(line)
+    if line[0] is not None and rc == 0:
+        sys.stdout.write(line[0])
         sys.stdout.flush()
     return rc
 
@@ -580,12 +626,49 @@ def main():
     dev = torch.device("cuda", local_rank)
     # HMME_BENCH_FORCE_DIST=1: run the collective path with world size 1 too (rehearses the RCCL calls on a 1-GPU box)
     use_dist = world > 1 or (os.environ.get("HMME_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    status_dir = os.environ.get("HMME_BENCH_STATUS_DIR")
+
+    def mark(stage):                         # start-up stages of this rank, for the parent of a self-launched run
+        if status_dir:
+            try:
+                open(os.path.join(status_dir, f"rank{rank}.{stage}"), "w").close()
+            except OSError:
+                pass
+
+    watchdog = None
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # an N-rank run first happens unattended: a rank that cannot get through rendezvous and its first collective ends itself (exit 3)
+        # with a line that names it and the stage, instead of leaving the job in a collective for the launcher's default half hour
+        watchdog = shard.StartupWatchdog(rank, world, args.rank_timeout)
+        mark("started")
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if args.backend == "nccl" else "n/a (gloo)"
+        except Exception as e:               # noqa: BLE001 -- a diagnostic must not end the run
+            rccl = f"unknown ({e})"
+        sys.stderr.write(f"bench.py: rank {rank}/{world} pid {os.getpid()} local_rank {local_rank}: hipGetDeviceCount {torch.cuda.device_count()}, "
+                         f"device {device_identity(torch, local_rank)}, RCCL {rccl}, backend {args.backend}, "
+                         f"MASTER {os.environ.get('MASTER_ADDR', '?')}:{os.environ.get('MASTER_PORT', '?')}\n")
+        sys.stderr.flush()
+        watchdog.stage("init_process_group (rendezvous)")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+        mark("process_group")
+        watchdog.stage("rendezvous store count")
+        seen = shard.rendezvous_report(rank, world, timeout_s=max(10.0, args.rank_timeout / 2) if args.rank_timeout > 0 else 120.0)
+        if rank == 0 and seen != world:
+            raise SystemExit(f"bench.py: only {seen} of {world} ranks reached the rendezvous store: nothing reported")
+        stall = os.environ.get("HMME_BENCH_TEST_STALL", "")   # tests: "<rank>:<seconds>" -- that rank sits still in front of its first barrier
+        if stall and int(stall.split(":")[0]) == rank:
+            time.sleep(float(stall.split(":")[1]))
+        watchdog.stage("first barrier (RCCL communicator)" if args.backend == "nccl" else "first barrier")
+        dist.barrier()
+        if args.backend == "nccl":
+            torch.cuda.synchronize()
+        watchdog.done()
+        mark("first_barrier")
 
     w, h = size_of(args.size)
     sr = args.search_range

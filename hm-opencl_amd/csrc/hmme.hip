@@ -85,6 +85,7 @@ struct hmme_ctx {
   int sr_max = 64;
   uint32_t lambda_q16 = 0;
   std::string err;
+  bool print_errors = true;   // hmme_set_error_printing
   std::string info;
   hipStream_t stream = nullptr;   // private stream of the synchronous entry points
   // frame-path scratch (job tables, merge table, cover table) is shared by every call of the context: a call on another stream
@@ -179,7 +180,7 @@ int fail(hmme_ctx* ctx, int code, const char* fmt, ...) {
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
   if (ctx) ctx->err = buf; else g_create_error = buf;
-  fprintf(stderr, "hmme: ERROR: %s\n", buf);   // TEncOpenCL::checkError prints too (TEncOpenCL.h:93-101)
+  if (!ctx || ctx->print_errors) fprintf(stderr, "hmme: ERROR: %s\n", buf);   // TEncOpenCL::checkError prints too (TEncOpenCL.h:93-101)
   return code;
 }
 
@@ -467,8 +468,10 @@ int hmme_create(int device, int sr_max, unsigned flags, hmme_ctx** out) {
   ctx->device = device;
   ctx->sr_max = sr_max;
   char info[256];
-  snprintf(info, sizeof info, "%s (%s), %d CUs, %.0f GiB", prop.name, prop.gcnArchName, prop.multiProcessorCount,
-           (double)prop.totalGlobalMem / (1 << 30));
+  // (the marketing name comes from libdrm's amdgpu.ids table, which a minimal install may lack: the string then starts with what the
+  // runtime always knows -- the architecture)
+  snprintf(info, sizeof info, "%s (%s), %d CUs, %.0f GiB", prop.name[0] ? prop.name : "AMD GPU (no marketing name on this host)", prop.gcnArchName,
+           prop.multiProcessorCount, (double)prop.totalGlobalMem / (1 << 30));
   ctx->info = info;
   ctx->wg_slots = 2 * prop.multiProcessorCount;
   ctx->num_cus = prop.multiProcessorCount;
@@ -511,6 +514,7 @@ void hmme_destroy(hmme_ctx* ctx) {
 }
 
 const char* hmme_last_error(const hmme_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+void hmme_set_error_printing(hmme_ctx* ctx, int on) { if (ctx) ctx->print_errors = on != 0; }
 const char* hmme_device_info(const hmme_ctx* ctx) { return ctx ? ctx->info.c_str() : ""; }
 int hmme_device_index(const hmme_ctx* ctx) { return ctx ? ctx->device : -1; }
 

@@ -1660,9 +1660,22 @@ __device__ __forceinline__ void me_frac_compute(const FracRaw<BPS>& R, const uin
   // (Round 3 tried to relieve these adds -- the large slots cover many positions, so lanes of one wave often add to the same address:
   // each quad starting its walk at another list position and two points per ds_add_u64 cut the kernel's LDS conflict cycles by 27 %
   // and its LDS waits by 90 %, and changed its time by -2 % .. +3 %: LDS is busy 10 % of the CU cycles here.  profiles/archive/r03d_frac_ab.txt)
-  for (int j2 = j + (KIND8 ? role : 0); j2 < NCOV; j2 += KIND8 ? 4 : 1) {
-    const int s2 = cov[j2];
-    if (j2 == j || ((st[s2] ^ sv) & keymask) == 0) add_to(s2, dist, pk);
+  // (slot ids first, then their keys, then the adds: two LDS round trips for the lane's whole share -- walking the list entry by entry
+  // was two dependent round trips PER entry at the end of every item, with nothing else for the wave to issue)
+  {
+    constexpr int STEP = KIND8 ? 4 : 1, MAXN = KIND8 ? 5 : kFracCover4;
+    const int j0 = j + (KIND8 ? role : 0);
+    int s2[MAXN];
+    uint32_t k2[MAXN];
+#pragma unroll
+    for (int k = 0; k < MAXN; ++k) s2[k] = cov[min(j0 + k * STEP, NCOV - 1)];
+#pragma unroll
+    for (int k = 0; k < MAXN; ++k) k2[k] = st[s2[k]];
+#pragma unroll
+    for (int k = 0; k < MAXN; ++k) {
+      const int j2 = j0 + k * STEP;
+      if (j2 < NCOV && (j2 == j || ((k2[k] ^ sv) & keymask) == 0)) add_to(s2[k], dist, pk);
+    }
   }
 #else   // every distortion still computed, ONE atomic per item: the difference to the product build is what the accumulation costs
   {

@@ -22,10 +22,10 @@ SYMBOLS = ["hmme_create", "hmme_destroy", "hmme_last_error", "hmme_device_info",
            "hmme_num_ctus", "hmme_search_frame", "hmme_search_frame_device", "hmme_search_frame_multi",
            "hmme_search_frame_multi_device", "hmme_refine_frame", "hmme_refine_frame_multi_device",
            "hmme_search_pairs_device", "hmme_refine_pairs_device", "hmme_plane_upload_async",
-           "hmme_upload_status", "hmme_abi_version", "hmme_build_id", "hmme_device_index"]
+           "hmme_upload_status", "hmme_abi_version", "hmme_build_id", "hmme_device_index", "hmme_set_error_printing"]
 # test / measurement entry points (include/hmme_test.h): not part of the boundary
 TEST_SYMBOLS = ["hmme_test_time_search_kernel", "hmme_test_device_address"]
-ABI_VERSION = 4   # HMME_ABI_VERSION of the include/hmme.h these bindings were written against
+ABI_VERSION = 5   # HMME_ABI_VERSION of the include/hmme.h these bindings were written against
 
 
 class HmmeError(RuntimeError):

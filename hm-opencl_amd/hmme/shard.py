@@ -3,12 +3,75 @@ xGMI on the MI355X node, "gloo" in the CPU tests).
 
 Open-loop motion estimation over a sequence is embarrassingly parallel per (current, reference)
 picture pair: pair p is searched by rank p % world with no exchange during the
-search.  The only collective is the result gather: every rank contributes an equally sized
-[pairs_per_rank, n_ctu, 593] block of (mv, sad) -- 9.7 MB per 2160p pair -- through
-all_gather_into_tensor, and the blocks are re-interleaved into pair order.
+search.  The only exchange step is the result gather TO RANK 0 (gather_to_root): every other rank
+sends its [k_r, n_ctu, 593] block of (mv, sad) -- 9.7 MB per 2160p pair, k_r pairs, ragged and
+possibly zero -- as grouped point-to-point sends (dist.batch_isend_irecv = ncclGroupStart / ncclSend /
+ncclRecv / ncclGroupEnd on RCCL); rank 0 re-interleaves the blocks into pair order.  Nothing is sent
+to ranks that do not read it.  PipelinedGather overlaps step k's transfer with step k + 1's search.
+
+Start-up of an unattended N-rank run (bench.py --gpus N): `StartupWatchdog` ends a rank that does not
+get through rendezvous and its first collective in time, naming itself and the stage it hung in, and
+`rendezvous_report` counts the ranks through the job's store BEFORE the first collective.
 """
+import os
+import sys
+import threading
+import time
+
 import torch
 import torch.distributed as dist
+
+
+class StartupWatchdog:
+    """A rank that hangs before its first barrier (a wedged device, a rank that never joins, an RCCL communicator that cannot be built)
+    would hang the whole job silently.  The watchdog thread ends THIS process with exit code 3 once `seconds` have passed without
+    `done()` -- after one stderr line that names the rank and the stage it was in; the launcher (torch.distributed.run, or bench.py's own
+    parent process) then takes the other ranks down and the job fails loudly instead of sitting in a collective.  Nothing is re-executed
+    and no other process is signalled from here."""
+
+    def __init__(self, rank, world, seconds, label="bench.py", _exit=os._exit, _out=None):
+        self.rank, self.world, self.seconds, self.label = rank, world, float(seconds), label
+        self._stage = "start"
+        self._done = threading.Event()
+        self._exit, self._out = _exit, _out or sys.stderr
+        self._t0 = time.monotonic()
+        self._thread = threading.Thread(target=self._run, name="hmme-startup-watchdog", daemon=True)
+        if self.seconds > 0:
+            self._thread.start()
+
+    def stage(self, name):
+        self._stage = name
+
+    def done(self):
+        self._done.set()
+
+    def _run(self):
+        if self._done.wait(self.seconds):
+            return
+        self._out.write(f"{self.label}: rank {self.rank} of {self.world} did not get past '{self._stage}' within {self.seconds:.0f} s "
+                        f"(pid {os.getpid()}, LOCAL_RANK {os.environ.get('LOCAL_RANK', '?')}): giving up so that the job fails instead of hanging\n")
+        self._out.flush()
+        self._exit(3)
+
+
+def rendezvous_report(rank, world, timeout_s=120.0, key="hmme/ranks_seen", out=None):
+    """Counts the ranks through the job's key-value store (TCP: no collective, no GPU) -- every rank adds itself, rank 0 waits until all
+    `world` have, or says which count it got stuck at.  Returns the number of ranks seen (rank 0) or None (other ranks)."""
+    out = out or sys.stderr
+    store = dist.distributed_c10d._get_default_store()
+    store.add(key, 1)
+    if rank != 0:
+        return None
+    t0 = time.monotonic()
+    seen = 0
+    while True:
+        seen = int(store.add(key, 0))
+        if seen >= world or time.monotonic() - t0 > timeout_s:
+            break
+        time.sleep(0.05)
+    out.write(f"hmme: ranks_seen {seen} of {world} through the rendezvous store, before the first collective\n")
+    out.flush()
+    return seen
 
 
 # reference-picture offsets (POC deltas) of the reference's two GOP presets, per position in the GOP of 4

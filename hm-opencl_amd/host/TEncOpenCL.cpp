@@ -106,6 +106,22 @@ Void TEncOpenCL::xPoison(Tables& t) {
   }
 }
 
+// row reductions of the compat-mode sample-width scan, vectorised whatever the optimisation level of the build they end up in (the
+// reference's own makefiles compile the encoder at -O2, where GCC 11 does not vectorise)
+#if defined(__GNUC__) && !defined(__clang__)
+#define HMME_VECTORISE __attribute__((optimize("O3", "tree-vectorize")))
+#else
+#define HMME_VECTORISE
+#endif
+static HMME_VECTORISE Pel xRowMax(const Pel* __restrict__ row, Int n, Pel m) {
+  for (Int x = 0; x < n; x++) m = row[x] > m ? row[x] : m;
+  return m;
+}
+static HMME_VECTORISE Pel xRowMin(const Pel* __restrict__ row, Int n, Pel m) {
+  for (Int x = 0; x < n; x++) m = row[x] < m ? row[x] : m;
+  return m;
+}
+
 // reference TEncOpenCL.cpp:240-362.  pelSearch = reference plane at the CTU origin, i_areaSize = search range,
 // *pcMvSrchRngLT = integer-pel top-left of the window.
 Void TEncOpenCL::calcMotionVectors(Pel* pelCtu, Pel* pelSearch, Int iRefStride, Int iCtuStride, Int i_areaSize,
@@ -125,26 +141,7 @@ Void TEncOpenCL::calcMotionVectors(Pel* pelCtu, Pel* pelSearch, Int iRefStride, 
   if (m_mode == ME_MODE_OCL_COMPAT) {
     hmme_params_ocl_compat(&p, pcMvSrchRngLT->getHor(), pcMvSrchRngLT->getVer(), i_areaSize);
     p.bit_depth = m_bitDepth;
-    if (m_bitDepth <= 0) {
-      // nothing in the reference tree tells this class the bit depth (createBuffers has no such argument), and cl/sad.cl
-      // works on whatever Pel holds without a shift: take the sample width from the samples of the call -- the reference window
-      // AND the current block (a dark window under a bright block, a fade or a cut, must not pick too narrow a width).  The block
-      // may be a bi-prediction origin 2*org - pred (TEncSearch.cpp:3702-3712), so it only has to fit [-maxv, 2*maxv]: such a call
-      // never widens the estimate beyond the true depth.  The width is latched (only ever grows), so one sequence does not
-      // alternate between the 8-bit and the 16-bit kernel; with shift-free sums the results do not depend on it.
-      Int hi = 0, chi = 0, clo = 0;
-      const Int side = 2 * i_areaSize + 64;   // the window the reference copies, TEncOpenCL.cpp:253-277
-      const Pel* row = pelSearch + (long)p.lt_y * iRefStride + p.lt_x;
-      for (Int y = 0; y < side; y++, row += iRefStride)
-        for (Int x = 0; x < side; x++) hi = row[x] > hi ? row[x] : hi;
-      row = pelCtu;
-      for (Int y = 0; y < HMME_CTU_SIZE; y++, row += iCtuStride)
-        for (Int x = 0; x < HMME_CTU_SIZE; x++) { chi = row[x] > chi ? row[x] : chi; clo = row[x] < clo ? row[x] : clo; }
-      Int d = m_inferredDepth;
-      while (d < 12 && (hi > (1 << d) - 1 || chi > 2 * ((1 << d) - 1) || clo < -((1 << d) - 1))) ++d;
-      m_inferredDepth = d;
-      p.bit_depth = d;
-    }
+    if (m_bitDepth <= 0) p.bit_depth = m_inferredDepth;   // the latched width; a call it is too narrow for comes back with HMME_ERR_RANGE (below)
   } else {
     p.lt_x = pcMvSrchRngLT->getHor(); p.lt_y = pcMvSrchRngLT->getVer();
     p.rb_x = m_rb.getHor(); p.rb_y = m_rb.getVer();
@@ -189,8 +186,34 @@ Void TEncOpenCL::calcMotionVectors(Pel* pelCtu, Pel* pelSearch, Int iRefStride, 
     m_fracOk = rc == HMME_OK;
     m_fracPred = m_pred;
   }
-  if (rc != HMME_OK && !weighted)
+  if (rc != HMME_OK && !weighted) {
+    const Bool probing = m_mode == ME_MODE_OCL_COMPAT && m_bitDepth <= 0 && p.bit_depth < 12;
+    if (probing) hmme_set_error_printing(m_ctx, 0);
     rc = hmme_search_ctu(m_ctx, pelCtu, iCtuStride, pelSearch, iRefStride, &p, reinterpret_cast<int16_t*>(m_engMv), reinterpret_cast<uint32_t*>(m_engCost));
+    if (probing) hmme_set_error_printing(m_ctx, 1);
+    if (probing && rc == HMME_ERR_RANGE) {
+      // Nothing in the reference tree tells this class the bit depth (createBuffers has no such argument), and cl/sad.cl works on
+      // whatever Pel holds without a shift: the sample width comes from the samples of the call -- the reference window AND the current
+      // block (a dark window under a bright block, a fade or a cut, must not pick too narrow a width).  The block may be a bi-prediction
+      // origin 2*org - pred (TEncSearch.cpp:3702-3712), so it only has to fit [-maxv, 2*maxv]: such a call never widens the estimate
+      // beyond the true depth.  The width is latched (only ever grows), so one sequence does not alternate between the 8-bit and the
+      // 16-bit kernel; with shift-free sums the results do not depend on it.  The engine looks at every sample of a call anyway and
+      // refuses one that does not fit the width it was given: only such a call pays for the scan that finds the width it needs
+      // (every call used to: 4 us beside a 55 us engine call, tools/class_latency.cpp).
+      Pel hi16 = 0, chi16 = 0, clo16 = 0;
+      const Int side = 2 * i_areaSize + 64;   // the window the reference copies, TEncOpenCL.cpp:253-277
+      const Pel* row = pelSearch + (long)p.lt_y * iRefStride + p.lt_x;
+      for (Int y = 0; y < side; y++, row += iRefStride) hi16 = xRowMax(row, side, hi16);
+      row = pelCtu;
+      for (Int y = 0; y < HMME_CTU_SIZE; y++, row += iCtuStride) { chi16 = xRowMax(row, HMME_CTU_SIZE, chi16); clo16 = xRowMin(row, HMME_CTU_SIZE, clo16); }
+      const Int hi = hi16, chi = chi16, clo = clo16;
+      Int d = m_inferredDepth;
+      while (d < 12 && (hi > (1 << d) - 1 || chi > 2 * ((1 << d) - 1) || clo < -((1 << d) - 1))) ++d;
+      m_inferredDepth = d;
+      p.bit_depth = d;
+      rc = hmme_search_ctu(m_ctx, pelCtu, iCtuStride, pelSearch, iRefStride, &p, reinterpret_cast<int16_t*>(m_engMv), reinterpret_cast<uint32_t*>(m_engCost));
+    }
+  }
   if (rc != HMME_OK) {
     fprintf(stderr, "ERROR: TEncOpenCL::calcMotionVectors: %s\n", hmme_last_error(m_ctx));
     xPoison(t);

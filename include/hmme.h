@@ -63,8 +63,8 @@ extern "C" {
  * written against (hmme_search_params grew by `shift_free` in version 2: a caller built against version 1 would have the library
  * read 4 bytes past its struct).  3: hmme_search_pairs_device / hmme_refine_pairs_device, asynchronous uploads, bi-prediction
  * origins in the refinement calls.  4: hmme_search_ctu_w (explicit weighted prediction); hmme_time_search_kernel and
- * hmme_debug_device_address left this header (include/hmme_test.h). */
-#define HMME_ABI_VERSION 4
+ * hmme_debug_device_address left this header (include/hmme_test.h).  5: hmme_set_error_printing. */
+#define HMME_ABI_VERSION 5
 int hmme_abi_version(void);
 /* identifies the kernel sources + build flags the library was compiled from (bench.py ties committed counter summaries to it) */
 const char* hmme_build_id(void);
@@ -113,6 +113,10 @@ typedef struct hmme_frame_params {
 int hmme_create(int device, int sr_max, unsigned flags, hmme_ctx** out);
 void hmme_destroy(hmme_ctx* ctx);
 const char* hmme_last_error(const hmme_ctx* ctx); /* ctx may be NULL: error of the calling thread's last failed hmme_create */
+/* A failed call prints its message on stderr (as TEncOpenCL::checkError does, TEncOpenCL.h:93-101) and keeps it for hmme_last_error.
+ * on = 0 keeps it only -- for a caller that PROBES with a call it expects to be refused (TEncOpenCL's reference-mode call tries the
+ * sample width it has latched and widens it on HMME_ERR_RANGE, instead of scanning every window for its largest sample first). */
+void hmme_set_error_printing(hmme_ctx* ctx, int on);
 const char* hmme_device_info(const hmme_ctx* ctx);
 int hmme_device_index(const hmme_ctx* ctx);   /* the HIP device the context lives on (host code that makes its own HIP calls beside the library's) */
 int hmme_set_lambda(hmme_ctx* ctx, double lambda);         /* m_lambda = floor(65536*sqrt(lambda)) */
@@ -271,12 +275,12 @@ int hmme_refine_pairs_device(hmme_ctx* ctx, const hmme_plane* const* curs, const
  *                         workgroups of the refinement kernel per CU); the TEncOpenCL host module prints its call summary in its destructor
  *   HMME_FRAC_GRID=<n>    workgroups of a refinement launch: default (0) = one per job; n > 0 = exactly n, each taking job after
  *                         job from a counter; -1 = as many of those as the chip holds at a time
- *   HMME_FRAC_WAVES=<2|3> 8-bit refinement kernel: its two-wave (no scratch) or three-wave build whatever the launch's job count
- *                         (default: two waves when jobs <= 4 x CUs, else three)
  *   HMME_FRAC_JOB_TABLE=1 whole-picture refinement launches: job table written by a kernel in front of the launch (as before round 4's
  *                         end) instead of every workgroup deriving its job itself
  *   HMME_NO_TABLE_CACHE=1 launches without predictors: rebuild the job table every time (default: a launch of the same geometry on the
  *                         same stream as the one before it reuses the table that is still in place)
+ *   HMME_FAIR_PRIO=<0|1>  search kernels: wave priorities that fall with a wave's progress off / on whatever the launch size (default: on
+ *                         for whole-CTU workgroups, and for split / strip launches of up to four rounds of workgroups)
  *   HMME_TAIL_PARTS=<n>   pieces per job of a launch's last, partial round of workgroups: default = the planner's choice
  *                         (DESIGN.md 5 "rounds of workgroups"); 1 = no tail plan
  *   HMME_STRIPS16=<n>     16-bit search kernel: that many equal window strips per job instead of the planner's number

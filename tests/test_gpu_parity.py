@@ -1165,6 +1165,30 @@ def test_job_table_cache_is_invisible():
     eng.close()
 
 
+def test_bench_n_rank_run_fails_loudly_when_a_rank_never_reaches_the_first_barrier(tmp_path):
+    """An N-rank run first happens unattended (the driver's 8-GPU node).  A rank that hangs in front of its first barrier -- here rank 1 is
+    made to sleep (HMME_BENCH_TEST_STALL) -- must not leave the job sitting in a collective: the waiting rank's watchdog ends it after
+    --rank-timeout with a line that names the rank and the stage, torch.distributed.run takes the rest down, bench.py's parent says which
+    ranks never passed the barrier, prints no result line and exits non-zero.  The diagnostics of every rank (device count, device, RCCL /
+    backend, ranks seen through the store) are on stderr before the first collective."""
+    import subprocess
+    import sys
+    import time
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HMME_BENCH_TEST_STALL"] = "1:120"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo", "--steps", "1", "--warmup", "0",
+                        "--size", "256x192", "--search-range", "8", "--no-cpu-baseline", "--rank-timeout", "10"], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode != 0, r.stdout[-500:]
+    assert time.time() - t0 < 100, "the stalled job was not ended by the watchdog"
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert "rank 0 of 2 did not get past 'first barrier" in r.stderr, r.stderr[-3000:]
+    assert "ranks that never passed their first barrier: [0, 1]" in r.stderr, r.stderr[-3000:]
+    assert "hipGetDeviceCount" in r.stderr and "ranks_seen 2 of 2" in r.stderr, r.stderr[-3000:]
+
+
 def test_refinement_launch_modes_give_the_same_tables():
     """HMME_FRAC_GRID: one workgroup per job (the default, whole-frame == oracle elsewhere in this file), n workgroups that take job
     after job from the launch's counter, and as many of those as the chip holds -- the same tables, whoever evaluates a job"""
@@ -1183,13 +1207,12 @@ def test_refinement_launch_modes_give_the_same_tables():
     for bd in ("8", "10"):
         assert crcs[("0", bd)] == crcs[("7", bd)] == crcs[("-1", bd)], crcs
     assert crcs[("0", "8")] != crcs[("0", "10")]
-    # the 8-bit kernel's two register budgets (two waves per SIMD without scratch: launches whose jobs are all resident at once, as this
-    # one's 104 are; three waves: the others) -- forced either way
-    for waves in ("2", "3"):
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "refine_rate.py"), "832x480", "8", "mixed"], capture_output=True, text=True,
-                           timeout=600, env=dict(os.environ, HMME_FRAC_WAVES=waves))
-        assert r.returncode == 0, r.stderr[-1500:]
-        assert json.loads(r.stdout.strip().splitlines()[-1])["tables_crc32"] == crcs[("0", "8")], waves
+    # HMME_FRAC_JOB_TABLE: the jobs read from a table that a kernel in front of the launch wrote (what the job-walking modes above do anyway)
+    # instead of derived inside each workgroup -- the same tables
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "refine_rate.py"), "832x480", "8", "mixed"], capture_output=True, text=True,
+                       timeout=600, env=dict(os.environ, HMME_FRAC_JOB_TABLE="1"))
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])["tables_crc32"] == crcs[("0", "8")]
 
 
 def test_sequence_driver_reads_a_yuv_file(tmp_path):

@@ -235,3 +235,79 @@ def test_gather_to_root_with_unequal_and_empty_shares_three_ranks_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got == (True, 1 * 3 * 593 * 4), got     # one table from rank 1, none from rank 2
+
+
+# ---- start-up of an unattended N-rank run: a rank that hangs before its first barrier must end the job loudly (bench.py --gpus N) ------
+def _startup_worker(rank, world, port, stall_rank, stall_s, limit_s, q):
+    sys.path.insert(0, os.path.join(ROOT, "hm-opencl_amd"))
+    from hmme import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import io
+    import time
+    msgs = io.StringIO()
+
+    def give_up(code):   # what os._exit would do, made visible to the parent first
+        q.put((rank, "watchdog", msgs.getvalue()))
+        q.close()
+        q.join_thread()   # the queue's feeder thread must have written the message before the process is gone
+        os._exit(code)
+
+    wd = shard.StartupWatchdog(rank, world, limit_s, label="test", _exit=give_up, _out=msgs)
+    wd.stage("init_process_group (rendezvous)")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    wd.stage("rendezvous store count")
+    seen = shard.rendezvous_report(rank, world, timeout_s=20.0, out=msgs)
+    if rank == stall_rank:
+        time.sleep(stall_s)
+    wd.stage("first barrier")
+    dist.barrier()
+    wd.done()
+    q.put((rank, "passed", seen))
+    dist.destroy_process_group()
+
+
+def _run_startup(stall_rank, stall_s, limit_s, world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_startup_worker, args=(r, world, port, stall_rank, stall_s, limit_s, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = []
+    import queue
+    try:
+        while len(got) < world:
+            got.append(q.get(timeout=60))
+            if got[-1][1] == "watchdog":
+                break
+    except queue.Empty:
+        pass
+    for p in procs:
+        p.join(timeout=20)
+        if p.is_alive():      # the rank left behind in the barrier by the one that gave up: what the launcher would take down
+            p.kill()
+            p.join()
+    return got, [p.exitcode for p in procs]
+
+
+def test_startup_watchdog_lets_a_healthy_start_through():
+    got, codes = _run_startup(stall_rank=-1, stall_s=0.0, limit_s=30.0)
+    assert sorted(g[0] for g in got) == [0, 1] and all(g[1] == "passed" for g in got), got
+    assert [g[2] for g in got if g[0] == 0] == [2]            # rank 0 counted both ranks through the store before the first collective
+    assert codes == [0, 0]
+
+
+def test_startup_watchdog_ends_the_rank_that_waits_for_a_sleeping_one():
+    """rank 1 sits still in front of the first barrier: rank 0, stuck in that barrier, gives up after its limit with exit code 3 and a line
+    that names itself and the stage -- the job fails instead of hanging"""
+    got, codes = _run_startup(stall_rank=1, stall_s=30.0, limit_s=3.0)
+    assert got and got[-1][1] == "watchdog", got
+    rank, _, text = got[-1]
+    assert f"rank {rank} of 2 did not get past" in text and ("first barrier" in text or "rendezvous" in text), text
+    assert 3 in codes, codes
+
+
+def test_shard_docstring_names_the_exchange_that_is_used():
+    from hmme import shard
+    assert "gather_to_root" in shard.__doc__ and "all_gather_into_tensor" not in shard.__doc__
