@@ -1007,6 +1007,11 @@ uint64_t hmme_test_device_address(const hmme_ctx* ctx, const hmme_plane* pl) {
   return ctx ? (uint64_t)(uintptr_t)(ctx->d_call + kCallCtu) : 0;
 }
 
+#ifdef ME_SEARCH_T_TIMELINE   // timing-only builds (tools/search16_timeline.py): the per-workgroup stamps me_search16_kernel left
+int hmme_test_timeline16(void* out, size_t bytes) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(hmme::g_timeline16), bytes < sizeof(hmme::g_timeline16) ? bytes : sizeof(hmme::g_timeline16)) == hipSuccess ? HMME_OK : HMME_ERR_DEVICE;
+}
+#endif
 int hmme_abi_version(void) { return HMME_ABI_VERSION; }
 #ifndef HMME_BUILD_ID
 #define HMME_BUILD_ID "unknown"

@@ -659,6 +659,9 @@ __device__ __forceinline__ uint32_t me_keymin3(uint32_t s0, uint32_t s1, uint32_
 #define ME16_KEYMIN_A(s0, s1, s2) me_keymin3(s0, s1, s2, mask_a, lsh_a, c0, c1, c2)
 #define ME16_KEYMIN_E(s0, s1, s2) me_keymin3(s0, s1, s2, mask_e, lsh_e, c0, c1, c2)
 
+#ifdef ME_SEARCH_T_TIMELINE   // timing-only builds: per workgroup of me_search16_kernel -- start, [per pass: window staged, wave 0 dry, all dry], end (100 MHz wall clock), hardware id
+__device__ uint32_t g_timeline16[16384 * 12];
+#endif
 template <int FEN, int PDW>
 __global__ void __launch_bounds__(kThreads16, 2)
 me_search16_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitch,
@@ -673,6 +676,14 @@ me_search16_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_
 #if ME_FAIR_PRIO
   if (fair_prio) __builtin_amdgcn_s_setprio(3);   // wave priority falls with the wave's progress: me_search_kernel
 #endif
+#ifdef ME_SEARCH_T_TIMELINE
+  const unsigned long long tl0 = wall_clock64();
+  uint32_t tl[8];
+  int tln = 0;
+#define ME16_STAMP() tl[tln++] = (uint32_t)(wall_clock64() - tl0)
+#else
+#define ME16_STAMP()
+#endif
   const MeJob16 jb = jobs[blockIdx.x];
   MeJob job = jb.j;
   const uint8_t* __restrict__ ref_base = refs.base[job.ctu_x & 63];
@@ -680,11 +691,6 @@ me_search16_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_
   job.ctu_x &= ~63;
   const int wx = job.rb_x - job.lt_x + 1;
   const int ny = jb.y1 - jb.y0;                                        // candidate rows of this strip
-#if ME_FAIR_PRIO
-  // lane-iterations of the two passes (even, odd columns), a quarter of one wave's share of them; state as in me_search_kernel
-  const int prio_quarter = fair_prio ? max(1, (((ny * ((((wx + 1) >> 1) + 2) / 3) + 63) >> 6) + ((ny * (((wx >> 1) + 2) / 3) + 63) >> 6) + 15) >> 4) : 0x0fffffff;
-  int prio_state = prio_quarter << 2;
-#endif
 
   for (int s = tid; s < kParts; s += kThreads16) best64[s] = ~0ull;
   // key = ((sum & mask) << lsh) + c  ==  (((sum << fen_shift) >> sh) << kIdxBits16) + c
@@ -730,6 +736,7 @@ me_search16_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_
       me_stage_window<PDW, kThreads16>(win, src_al, pitch_dw, n, mis, tid);
     }
     __syncthreads();
+    ME16_STAMP();
 
   const int n_par = (wx + 1 - par) >> 1;                               // candidates of this column parity per window row
   const int pairs = (n_par + 2) / 3;                                   // lanes per window row
@@ -744,13 +751,16 @@ me_search16_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_
     const int it0 = t;
     constexpr int n_it = 1;
 #if ME_FAIR_PRIO
-    if (prio_state < 4 && (prio_state & 3) < 3) {
-      prio_state += (prio_quarter << 2) + 1;
-      if ((prio_state & 3) == 1) __builtin_amdgcn_s_setprio(2);
-      else if ((prio_state & 3) == 2) __builtin_amdgcn_s_setprio(1);
+    // Priority by the WORKGROUP's progress (the pass and the half of its iterations the task counter has reached), the same for its
+    // four waves: they meet at a barrier after each pass, and per-wave levels (me_search_kernel's scheme) let the wave that had pulled
+    // one iteration more fall behind the others by another -- barrier waits of 100 us instead of 35 (profiles/r05q_search16_timeline.txt)
+    if (fair_prio) {
+      const int lvl = 2 * par + (2 * t >= n_tasks ? 1 : 0);
+      if (lvl == 0) __builtin_amdgcn_s_setprio(3);
+      else if (lvl == 1) __builtin_amdgcn_s_setprio(2);
+      else if (lvl == 2) __builtin_amdgcn_s_setprio(1);
       else __builtin_amdgcn_s_setprio(0);
     }
-    prio_state -= n_it << 2;
 #endif
     uint32_t b0 = ME_MAXKEY, b1 = ME_MAXKEY, b2 = ME_MAXKEY, b3 = ME_MAXKEY, b4 = ME_MAXKEY, b5 = ME_MAXKEY,
              b6 = ME_MAXKEY, b7 = ME_MAXKEY, b8 = ME_MAXKEY, b9 = ME_MAXKEY;
@@ -793,11 +803,27 @@ me_search16_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_
     ME_FLUSH16(5, b5) ME_FLUSH16(6, b6) ME_FLUSH16(7, b7) ME_FLUSH16(8, b8) ME_FLUSH16(9, b9)
 #undef ME_FLUSH16
   }
+    ME16_STAMP();   // this wave found the pass's counter dry
+#ifdef ME_SEARCH_T_TIMELINE
+    __syncthreads();
+    ME16_STAMP();   // all waves dry
+#endif
   }   // par
 #undef ME16_CUR
 #undef ME16_CUR_WAIT
   __syncthreads();
   for (int s = tid; s < kParts; s += kThreads16) atomicMin(&g_best[(long)jb.job * kParts + s], best64[s]);
+#ifdef ME_SEARCH_T_TIMELINE
+  if (tid == 0 && blockIdx.x < 16384) {
+    uint32_t* o = g_timeline16 + blockIdx.x * 12;
+    uint32_t hw_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    o[0] = (uint32_t)tl0; o[1] = (uint32_t)(tl0 >> 32);
+    for (int i = 0; i < 6; ++i) o[2 + i] = tl[i];
+    o[8] = (uint32_t)(wall_clock64() - tl0); o[9] = hw_id; o[10] = (uint32_t)ny; o[11] = (uint32_t)wx;
+  }
+#endif
+#undef ME16_STAMP
 }
 
 // strips of one CTU have merged into g_best: decode (cost, y, x) -> TComMv + pure SAD
@@ -1825,6 +1851,8 @@ __device__ __forceinline__ void me_frac_stage(const uint8_t* __restrict__ src, i
       }
     }
   } else {
+    // (the listed items in chunks of 64 lanes drawn from a counter by the four waves were measured too: no better than this static walk
+    // on mixed content, 1 % worse on unrelated pictures, and 14-46 spilled dwords in the u16 kernels)
     int n8 = 0;
 #pragma unroll 1
     for (int i8 = tid - NT;; i8 += NT) {   // first turn (i8 < 0 in every lane): the implicit item
@@ -1851,8 +1879,10 @@ __device__ __forceinline__ void me_frac_stage(const uint8_t* __restrict__ src, i
     }
     const int n4 = (int)counter[1];
 #ifndef ME_FRAC_T_NOITEMS
+    // (dealt from the last thread down: the partly filled last turn of the kind-8 walk above falls on the first waves, this one's on
+    // the last -- the waves reach the barrier that ends the stage closer together)
 #pragma unroll 1
-    for (int i4 = tid; i4 < n4; i4 += NT) {
+    for (int i4 = NT - 1 - tid; i4 < n4; i4 += NT) {
       const int pair = list4[i4];
       FracRaw<BPS> R;
       me_frac_fetch<STAGE, BPS, 0>(src, gpitch, st, cover, pair, 0, R);
