@@ -800,7 +800,7 @@ def _fuzz_case(engine, oracle_lib, seed):
     assert np.array_equal(mv[:, :, 0], ox) and np.array_equal(mv[:, :, 1], oy) and np.array_equal(sad, osad), tag
     table = oracle_lib.slot_table()
     ctus_x = (w + 63) // 64
-    for k in range(12):
+    for k in range(int(os.environ.get("HMME_FUZZ_SLOTS", "12"))):
         ctu, s = int(rng.integers(0, n)), int(rng.integers(0, 593))
         cx, cy = (ctu % ctus_x) * 64, (ctu // ctus_x) * 64
         x, y, bw, bh = (int(v) for v in table[s])
