@@ -650,9 +650,9 @@ int hmme_slot_rect(int slot, int* x, int* y, int* w, int* h) {
 namespace {
 int build_frac_cover(hmme_ctx* ctx);
 using frac_fn = void (*)(const RefSet, int, const RefSet, int, const MeJob*, const hmme::FracPrep, int, uint32_t*, const uint16_t*, const int16_t*, uint32_t, int, const hmme::FracWp, int16_t*, uint32_t*);
-// The 8-bit kernel runs at two waves per SIMD (249..256 VGPRs, no scratch) and two workgroups per CU: each workgroup's LDS block holds
-// the patch rows of every lane's next item (LDS-DMA, me_frac_stage).  Round 4's three-wave build (168 VGPRs + 50 spilled dwords per
-// lane: 104 MB of scratch writes per 2160p launch) is gone.
+// One build per (sample width, distortion, weighting) at two waves per SIMD: the 8-bit kernels spill nothing (231 / 237 VGPRs), two
+// workgroups per CU.  Round 4's three-wave build of the 8-bit kernel (168 VGPRs + 50 spilled dwords per lane: 104 MB of scratch writes
+// per 2160p launch) is gone.
 inline frac_fn frac_kernel(int wide, int had, int wp = 0) {
   static const frac_fn fns[2][2] = {{hmme::me_frac_kernel<0, 1, 0, 2>, hmme::me_frac_kernel<1, 1, 0, 2>}, {hmme::me_frac_kernel<0, 2, 0>, hmme::me_frac_kernel<1, 2, 0>}};
   static const frac_fn fns_wp[2] = {hmme::me_frac_kernel<0, 2, 1>, hmme::me_frac_kernel<1, 2, 1>};   // weighted calls always stage u16 samples
@@ -1355,7 +1355,7 @@ int hmme_refine_pairs_device(hmme_ctx* ctx, const hmme_plane* const* curs, const
     const int had = use_hadamard ? 1 : 0, wide = curs[0]->bps == 2 ? 1 : 0;
     const int grid = frac_grid(ctx, wide, had, jobs);
     // one workgroup per job (the default) on the two-wave builds: every workgroup derives its job itself (FracPrep) -- no job table, no
-    // launch in front of this one (1080p: 0.095 -> 0.090 ms).  The three-wave build reads a table (me_frac_kernel), and so does the
+    // launch in front of this one (1080p: 0.095 -> 0.090 ms).  A table is read by the
     // job-walking launch of HMME_FRAC_GRID: its prep kernel is also what resets the job counter
     const hmme::FracPrep prep = {(const int16_t*)d_pred_q, (uint32_t)pl.first | (uint32_t)pl.count << 16, (uint32_t)curs[0]->width | (uint32_t)curs[0]->height << 16, fp->search_range};
     static const bool table = std::getenv("HMME_FRAC_JOB_TABLE") != nullptr;   // A/B: the job table and its kernel as before

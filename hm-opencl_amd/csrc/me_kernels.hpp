@@ -1021,7 +1021,7 @@ constexpr int frac_acc_dw(int bps) { return (593 * frac_acc_row(bps) + 15) & ~15
 static_assert(64 * 32640 < (1 << 21) && 4096 * 255 < (1 << 21), "me_frac_kernel: a packed sum field holds the largest 8-bit slot sum");
 constexpr int frac_threads(int bps) { return 256; }
 // sums [593][9] | slot states | tap tables, counters | the two work lists | current block | cover table (uint16 [64][18] + [256][6])
-#ifndef ME_FRAC_T_LDS_PAD   // timing-only: LDS bytes a workgroup asks for beyond its need (56 KiB in all = two workgroups per CU with the three-wave register budget)
+#ifndef ME_FRAC_T_LDS_PAD   // timing-only: LDS bytes a workgroup asks for beyond its need (occupancy experiments)
 #define ME_FRAC_T_LDS_PAD 0
 #endif
 // 8-bit planes: + the patch rows of each lane's NEXT item, written by LDS-DMA while the current item is evaluated (me_frac_stage):
@@ -1922,11 +1922,10 @@ __device__ __forceinline__ int me_frac_deal(int k, int n_jobs, const FracPrep& p
   return pair * n_ctu + ctu;
 }
 
-// WAVES: waves per SIMD the register budget is cut for.  The 8-bit kernel wants 230 VGPRs.  At two waves (no scratch) a job takes
-// 1 / 1.27 of its time at three (168 VGPRs + 46 spilled dwords per lane, three workgroups sharing a CU), at three waves a CU holds
-// half as many jobs again: two waves win while the launch is a round or two of 2 x CUs workgroups (a per-CTU call, a 1080p or 1440p
-// picture pair: -9 %, -10 %), three waves from there on (2160p: 2 040 jobs = 4 rounds against 3: +5 %).  The host picks (hmme.hip
-// frac_kernel); the u16 kernel fits two waves without scratch.
+// WAVES: waves per SIMD the register budget is cut for.  The kernel runs at two (8-bit planes: 237 VGPRs, nothing spilled; two workgroups
+// per CU).  Round 4 also ran the 8-bit kernel at three waves for large launches (168 VGPRs + 50 spilled dwords per lane: 104 MB of
+// scratch writes per 2160p launch); the round-5 flow made the two-wave build the faster one on content that shares its motion and
+// the only one without scratch -- on unrelated pictures the third wave's occupancy would still be worth 6 %.
 template <int HAD, int BPS, int WP, int WAVES = 2>
 __global__ void __launch_bounds__(frac_threads(BPS), WAVES)
 me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitch,
@@ -1998,9 +1997,7 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
 #define ME_FRAC_STAMP()
 #endif
   MeJob job;
-  // (the three-wave build always reads a table: the few registers the derivation holds across the kernel cost it 48 B more scratch per
-  // lane and 3 % of its time -- more than the launch it saves, hmme.hip hmme_refine_pairs_device)
-  if (WAVES == 3 || jobs) {
+  if (jobs) {   // a table (job-walking launches, HMME_FRAC_JOB_TABLE, CTU ranges beyond 16 bits), else the job derived here
     job = jobs[jb];
   } else {   // job jb = pair jb / ctu_count, CTU ctu_first + jb % ctu_count
     const int ctu_first = (int)(prep.ctus & 0xffff), ctu_count = (int)(prep.ctus >> 16), pic_w = (int)(prep.dims & 0xffff), pic_h = (int)(prep.dims >> 16);
