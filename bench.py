@@ -307,7 +307,7 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-gpu: rehearse the N > 1 code path on a one-GPU box (not a measurement)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
-    ap.add_argument("--rank-timeout", type=float, default=240.0,
+    ap.add_argument("--rank-timeout", type=float, default=600.0,
                     help="N > 1: seconds a rank may take from its start to the end of its first barrier (rendezvous, RCCL communicator) before it "
                          "gives up with exit code 3, naming itself and the stage it hung in; 0 = no limit")
     ap.add_argument("--launch-timeout", type=float, default=1500.0,
