@@ -206,8 +206,11 @@ def verify_against_oracle(res, cur, ref, w, h, sr, lq, bd, what="tables of the t
     from hmme import synth
     m = synth.MARGIN
     ctus_x, ctus_y = (w + 63) // 64, (h + 63) // 64
-    if sample is None:
-        sample = sorted({0, ctus_x * (ctus_y // 2) + ctus_x // 3, ctus_x * ctus_y - 1, ctus_x * (ctus_y - 1) + ctus_x // 2})
+    if sample is None:   # the four corners, one CTU of each edge (the bottom row is partial at 2160 / 1080 rows), four interior CTUs
+        sample = sorted({0, ctus_x - 1, ctus_x * (ctus_y - 1), ctus_x * ctus_y - 1,
+                         ctus_x // 2, ctus_x * (ctus_y // 2), ctus_x * (ctus_y // 2 + 1) - 1, ctus_x * (ctus_y - 1) + ctus_x // 2,
+                         ctus_x * (ctus_y // 2) + ctus_x // 3, ctus_x * (ctus_y // 3) + ctus_x // 2, ctus_x * (2 * ctus_y // 3) + 2 * ctus_x // 3,
+                         ctus_x * (ctus_y // 4) + ctus_x // 5})
     mv = np.ascontiguousarray(res[0, 0]).view(np.int16).reshape(res.shape[2], 593, 2)
     sad = res[1, 0].view(np.uint32)
     t0 = time.time()
