@@ -1009,7 +1009,7 @@ __global__ void me_prep_jobs_tile_kernel(MeJob16* jobs, int* first_strip_of_job,
 // BPS = bytes per sample of the planes (1: 8-bit video, 2: 9..12 bit)
 // 8-bit planes: the nine sums of a slot are three 64-bit words of three 21-bit fields each (points 3k, 3k + 1, 3k + 2 of word k), added
 // with ds_add_u64 -- a third of the LDS atomics, which on content whose slots share their motion were 40 % of an item's time (up to sixteen
-// lanes of a wave add to the same large slot: profiles/r05g_frac_phases.txt).  A field never carries into the next: the largest sum is the
+// lanes of a wave add to the same large slot: profiles/r05k_frac_phases_before_after.txt).  A field never carries into the next: the largest sum is the
 // 64x64 slot's, 64 8x8 Hadamard blocks of at most 8 * 64 * 255 / 4 = 32 640 each (Parseval) = 2 088 960 < 2^21; SAD 64 * 64 * 255.
 // Wider samples (and the biased ones of bi-prediction origins) keep nine 32-bit sums.
 #ifndef ME_FRAC_PACK3
@@ -1775,7 +1775,7 @@ __device__ __forceinline__ void me_frac_dedupe4(const uint32_t* st, const uint16
 // of the work lists (the remaining distinct (position, key) pairs) while the rows are on their way, evaluates the item, and only then meets
 // the other waves at the barrier that completes the lists.  On content whose slots share their motion the lists stay empty and a stage is
 // one item per lane; the list phase used to be a barrier-separated 2.5 .. 3.5 us of dependent LDS round trips in front of every stage's
-// items (profiles/r05g_frac_phases.txt).  The listed items follow: kind-8 items (whole quads), then kind-4 items.  (Round 4 built the walk
+// items (profiles/r05k_frac_phases_before_after.txt).  The listed items follow: kind-8 items (whole quads), then kind-4 items.  (Round 4 built the walk
 // over the listed items software-pipelined -- the next item's rows requested before the current item is evaluated -- slower on every content,
 // profiles/r04a_frac_pipelined_vs_plain_ab.txt.)
 template <int STAGE, int HAD, int BPS, int WP>
@@ -1898,7 +1898,7 @@ __device__ __forceinline__ void me_frac_stage(const uint8_t* __restrict__ src, i
 // Which job the k-th workgroup (or the k-th draw from the job counter) takes.  A launch ends one job time after its last job STARTS, and
 // the CTUs on the picture's edge are the slow ones: their slots reach into the padding (a partial bottom row most of all: 2160 = 33 x 64
 // + 48), find MVs of their own there and share little -- 2-3 x the time of an interior CTU (profiles/r04k_frac_timeline.txt: the bottom
-// row dealt last kept a 2160p launch alive for an extra job time; profiles/r05j_frac_phases.txt: so did the TOP row once the table
+// row dealt last kept a 2160p launch alive for an extra job time; profiles/r05k_frac_phases_before_after.txt: so did the TOP row once the table
 // was simply dealt from its end).  So the edge CTUs of every pair go first -- bottom row, top row, left and right column -- then the
 // interiors.  Launches over a CTU sub-range (and pictures less than three CTUs wide or high) keep the plain last-first order.
 __device__ __forceinline__ int me_frac_deal(int k, int n_jobs, const FracPrep& prep) {
