@@ -1115,7 +1115,8 @@ def test_job_table_cache_is_invisible():
     """launches without predictors keep their job table for the next launch of the same geometry (hmme.hip TableTag): a sequence that
     revisits geometries, slips launches WITH predictors in between (they overwrite the table) and changes the CTU range gives, call
     by call, what a fresh context gives for that call alone -- search tables (8-bit whole jobs with a tail plan, 10-bit strips) and
-    the table of the refinement's three-wave build (2160p: 2 040 jobs)"""
+    whole-picture refinement launches (2160p: 2 040 jobs; their workgroups derive their jobs themselves since round 5, a table is
+    read only by the job-walking modes and under HMME_FRAC_JOB_TABLE=1, which test_refinement_launch_modes_give_the_same_tables runs)"""
     from hmme import api, synth
     m = synth.MARGIN
 
@@ -1148,7 +1149,7 @@ def test_job_table_cache_is_invisible():
         fresh.close()
         for a, b in zip(got, want):
             assert np.array_equal(a, b), (step, k, pk, first, count)
-    # the refinement's own table (three-wave build): 2160p, without / with / without predictors
+    # whole-picture refinement at 2160p, without / with / without predictors
     w, h, sr = 3840, 2160, 16
     big = planes(eng, w, h, 8, seed=77)
     n = api.load().hmme_num_ctus(w, h)
