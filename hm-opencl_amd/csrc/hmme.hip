@@ -1012,6 +1012,14 @@ int hmme_test_timeline16(void* out, size_t bytes) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(hmme::g_timeline16), bytes < sizeof(hmme::g_timeline16) ? bytes : sizeof(hmme::g_timeline16)) == hipSuccess ? HMME_OK : HMME_ERR_DEVICE;
 }
 #endif
+int hmme_test_frac_deal(int k, int n_pairs, int width, int height) {
+  if (n_pairs < 1 || width < 8 || height < 8 || width > 16384 || height > 16384) return -1;
+  const int n_ctu = hmme_num_ctus(width, height);
+  if (n_ctu > 0xffff || k < 0 || k >= n_pairs * n_ctu) return -1;
+  const hmme::FracPrep prep = {nullptr, (uint32_t)n_ctu << 16, (uint32_t)width | (uint32_t)height << 16, 0};
+  return hmme::me_frac_deal(k, n_pairs * n_ctu, prep);
+}
+
 int hmme_abi_version(void) { return HMME_ABI_VERSION; }
 #ifndef HMME_BUILD_ID
 #define HMME_BUILD_ID "unknown"

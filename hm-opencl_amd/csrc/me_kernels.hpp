@@ -1901,7 +1901,7 @@ __device__ __forceinline__ void me_frac_stage(const uint8_t* __restrict__ src, i
 // row dealt last kept a 2160p launch alive for an extra job time; profiles/r05k_frac_phases_before_after.txt: so did the TOP row once the table
 // was simply dealt from its end).  So the edge CTUs of every pair go first -- bottom row, top row, left and right column -- then the
 // interiors.  Launches over a CTU sub-range (and pictures less than three CTUs wide or high) keep the plain last-first order.
-__device__ __forceinline__ int me_frac_deal(int k, int n_jobs, const FracPrep& prep) {
+__host__ __device__ inline int me_frac_deal(int k, int n_jobs, const FracPrep& prep) {
   const int first = (int)(prep.ctus & 0xffff), count = (int)(prep.ctus >> 16);
   const int X = ((int)(prep.dims & 0xffff) + 63) >> 6, Y = ((int)(prep.dims >> 16) + 63) >> 6, n_ctu = X * Y;
   if (first != 0 || count != n_ctu || X < 3 || Y < 3 || n_jobs % n_ctu) return n_jobs - 1 - k;

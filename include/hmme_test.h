@@ -18,6 +18,10 @@ int hmme_test_time_search_kernel(hmme_ctx* ctx, const hmme_plane* cur, const hmm
                                  const void* d_pred_q, void* d_out_mv, void* d_out_sad, void* stream, int reps,
                                  float* avg_ms);
 
+/* which job the k-th workgroup of a refinement launch over `n_pairs` whole pictures of width x height takes (me_frac_deal, me_kernels.hpp:
+ * edge CTUs of every pair first, then the interiors); host code, needs no device.  -1 for k outside the launch */
+int hmme_test_frac_deal(int k, int n_pairs, int width, int height);
+
 #ifdef __cplusplus
 }
 #endif

@@ -221,3 +221,47 @@ def test_cpp_sequence_driver_is_clean_under_asan_and_ubsan(tmp_path):
                UBSAN_OPTIONS="print_stacktrace=1")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-1500:] + r.stderr[-4000:]
+
+
+def test_refinement_jobs_are_dealt_as_a_permutation_with_the_edge_ctus_first():
+    """me_frac_deal (host + device function): workgroup k of a whole-picture refinement launch takes job hmme_test_frac_deal(k) -- every job of
+    every pair exactly once, the CTUs on the picture's edge (bottom row, top row, side columns) of all pairs before any interior CTU; pictures
+    less than three CTUs wide or high are dealt from the end of the table"""
+    from hmme import api
+    L = api.load()
+    for (w, h, pairs) in ((3840, 2160, 1), (1920, 1080, 4), (832, 480, 3), (200, 192, 2), (64, 64, 1), (136, 72, 5), (16384, 128, 1)):
+        X, Y = (w + 63) // 64, (h + 63) // 64
+        n = X * Y
+        deal = [L.hmme_test_frac_deal(k, pairs, w, h) for k in range(pairs * n)]
+        assert sorted(deal) == list(range(pairs * n)), (w, h, pairs)
+        assert L.hmme_test_frac_deal(pairs * n, pairs, w, h) == -1 and L.hmme_test_frac_deal(-1, pairs, w, h) == -1
+        if X >= 3 and Y >= 3:
+            edge = lambda j: (j % n) % X in (0, X - 1) or (j % n) // X in (0, Y - 1)
+            n_edge = pairs * (2 * X + 2 * (Y - 2))
+            assert all(edge(j) for j in deal[:n_edge]) and not any(edge(j) for j in deal[n_edge:]), (w, h, pairs)
+            assert [j % n for j in deal[:X]] == list(range((Y - 1) * X, n))      # the (possibly partial) bottom row goes first
+        else:
+            assert deal == list(range(pairs * n - 1, -1, -1))
+
+
+def test_bench_counts_the_candidates_actually_searched():
+    """bench.py's work count with per-CTU predictors = sum over CTUs of (in-picture 4x4 blocks) x (candidates of the window the oracle's
+    xSetSearchRange + clipMv restatement gives for that CTU's predictor)"""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from hmme import api, synth
+    import ctypes as C
+    import oracle_py as O
+    w, h, sr = 832, 480, 64
+    n = ((w + 63) // 64) * ((h + 63) // 64)
+    pred = synth.random_predictors(n, seed=5, max_pel=16)
+    total = 0
+    for ctu in range(n):
+        cx, cy = (ctu % ((w + 63) // 64)) * 64, (ctu // ((w + 63) // 64)) * 64
+        lt = [C.c_int() for _ in range(4)]   # (pred_x, pred_y, sr, cu_x, cu_y, pic_w, pic_h, max_cu) -> lt_x, lt_y, rb_x, rb_y
+        O.oracle().hmo_set_search_range(int(pred[ctu, 0]), int(pred[ctu, 1]), sr, cx, cy, w, h, 64, *[C.byref(v) for v in lt])
+        lt_x, lt_y, rb_x, rb_y = (v.value for v in lt)
+        total += (min(64, w - cx) // 4) * (min(64, h - cy) // 4) * (rb_x - lt_x + 1) * (rb_y - lt_y + 1)
+    assert bench.work_4x4_sads(api, w, h, sr, pred) == total
+    assert bench.work_4x4_sads(api, w, h, sr) >= total * 0.95 and bench.work_4x4_sads(api, w, h, sr) != total
