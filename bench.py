@@ -663,10 +663,10 @@ def main():
         seen = shard.rendezvous_report(rank, world, timeout_s=max(10.0, args.rank_timeout / 2) if args.rank_timeout > 0 else 120.0)
         if rank == 0 and seen != world:
             raise SystemExit(f"bench.py: only {seen} of {world} ranks reached the rendezvous store: nothing reported")
+        watchdog.stage("first barrier (RCCL communicator)" if args.backend == "nccl" else "first barrier")
         stall = os.environ.get("HMME_BENCH_TEST_STALL", "")   # tests: "<rank>:<seconds>" -- that rank sits still in front of its first barrier
         if stall and int(stall.split(":")[0]) == rank:
             time.sleep(float(stall.split(":")[1]))
-        watchdog.stage("first barrier (RCCL communicator)" if args.backend == "nccl" else "first barrier")
         dist.barrier()
         if args.backend == "nccl":
             torch.cuda.synchronize()

@@ -1168,7 +1168,7 @@ def test_job_table_cache_is_invisible():
 
 def test_bench_n_rank_run_fails_loudly_when_a_rank_never_reaches_the_first_barrier(tmp_path):
     """An N-rank run first happens unattended (the driver's 8-GPU node).  A rank that hangs in front of its first barrier -- here rank 1 is
-    made to sleep (HMME_BENCH_TEST_STALL) -- must not leave the job sitting in a collective: the waiting rank's watchdog ends it after
+    made to sleep (HMME_BENCH_TEST_STALL) -- must not leave the job sitting in a collective: a rank's watchdog ends it after
     --rank-timeout with a line that names the rank and the stage, torch.distributed.run takes the rest down, bench.py's parent says which
     ranks never passed the barrier, prints no result line and exits non-zero.  The diagnostics of every rank (device count, device, RCCL /
     backend, ranks seen through the store) are on stderr before the first collective."""
@@ -1180,12 +1180,15 @@ def test_bench_n_rank_run_fails_loudly_when_a_rank_never_reaches_the_first_barri
     env["HMME_BENCH_TEST_STALL"] = "1:120"
     t0 = time.time()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo", "--steps", "1", "--warmup", "0",
-                        "--size", "256x192", "--search-range", "8", "--no-cpu-baseline", "--rank-timeout", "10"], capture_output=True, text=True,
+                        "--size", "256x192", "--search-range", "8", "--no-cpu-baseline", "--rank-timeout", "20"], capture_output=True, text=True,
                        timeout=600, env=env, cwd=str(tmp_path))
     assert r.returncode != 0, r.stdout[-500:]
-    assert time.time() - t0 < 100, "the stalled job was not ended by the watchdog"
+    assert time.time() - t0 < 110, "the stalled job was not ended by the watchdog"
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
-    assert "rank 0 of 2 did not get past 'first barrier" in r.stderr, r.stderr[-3000:]
+    # (both ranks' watchdogs run out at about the same time -- the sleeping rank's as well as the one waiting for it in the barrier --
+    # and the launcher ends the other as soon as one has given up: either rank may be the one that is named)
+    import re
+    assert re.search(r"rank [01] of 2 did not get past '[a-z_ ()A-Z]+' within 20 s", r.stderr), r.stderr[-3000:]
     assert "ranks that never passed their first barrier: [0, 1]" in r.stderr, r.stderr[-3000:]
     assert "hipGetDeviceCount" in r.stderr and "ranks_seen 2 of 2" in r.stderr, r.stderr[-3000:]
 
