@@ -1093,6 +1093,14 @@ __device__ __forceinline__ float me_dpp_f(float v, const int ctrl_b1) {
                  : __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));
 }
 
+// max(|a|, |b|) in ONE instruction: fmaxf() of two fabsf() compiles to three (llvm.maxnum quiets signalling NaNs first: a
+// v_max_f32 x, |x|, |x| per operand in IEEE mode); no NaN ever reaches these
+__device__ __forceinline__ float me_absmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // distortion of one 4x4 difference block d (row-major): SAD, or the Hadamard sum (xCalcHADs4x4; with KIND8 the quad's four 4x4
 // transforms are combined into the 8x8 transform, xCalcHADs8x8, and all four lanes return the block's value)
 // want4 (wave-uniform, KIND8 only): also return in `own4` what this lane's 4x4 block alone contributes to a slot made of 4x4 blocks
@@ -1117,19 +1125,23 @@ __device__ __forceinline__ uint32_t me_frac_dist(const float (&d)[16], float s1,
       const float a = d[4 * r] + d[4 * r + 3], b = d[4 * r + 1] + d[4 * r + 2], e = d[4 * r + 1] - d[4 * r + 2], f = d[4 * r] - d[4 * r + 3];
       m[4 * r] = a + b; m[4 * r + 1] = a - b; m[4 * r + 2] = f + e; m[4 * r + 3] = f - e;
     }
+    // columns, first level; z = {a, b, e, f}[k].  The second level would be a + b, a - b, f + e, f - e -- but only the sum of the
+    // absolute coefficients is wanted and |a + b| + |a - b| = 2 max(|a|, |b|): the level and its sixteen absolute adds become eight
+    // v_max_f32 (|.| is a source modifier) and eight adds of HALF the sum.  The levels of a Walsh-Hadamard transform commute, so with
+    // KIND8 the two levels across the quad run BEFORE that last one -- and the lane's own 4x4 sum (want4) is the same eight maxima
+    // taken before them.
     float z[16];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float a = m[k] + m[12 + k], b = m[4 + k] + m[8 + k], e = m[4 + k] - m[8 + k], f = m[k] - m[12 + k];
-      z[k] = a + b; z[4 + k] = a - b; z[8 + k] = f + e; z[12 + k] = f - e;
+      z[k] = m[k] + m[12 + k]; z[4 + k] = m[4 + k] + m[8 + k]; z[8 + k] = m[4 + k] - m[8 + k]; z[12 + k] = m[k] - m[12 + k];
     }
     float sum = 0.f;
     if (KIND8) {   // combine the quad's four 4x4 transforms into the 8x8 transform (xCalcHADs8x8)
-      if (want4) {   // xCalcHADs4x4 of this block, as the 4x4 kind computes it
+      if (want4) {   // xCalcHADs4x4 of this block, as the 4x4 kind computes it: ((2 * s4) + 1) >> 1
         float s4 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s4 += __builtin_fabsf(z[i]);
-        own4 = ((uint32_t)s4 + 1) >> 1;
+        for (int k = 0; k < 4; ++k) { const float t = me_absmax(z[k], z[4 + k]) + me_absmax(z[8 + k], z[12 + k]); s4 = k ? s4 + t : t; }
+        own4 = (uint32_t)s4;
       }
       // two butterflies across the quad, each one v_fmac_f32 with a DPP source: z += t * z[neighbour], t = +-1 by
       // role.  Odd roles hold the negated difference, which the absolute sum does not see.  One asm block keeps
@@ -1147,14 +1159,15 @@ __device__ __forceinline__ uint32_t me_frac_dist(const float (&d)[16], float s1,
             "+v"(z[10]), "+v"(z[11]), "+v"(z[12]), "+v"(z[13]), "+v"(z[14]), "+v"(z[15])
           : "v"(s1), "v"(s2));
 #pragma unroll
-      for (int i = 0; i < 16; ++i) sum += __builtin_fabsf(z[i]);
+      for (int k = 0; k < 4; ++k) { const float t = me_absmax(z[k], z[4 + k]) + me_absmax(z[8 + k], z[12 + k]); sum = k ? sum + t : t; }
+      sum += sum;
       sum += me_dpp_f(sum, 1);
       sum += me_dpp_f(sum, 0);
       contrib = ((uint32_t)sum + 2) >> 2;
     } else {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) sum += __builtin_fabsf(z[i]);
-      contrib = ((uint32_t)sum + 1) >> 1;
+      for (int k = 0; k < 4; ++k) { const float t = me_absmax(z[k], z[4 + k]) + me_absmax(z[8 + k], z[12 + k]); sum = k ? sum + t : t; }
+      contrib = (uint32_t)sum;   // (2 * sum + 1) >> 1
     }
   }
   return contrib;
@@ -1179,18 +1192,20 @@ __device__ __forceinline__ uint32_t me_frac_had_pk(const v2f (&P)[4][2], float s
     B[0][h] = A[0][h] + A[1][h]; B[1][h] = A[0][h] - A[1][h]; B[2][h] = A[2][h] + A[3][h]; B[3][h] = A[2][h] - A[3][h];
     C[0][h] = B[0][h] + B[2][h]; C[2][h] = B[0][h] - B[2][h]; C[1][h] = B[1][h] + B[3][h]; C[3][h] = B[1][h] - B[3][h];
   }
+  // the level that pairs the two halves of a register comes last and is never carried out: |x + y| + |x - y| = 2 max(|x|, |y|)
+  // (me_frac_dist); with KIND8 the two levels across the quad run before it, the lane's own 4x4 sum is taken before those
   float z[16];
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) { z[4 * r + 2 * h] = C[r][h].x + C[r][h].y; z[4 * r + 2 * h + 1] = C[r][h].x - C[r][h].y; }
+    for (int h = 0; h < 2; ++h) { z[4 * r + 2 * h] = C[r][h].x; z[4 * r + 2 * h + 1] = C[r][h].y; }
   float sum = 0.f;
   if (KIND8) {
     if (want4) {
       float s4 = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s4 += __builtin_fabsf(z[i]);
-      own4 = ((uint32_t)s4 + 1) >> 1;
+      for (int i = 0; i < 8; ++i) { const float t = me_absmax(z[2 * i], z[2 * i + 1]); s4 = i ? s4 + t : t; }
+      own4 = (uint32_t)s4;
     }
     asm("s_nop 1\n\t"
         ME_FRAC_BFLY(%0, %16, "[1,0,3,2]") ME_FRAC_BFLY(%1, %16, "[1,0,3,2]") ME_FRAC_BFLY(%2, %16, "[1,0,3,2]") ME_FRAC_BFLY(%3, %16, "[1,0,3,2]")
@@ -1205,14 +1220,15 @@ __device__ __forceinline__ uint32_t me_frac_had_pk(const v2f (&P)[4][2], float s
           "+v"(z[10]), "+v"(z[11]), "+v"(z[12]), "+v"(z[13]), "+v"(z[14]), "+v"(z[15])
         : "v"(s1), "v"(s2));
 #pragma unroll
-    for (int i = 0; i < 16; ++i) sum += __builtin_fabsf(z[i]);
+    for (int i = 0; i < 8; ++i) { const float t = me_absmax(z[2 * i], z[2 * i + 1]); sum = i ? sum + t : t; }
+    sum += sum;
     sum += me_dpp_f(sum, 1);
     sum += me_dpp_f(sum, 0);
     return ((uint32_t)sum + 2) >> 2;
   }
 #pragma unroll
-  for (int i = 0; i < 16; ++i) sum += __builtin_fabsf(z[i]);
-  return ((uint32_t)sum + 1) >> 1;
+  for (int i = 0; i < 8; ++i) { const float t = me_absmax(z[2 * i], z[2 * i + 1]); sum = i ? sum + t : t; }
+  return (uint32_t)sum;   // (2 * sum + 1) >> 1
 }
 #endif
 
