@@ -1026,6 +1026,11 @@ constexpr int frac_threads(int bps) { return 256; }
 #endif
 // 8-bit planes: + the patch rows of each lane's NEXT item, written by LDS-DMA while the current item is evaluated (me_frac_stage):
 // 12 rows x 16 B x 256 lanes = 48 KiB.  80 KiB a workgroup, two workgroups a CU -- which is what the kernel's registers allow anyway
+#ifdef ME_FRAC_RIDE_ANY
+#define ME_FRAC_RIDE_LISTED 1
+#else
+#define ME_FRAC_RIDE_LISTED 0
+#endif
 #ifndef ME_FRAC_GLDS   // measured: no faster than plain loads on any content (profiles/r05j_frac_glds_ab.txt) -- the items do not wait for their rows
 #define ME_FRAC_GLDS 0
 #endif
@@ -1629,7 +1634,7 @@ __device__ __forceinline__ void me_frac_fetch(const uint8_t* __restrict__ src, i
 
 template <int STAGE, int HAD, int BPS, int KIND8, int WP>
 __device__ __forceinline__ void me_frac_compute(const FracRaw<BPS>& R, const uint32_t* curl, const uint32_t* st, const uint16_t* cover, int pair, int role,
-                                                int bd, float clip_lo, const FracWp wp, const uint32_t* tab_h, const float* tab_v, uint32_t* acc) {
+                                                int bd, float clip_lo, const FracWp wp, const uint32_t* tab_h, const float* tab_v, uint32_t* acc, bool ride) {
   constexpr int PW = 3 * BPS, NCOV = KIND8 ? kFracCover8 : kFracCover4;
   constexpr uint32_t keymask = STAGE ? kFracKey1 : kFracKey0;
   const int q = KIND8 ? pair : pair - kFracPairs8;
@@ -1661,9 +1666,12 @@ __device__ __forceinline__ void me_frac_compute(const FracRaw<BPS>& R, const uin
   // Slots made of 4x4 blocks (the AMP shapes at 16, 8x4, 4x8: six per 4x4 position) whose key equals this item's get this lane's 4x4
   // block for nothing: same patch, same interpolated samples, same difference, same 4x4 transform -- the work-list pass left such
   // (4x4 position, key) pairs out of the 4x4 list (me_frac_dedupe4).  On coherent content that is every one of them.
+  // `ride` (wave-uniform): only a position's IMPLICIT item carries riders.  A listed kind-8 item used to as well; but one rider in a
+  // wave makes all 64 lanes compute their own 4x4 sums at all nine points (7 % of an item), and on content whose slots do not share
+  // their motion nearly every wave had one and nearly no lane needed it -- as an item of its own that rider costs one LANE of a wave.
   uint32_t match4 = 0;
   const uint16_t* cov4 = cover + kFracPairs8 + (by * 16 + bx) * kFracCover4;
-  if (KIND8) {
+  if (KIND8 && ride) {
 #pragma unroll
     for (int k = 0; k < kFracCover4; ++k) match4 |= (((st[cov4[k]] ^ sv) & keymask) == 0 ? 1u : 0u) << k;
   }
@@ -1754,8 +1762,8 @@ __device__ __forceinline__ void me_frac_dedupe(const uint32_t* st, const uint16_
   }
 }
 
-// the 4x4 kind: a (4x4 position, key) pair is listed only if no slot of the 8x8 kind covers the position with the same key -- otherwise the
-// lane of that 8x8 item that owns this 4x4 block hands its result to the 4x4-kind slots as well (me_frac_compute)
+// the 4x4 kind: a (4x4 position, key) pair is listed unless its key is that of the position's 8x8 slot -- then the lane of the position's
+// implicit item that owns this 4x4 block hands its result to the 4x4-kind slots as well (me_frac_compute, `ride`)
 __device__ __forceinline__ void me_frac_dedupe4(const uint32_t* st, const uint16_t* cover, int p4, uint32_t keymask, uint32_t* counter, uint16_t* list) {
   const uint16_t* cov = cover + kFracPairs8 + p4 * kFracCover4;
   const uint16_t* cov8 = cover + (((p4 >> 4) >> 1) * 8 + ((p4 & 15) >> 1)) * kFracCover8;   // the 8x8 position that holds block (p4 & 15, p4 >> 4)
@@ -1775,12 +1783,14 @@ __device__ __forceinline__ void me_frac_dedupe4(const uint32_t* st, const uint16
 #pragma unroll
     for (int k = 0; k < j; ++k) first[j] = first[j] && key[k] != key[j];
   }
+#ifdef ME_FRAC_RIDE_ANY   // A/B: riders on listed kind-8 items too (round 4 / early round 5)
 #pragma unroll
   for (int k = 1; k < kFracCover8; ++k) {
     const uint32_t k8 = st[cov8[k]] & keymask;
 #pragma unroll
     for (int j = 0; j < kFracCover4; ++j) first[j] = first[j] && key[j] != k8;
   }
+#endif
 #pragma unroll
   for (int j = 0; j < kFracCover4; ++j)
     if (first[j]) list[atomicAdd(counter, 1u)] = (uint16_t)(kFracPairs8 + p4 * kFracCover4 + j);
@@ -1841,7 +1851,7 @@ __device__ __forceinline__ void me_frac_stage(const uint8_t* __restrict__ src, i
         meta = me_frac_prefetch<STAGE, 1>(src, gpitch, st, cover, pair, role, pf_wave);
       }
 #ifndef ME_FRAC_T_NOITEMS
-      me_frac_compute<STAGE, HAD, BPS, 1, WP>(R, curl, st, cover, cur, role, bd, clip_lo, wp, tab_h, tab_v, acc);
+      me_frac_compute<STAGE, HAD, BPS, 1, WP>(R, curl, st, cover, cur, role, bd, clip_lo, wp, tab_h, tab_v, acc, ME_FRAC_RIDE_LISTED || i8 < NT);
 #endif
       if (!more) break;
     }
@@ -1861,7 +1871,7 @@ __device__ __forceinline__ void me_frac_stage(const uint8_t* __restrict__ src, i
           meta = me_frac_prefetch<STAGE, 0>(src, gpitch, st, cover, pair, 0, pf_wave);
         }
 #ifndef ME_FRAC_T_NOITEMS
-        me_frac_compute<STAGE, HAD, BPS, 0, WP>(R, curl, st, cover, cur, 0, bd, clip_lo, wp, tab_h, tab_v, acc);
+        me_frac_compute<STAGE, HAD, BPS, 0, WP>(R, curl, st, cover, cur, 0, bd, clip_lo, wp, tab_h, tab_v, acc, false);
 #endif
         if (!more) break;
       }
@@ -1886,7 +1896,7 @@ __device__ __forceinline__ void me_frac_stage(const uint8_t* __restrict__ src, i
 #endif
       }
 #ifndef ME_FRAC_T_NOITEMS
-      me_frac_compute<STAGE, HAD, BPS, 1, WP>(R, curl, st, cover, pair, role, bd, clip_lo, wp, tab_h, tab_v, acc);
+      me_frac_compute<STAGE, HAD, BPS, 1, WP>(R, curl, st, cover, pair, role, bd, clip_lo, wp, tab_h, tab_v, acc, ME_FRAC_RIDE_LISTED || i8 < 0);
 #endif
       if (i8 < 0) {
         __syncthreads();   // the work lists are complete
@@ -1902,7 +1912,7 @@ __device__ __forceinline__ void me_frac_stage(const uint8_t* __restrict__ src, i
       const int pair = list4[i4];
       FracRaw<BPS> R;
       me_frac_fetch<STAGE, BPS, 0>(src, gpitch, st, cover, pair, 0, R);
-      me_frac_compute<STAGE, HAD, BPS, 0, WP>(R, curl, st, cover, pair, 0, bd, clip_lo, wp, tab_h, tab_v, acc);
+      me_frac_compute<STAGE, HAD, BPS, 0, WP>(R, curl, st, cover, pair, 0, bd, clip_lo, wp, tab_h, tab_v, acc, false);
     }
 #endif
   }
