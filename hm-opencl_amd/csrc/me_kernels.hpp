@@ -634,8 +634,10 @@ __global__ void me_fill_plane_kernel(uint8_t* __restrict__ dst, int dst_pitch, i
 
 // ---- 16-bit sample path (bit depth 9..12, bi-prediction origins of any depth) -----------------------------------------------
 // Same task / key / butterfly / merge machinery as me_search_kernel; differences (see tools/gen_me_tree.py, class Tree16):
-// v_sad_u16 leaves on u16 samples, three candidates per lane (x, x+2, x+4), exact 32-bit sums and
-//   key = ((sum << fen_shift) >> (bitDepth-8)) << kIdxBits16 + c     (reference TComRdCost.cpp:520-521),
+// v_sad_u16 leaves on u16 samples, three candidates per lane (x, x+2, x+4), exact 32-bit sums (candidates 0 and 1 as one 64-bit
+// register pair: one add for both) and
+//   key = ((sum << fen_shift) >> (bitDepth-8)) << kIdxBits16 + c     (reference TComRdCost.cpp:520-521)
+// formed as (S' & ~0xff) + c from sums that the tree's first add of two leaves has already shifted to the key's field,
 // lanes packed linearly over the window (candidate triple q = iteration*64 + lane), one lane-iteration per task, and the window
 // is cut into horizontal strips of candidate rows so that one strip's reference rows fit LDS (SR 128: 320 x 322 samples); strips
 // of a CTU are separate workgroups that merge through 64-bit atomicMin on a global table.
@@ -645,19 +647,31 @@ typedef volatile __attribute__((address_space(3))) u32x4_t lds_vu32x4_t;
 #define ME_SAD16(a, b, acc) __builtin_amdgcn_sad_u16((a), (b), (acc))
 
 // key of each of the lane's three candidates from its exact sum, and their minimum; `asm volatile` for the same reason as me_min4
-// (ordered against the masked merges)
-__device__ __forceinline__ uint32_t me_keymin3(uint32_t s0, uint32_t s1, uint32_t s2, uint32_t mask, uint32_t lsh, uint32_t c0, uint32_t c1,
-                                               uint32_t c2) {
+// (ordered against the masked merges).  The sums arrive shifted to the key's sum field (the tree's first add of two leaf sums shifts
+// the result, tools/gen_me_tree.py Tree16): key = (S' & ~0xff) + c -- the mask drops the bits HM's >> (bitDepth-8) drops.
+// This three-register form is what the generator emits with PAIR64 = False (the A/B build); the kernel as shipped uses me_keymin3_p
+__device__ __forceinline__ uint32_t me_keymin3(uint32_t s0, uint32_t s1, uint32_t s2, uint32_t mask, uint32_t c0, uint32_t c1, uint32_t c2) {
   uint32_t r, t, u;
   asm volatile("v_and_b32 %0, %6, %3\n\tv_and_b32 %1, %6, %4\n\tv_and_b32 %2, %6, %5\n\t"
-               "v_lshl_add_u32 %0, %0, %7, %8\n\tv_lshl_add_u32 %1, %1, %7, %9\n\tv_lshl_add_u32 %2, %2, %7, %10\n\t"
+               "v_add_u32 %0, %0, %7\n\tv_add_u32 %1, %1, %8\n\tv_add_u32 %2, %2, %9\n\t"
                "v_min3_u32 %0, %0, %1, %2"
-               : "=&v"(r), "=&v"(t), "=&v"(u) : "v"(s0), "v"(s1), "v"(s2), "s"(mask), "s"(lsh), "v"(c0), "v"(c1), "v"(c2));
+               : "=&v"(r), "=&v"(t), "=&v"(u) : "v"(s0), "v"(s1), "v"(s2), "s"(mask), "v"(c0), "v"(c1), "v"(c2));
   return r;
 }
 
-#define ME16_KEYMIN_A(s0, s1, s2) me_keymin3(s0, s1, s2, mask_a, lsh_a, c0, c1, c2)
-#define ME16_KEYMIN_E(s0, s1, s2) me_keymin3(s0, s1, s2, mask_e, lsh_e, c0, c1, c2)
+#define ME16_KEYMIN(s0, s1, s2) me_keymin3(s0, s1, s2, keymask16, c0, c1, c2)
+// the same with candidates 0 and 1 as one 64-bit pair (tools/gen_me_tree.py PAIR64): two v_and_b32 on its halves, ONE 64-bit add for both
+// keys (v_lshl_add_u64, shift 0; neither half carries into the other: a key is below 2^32), and + add for the third, v_min3_u32 -- six
+// instructions where three separate candidates took seven.  Only the minimum is `asm volatile` (ordered against the masked merges)
+__device__ __forceinline__ uint64_t me_pair(uint32_t lo, uint32_t hi) { return (uint64_t)lo | (uint64_t)hi << 32; }
+__device__ __forceinline__ uint32_t me_keymin3_p(uint64_t s01, uint32_t s2, uint32_t mask, uint64_t c01, uint32_t c2) {
+  const uint64_t k01 = (s01 & me_pair(mask, mask)) + c01;
+  const uint32_t k2 = (s2 & mask) + c2;
+  uint32_t r;
+  asm volatile("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"((uint32_t)k01), "v"((uint32_t)(k01 >> 32)), "v"(k2));
+  return r;
+}
+#define ME16_KEYMIN_P(s01, s2) me_keymin3_p(s01, s2, keymask16, c01, c2)
 
 #ifdef ME_SEARCH_T_TIMELINE   // timing-only builds: per workgroup of me_search16_kernel -- start, [per pass: window staged, wave 0 dry, all dry], end (100 MHz wall clock), hardware id
 __device__ uint32_t g_timeline16[16384 * 12];
@@ -693,9 +707,9 @@ me_search16_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_
   const int ny = jb.y1 - jb.y0;                                        // candidate rows of this strip
 
   for (int s = tid; s < kParts; s += kThreads16) best64[s] = ~0ull;
-  // key = ((sum & mask) << lsh) + c  ==  (((sum << fen_shift) >> sh) << kIdxBits16) + c
-  const uint32_t mask_a = ~((1u << sh) - 1u), lsh_a = kIdxBits16 - sh;
-  const uint32_t mask_e = FEN ? ~((1u << (sh > 0 ? sh - 1 : 0)) - 1u) : mask_a, lsh_e = FEN ? kIdxBits16 + 1 - sh : lsh_a;
+  // key = ((sum << lsh) & ~0xff) + c  ==  (((sum << fen_shift) >> sh) << kIdxBits16) + c; the shift rides on the tree's first adds
+  const uint32_t lsh_a = kIdxBits16 - sh, lsh_e = FEN ? kIdxBits16 + 1 - sh : lsh_a;
+  const uint32_t keymask16 = ~((1u << kIdxBits16) - 1u);
   const bool rb1 = lane & 2, rb0 = lane & 1;
   constexpr int ME16_PDW = PDW;
   // The current block comes through the scalar cache into SGPRs (v_sad_u16 takes one SGPR operand): no LDS slot and no VGPR for
@@ -779,6 +793,7 @@ me_search16_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_
         cc[j] = (((vy && (cx + 2 * j) < wx) ? cost : kInvCost16) << kIdxBits16) | tag | (uint32_t)j;
       }
       const uint32_t c0 = cc[0], c1 = cc[1], c2 = cc[2];
+      const uint64_t c01 = me_pair(c0, c1);
       const lds_char_t* lpd = (const lds_char_t*)(win + min(row, ny - 1) * PDW + 3 * pr);
       if constexpr (FEN) {
 #include "me_tree16_fen1.inc"

@@ -350,7 +350,18 @@ class Tree16(Tree):
     per two window rows (its offsets reach 255 dwords).
     Every value is a triple of exact 32-bit sums: HM applies `>> (bitDepth-8)` to the whole-PU sum *after* the FEN `<< 1`
     (TComRdCost.cpp:520-521), a floor and therefore not linear -- no key linearity, no u16 packing; each slot's key is formed
-    from its own exact sum:   key_j = ((S_j & MASK_f) << LSH_f) + C_j      (v_and_b32 + v_lshl_add_u32)
+    from its own exact sum.  Round 5 cut the INSTRUCTION COUNT of that arithmetic (this kernel does not care what an instruction costs in
+    a pure stream -- VOP2 keys instead of VOP3 ones changed nothing -- it cares how many there are):
+      * every slot is a sum of at least two 4x4 leaves, and the first add of two leaf sums also shifts the result to its place in
+        the key: (a + b) << LSH_f, LSH_f = 8 - sh for the all-rows family, 9 - sh for the even-rows family of FEN (its `<< 1`).
+        Every sum above the leaves is S << LSH_f (28 bits at most: adds and subtractions of such sums are exact) with the bits that
+        HM's `>> (bitDepth-8)` drops sitting just below the key's cost field:   key_j = (S'_j & ~0xff) + C_j
+      * candidates 0 and 1 of every value travel as ONE 64-bit register pair (PAIR64): an add of two sums is one v_lshl_add_u64 for
+        both (+ one v_add_u32 for the third candidate), the first-level shift one v_lshlrev_b64, the add of the key constants one
+        v_lshl_add_u64 -- neither half ever carries into or borrows from the other, every sum and key stays below 2^32.  (The shift
+        cannot ride on v_lshl_add_u64 itself: the instruction only shifts by 0..4 -- a build that asked it for 6 and 7 was 5 % faster
+        and wrong.)  Per slot 6 instructions instead of 7, per add 2 instead of 3: 14 268 -> 13 534 VALU instructions per
+        lane-iteration, BASELINE config 5 1 811 -> 1 868 GSAD/s (profiles/r05aa_search16_instruction_count.txt).
     Leaves are v_sad_u16 (2 samples per op).  Three 32-bit sums per value leave no room for a whole CU of loads in flight on top
     of the CU being consumed, so the prefetch distance is half a CU (_assemble)."""
 
@@ -388,13 +399,17 @@ class Tree16(Tree):
                 if self.fen:
                     e = chain(2, chain(0, None))
                     a = chain(3, chain(1, e))
+                    self.leaf_family[e], self.leaf_family[a] = "E", "A"
                     out.append((e, a))
                 else:
                     a = chain(3, chain(2, chain(1, chain(0, None))))
+                    self.leaf_family[a] = "A"
                     out.append((a, a))
         return out
 
     def level0(self, cx8, cy8, cx, cy):
+        if not hasattr(self, "leaf_family"):
+            self.leaf_family = {}     # leaf sum -> family ("A" all rows, "E" even rows): unshifted values; everything else is shifted
         self._blocks = self.block16(cx8, cy8)
         self._next_block = 0
         return Tree.level0(self, cx8, cy8, cx, cy)
@@ -406,10 +421,16 @@ class Tree16(Tree):
 
     def pkadd(self, a, b):
         v = self.new("p")
-        self.ops.append(("ADDN", v, a, b))
+        fa, fb = self.leaf_family.get(a), self.leaf_family.get(b)
+        assert fa == fb, "a leaf sum only ever meets a leaf sum of its own family"
+        if fa:     # two leaves: the add that also shifts the sum to its place in the key
+            self.ops.append(("ADDSHLN", v, a, b, fa))
+        else:
+            self.ops.append(("ADDN", v, a, b))
         return v
 
     def pksub(self, a, b):
+        assert a not in self.leaf_family and b not in self.leaf_family
         v = self.new("p")
         self.ops.append(("SUBN", v, a, b))
         return v
@@ -476,13 +497,18 @@ HEADER16 = """// GENERATED by tools/gen_me_tree.py -- do not edit.  One lane-ite
 // (fen=%d): three candidates (x, x+2, x+4) per lane, exact 32-bit sums, v_sad_u16 leaves.
 // Expects in scope: lpd (per-lane LDS byte pointer at the first candidate, window row 0; 4-byte aligned), ME16_PDW (window pitch in
 // dwords), ME16_CUR(row, q) (scalar load of 8 current-block samples) and ME16_CUR_WAIT (the batch has arrived), c0, c1, c2,
-// b0..b9, rb1, rb0, the key macros ME16_KEYMIN_A / ME16_KEYMIN_E (all-rows / even-rows family) and the me_merge* helpers.
+// b0..b9, rb1, rb0, lsh_a / lsh_e (the shift of the first add of two leaf sums, all-rows / even-rows family), the key macro
+// ME16_KEYMIN and the me_merge* helpers.
 """
 
 
 MASKED_MERGE_LEVELS = (0, 1)   # the two levels done with hand-written bank-masked DPP pairs (me_merge0 / me_merge1)
 # instructions of the ops that the 8-bit kernel emits as `asm volatile` (their mutual order in the ISA is the order here)
-ORDERED_INSTRS = {"KEYS": 4, "LIN": 4, "SUB": 4, "MIN4": 2, "KEYMINN": 7}
+# 16-bit tree: candidates 0 and 1 of every sum above the leaves travel as ONE 64-bit value -- an add of two sums and the add of the
+# pair's key constants are one v_lshl_add_u64 each (shift 0: the instruction only shifts by 0..4, which is why the key's shift rides on the
+# first add of two leaf sums), 6 instructions per slot where three separate candidates took 7, 2 per add where they took 3
+PAIR64 = True
+ORDERED_INSTRS = {"KEYS": 4, "LIN": 4, "SUB": 4, "MIN4": 2, "KEYMINN": 1 if PAIR64 else 7}
 
 
 def space_merges(ops, enable):
@@ -614,13 +640,25 @@ def emit_cpp(tree, path, header=None):
                 a = f"{acc}_{j}" if acc else "0u"
                 parts.append(f"{v}_{j} = ME_SAD16({d1}, {w}[{wi + 1}], ME_SAD16({d0}, {w}[{wi}], {a}))")
             o.append("const uint32_t " + ", ".join(parts) + ";")
+            if PAIR64 and v in tree.leaf_family:
+                o.append(f"const uint64_t {v}_p = me_pair({v}_0, {v}_1);")
+        elif t == "ADDN" and PAIR64:   # candidates 0 and 1 as one 64-bit add (v_lshl_add_u64): neither half ever carries, a sum stays below 2^32
+            o.append(f"const uint64_t {op[1]}_p = {op[2]}_p + {op[3]}_p; const uint32_t {op[1]}_2 = {op[2]}_2 + {op[3]}_2;")
         elif t == "ADDN":
             o.append("const uint32_t " + ", ".join(f"{op[1]}_{j} = {op[2]}_{j} + {op[3]}_{j}" for j in range(tree.nc)) + ";")
+        elif t == "ADDSHLN":
+            if PAIR64:   # the two leaves' pairs added as one (v_lshl_add_u64), the pair shifted as one (v_lshlrev_b64: a leaf-pair sum is 17 bits, the low half never reaches the high one)
+                o.append(f"const uint64_t {op[1]}_p = ({op[2]}_p + {op[3]}_p) << lsh_{op[4].lower()}; const uint32_t {op[1]}_2 = ({op[2]}_2 + {op[3]}_2) << lsh_{op[4].lower()};")
+            else:
+                o.append("const uint32_t " + ", ".join(f"{op[1]}_{j} = ({op[2]}_{j} + {op[3]}_{j}) << lsh_{op[4].lower()}" for j in range(tree.nc)) + ";")
+        elif t == "SUBN" and PAIR64:   # a region minus a part of it: neither half ever borrows
+            o.append(f"const uint64_t {op[1]}_p = {op[2]}_p - {op[3]}_p; const uint32_t {op[1]}_2 = {op[2]}_2 - {op[3]}_2;")
         elif t == "SUBN":
             o.append("const uint32_t " + ", ".join(f"{op[1]}_{j} = {op[2]}_{j} - {op[3]}_{j}" for j in range(tree.nc)) + ";")
+        elif t == "KEYMINN" and PAIR64:
+            o.append(f"const uint32_t {op[1]} = ME16_KEYMIN_P({op[2]}_p, {op[2]}_2);")
         elif t == "KEYMINN":
-            f_ = "e" if op[3] == "E" else "a"
-            o.append(f"const uint32_t {op[1]} = ME16_KEYMIN_{f_.upper()}({op[2]}_0, {op[2]}_1, {op[2]}_2);")
+            o.append(f"const uint32_t {op[1]} = ME16_KEYMIN({op[2]}_0, {op[2]}_1, {op[2]}_2);")
         elif t == "CURLD16":
             o.append(f"u32x4_t {op[1]} = ME16_CUR({op[2]}, {op[3]});")
         elif t == "CURWAIT":
@@ -680,8 +718,8 @@ def simulate16(tree, window, cur, lane_off, c, best, sh):
     rowbase = {}
     flat = np.concatenate([window.reshape(-1), np.zeros(64, window.dtype)]).astype(np.int64)
     pitch = window.shape[1]
-    mask = {"A": ~((1 << sh) - 1), "E": ~((1 << max(sh - 1, 0)) - 1) if tree.fen else ~((1 << sh) - 1)}
     lsh = {"A": IDX_BITS16 - sh, "E": (IDX_BITS16 + 1 - sh) if tree.fen else IDX_BITS16 - sh}
+    keymask = ~((1 << IDX_BITS16) - 1)
     val = {}
     MAXK = np.full(64, 0xFFFFFFFF, np.uint32)
     for op in tree.ops:
@@ -705,10 +743,14 @@ def simulate16(tree, window, cur, lane_off, c, best, sh):
             val[v] = res
         elif t == "ADDN":
             val[op[1]] = val[op[2]] + val[op[3]]
+        elif t == "ADDSHLN":
+            val[op[1]] = (val[op[2]] + val[op[3]]) << lsh[op[4]]
         elif t == "SUBN":
             val[op[1]] = val[op[2]] - val[op[3]]
+            assert (val[op[1]] >= 0).all()
         elif t == "KEYMINN":
-            k = ((val[op[2]] & mask[op[3]]) << lsh[op[3]]) + c.T.astype(np.int64)
+            assert (val[op[2]] < (1 << 32)).all()
+            k = (val[op[2]] & keymask) + c.T.astype(np.int64)
             val[op[1]] = k.min(axis=1).astype(np.uint32)
         elif t == "MERGE":
             _, level, m, a, b = op
