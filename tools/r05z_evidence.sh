@@ -1,5 +1,5 @@
 # final evidence of round 5 (one gpurun call): GPU suite, default bench line, rocprofv3 summaries of both configurations, extended fuzz, latencies
-OUT=gpurun_out/r05z; mkdir -p $OUT; export TMPDIR=/tmp
+OUT=gpurun_out/r05z; mkdir -p $OUT; export TMPDIR=/tmp; rm -rf gpurun_out/prof_r05z   # (on the box this is empty anyway; what comes back is MERGED into the build container's gpurun_out/: delete gpurun_out/prof_r05z there before a new run, tools/summarize_profile.py reads every trace it finds)
 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 | tee $OUT/gpu_tests.txt
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"
 bash tools/profile_bench.sh r05z > $OUT/profile.log 2>&1; echo "profile rc=$?"
