@@ -68,6 +68,7 @@ def slot_2Nx2N(s, cx, cy):
     return BASE_2Nx2N[s] + cy * n + cx
 
 
+SHARED_BASES = True   # LDS base registers made once per lane-iteration, not once per CU (A/B: False)
 LOAD_OPS = ("LDS", "CURLD", "BASE", "LDS16Q", "ROWBASE", "CURLD16")
 
 
@@ -82,6 +83,7 @@ class Tree:
         self.pending = {}          # butterfly level -> var
         self.group = 0
         self.loaded = {}
+        self.bases = {}
         self.cu_loads = []
 
     def new(self, prefix="v"):
@@ -94,13 +96,17 @@ class Tree:
         register, so each 4-row block row of a CU gets its own (opaque) base: 2 v_add per CU."""
         key = (row, k)
         if key not in self.loaded:
-            bkey = ("base", row // 4, self.cu_k0)
-            if bkey not in self.loaded:
+            # SHARED_BASES: one base per 4-row block row for the whole lane-iteration (offsets reach 3 * PDW + 17 = 164 dwords), 16 v_add
+            # instead of 2 per CU = 128
+            k0 = 0 if SHARED_BASES else self.cu_k0
+            bkey = ("base", row // 4, k0)
+            where = self.bases if SHARED_BASES else self.loaded
+            if bkey not in where:
                 b = self.new("a")
-                self.ops.append(("BASE", b, (row // 4) * 4, self.cu_k0))
-                self.loaded[bkey] = b
+                self.ops.append(("BASE", b, (row // 4) * 4, k0))
+                where[bkey] = b
             v = self.new("d")
-            self.ops.append(("LDS", v, row, k, self.loaded[bkey], (row % 4) * PDW + (k - self.cu_k0)))
+            self.ops.append(("LDS", v, row, k, where[bkey], (row % 4) * PDW + (k - k0)))
             self.loaded[key] = v
         return self.loaded[key]
 
@@ -374,8 +380,12 @@ class Tree16(Tree):
         nc = self.nc
         for r in range(8):
             row = cy8 * 8 + r
-            base = f"lrow{row & ~1}_{cx8}"
-            if r % 2 == 0:   # one opaque base per two window rows: ds_read2_b32 offsets reach 255 dwords, a row is ME16_PDW <= 162
+            # one opaque base per two window rows: ds_read2_b32 offsets reach 255 dwords, a row is ME16_PDW <= 162 (+ 37 for the last CU column).
+            # SHARED_BASES: the base is made once per lane-iteration and serves all eight CU columns (it used to be made again for every
+            # CU: 256 v_mov per lane-iteration of values the compiler kept in registers anyway)
+            base = f"lrow{row & ~1}" if SHARED_BASES else f"lrow{row & ~1}_{cx8}"
+            if r % 2 == 0 and not (SHARED_BASES and base in self.rowbases):
+                self.rowbases.add(base)
                 self.ops.append(("ROWBASE", base, row))
             d = []
             for i in range(0, 6, 2):
@@ -408,6 +418,8 @@ class Tree16(Tree):
         return out
 
     def level0(self, cx8, cy8, cx, cy):
+        if not hasattr(self, "rowbases"):
+            self.rowbases = set()
         if not hasattr(self, "leaf_family"):
             self.leaf_family = {}     # leaf sum -> family ("A" all rows, "E" even rows): unshifted values; everything else is shifted
         self._blocks = self.block16(cx8, cy8)

@@ -49,7 +49,7 @@ int main() {
   uint32_t* d; CK(hipMalloc(&d, 64 * 5 * 4 + 64));
   std::vector<uint32_t> h(64 * 5);
   auto s16 = [](int i) { return (uint32_t)(uint16_t)(i * 7 + 1); };
-  for (int shift : {0, 2, 1}) {
+  for (int shift : {0, 2, 4, 1}) {   // 4: the search kernels' case -- 64-bit reads at 4-byte-aligned addresses
     hipLaunchKernelGGL(k_check, dim3(1), dim3(64), 0, 0, d, shift);
     CK(hipMemcpy(h.data(), d, h.size() * 4, hipMemcpyDeviceToHost));
     int bad32 = 0, bad64 = 0, bad2 = 0;
@@ -65,7 +65,7 @@ int main() {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int iters = 2048, blocks = p.multiProcessorCount * 2;
   for (int mode = 0; mode < 3; ++mode)
-    for (int shift : {0, 2}) {
+    for (int shift : {0, 2, 4}) {
       auto launch = [&]() {
         if (mode == 0) hipLaunchKernelGGL(k_rate<0>, dim3(blocks), dim3(256), 0, 0, d, shift, iters);
         if (mode == 1) hipLaunchKernelGGL(k_rate<1>, dim3(blocks), dim3(256), 0, 0, d, shift, iters);
