@@ -260,7 +260,15 @@ int launch_search8(hmme_ctx* ctx, const RefSet& cur, int cur_pitch, const RefSet
                    int n_jobs, int fen, int16_t* d_mv, uint32_t* d_sad, hipStream_t stream) {
   if (n_jobs <= 0) return HMME_OK;
   const int fair = fair_prio(ctx, n_jobs, true);
-  if (fen)
+  // (the pitches of 2160p and 1080p planes as compile-time constants: me_kernels.hpp CPITCH; HMME_CPITCH=0 forces the general kernel for A/B runs)
+  static const bool any_pitch = std::getenv("HMME_CPITCH") && std::atoi(std::getenv("HMME_CPITCH")) == 0;
+  if (fen && cur_pitch == 4096 && !any_pitch)
+    hipLaunchKernelGGL((hmme::me_search_kernel<1, 0, 4096>), dim3(n_jobs), dim3(hmme::kThreads), 0, stream, cur, cur_pitch, ref,
+                       ref_pitch, (const void*)d_jobs, ctx->lambda_q16, d_mv, d_sad, (unsigned long long*)nullptr, fair);
+  else if (fen && cur_pitch == 2304 && !any_pitch)
+    hipLaunchKernelGGL((hmme::me_search_kernel<1, 0, 2304>), dim3(n_jobs), dim3(hmme::kThreads), 0, stream, cur, cur_pitch, ref,
+                       ref_pitch, (const void*)d_jobs, ctx->lambda_q16, d_mv, d_sad, (unsigned long long*)nullptr, fair);
+  else if (fen)
     hipLaunchKernelGGL((hmme::me_search_kernel<1, 0>), dim3(n_jobs), dim3(hmme::kThreads), 0, stream, cur, cur_pitch, ref,
                        ref_pitch, (const void*)d_jobs, ctx->lambda_q16, d_mv, d_sad, (unsigned long long*)nullptr, fair);
   else

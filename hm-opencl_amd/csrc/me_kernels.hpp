@@ -313,7 +313,11 @@ constexpr int kTileStep = 129, kTileJobMask = 0x1fffffff;
 // SPLIT = 0: one workgroup searches the whole window of jobs[blockIdx.x] (MeJob) and writes its 593 results.
 // SPLIT = 1: jobs are MeJob16; the workgroup runs tasks [y0, y1) only and merges into g_best with 64-bit atomicMin
 //            (decoded afterwards by me_finalize16_kernel) -- used where one CTU must fill many CUs.
-template <int FEN, int SPLIT>
+// CPITCH: the current picture's pitch in bytes as a compile-time constant (0 = any pitch).  A current-block load is s_load_dwordx2 at
+// row * pitch + 8 * q: with the pitch known the offset is an immediate; without, every one of the 512 loads of a lane-iteration is
+// preceded by an s_mul_i32 -- 5.5 % of the instructions of the body, and this kernel's time follows its instruction count.  The pitches of
+// the BASELINE pictures (2160p: 4096, 1080p: 2304) have instantiations of their own (hmme.hip launch_search8); any other picture runs CPITCH 0.
+template <int FEN, int SPLIT, int CPITCH = 0>
 __global__ void __launch_bounds__(kThreads, 2)
 me_search_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitch,
                  const void* __restrict__ jobs_v, uint32_t lambda_q16, int16_t* __restrict__ out_mv,
@@ -480,9 +484,13 @@ me_search_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pi
 #define ME8_CUR(row, q)                                                                                                            \
   ({                                                                                                                               \
     uint64_t w_;                                                                                                                   \
-    uint32_t o_;                                                                                                                   \
-    asm volatile("s_mul_i32 %1, %3, %4\n\ts_load_dwordx2 %0, %2, %1 offset:%5"                                                     \
-                 : "=s"(w_), "=&s"(o_) : "s"(curc), "s"(cur_pitch_s), "n"(row), "n"(8 * (q)));                                      \
+    if constexpr (CPITCH != 0) {                                                                                                   \
+      asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(w_) : "s"(curc), "n"((row) * CPITCH + 8 * (q)));                              \
+    } else {                                                                                                                       \
+      uint32_t o_;                                                                                                                 \
+      asm volatile("s_mul_i32 %1, %3, %4\n\ts_load_dwordx2 %0, %2, %1 offset:%5"                                                   \
+                   : "=s"(w_), "=&s"(o_) : "s"(curc), "s"(cur_pitch_s), "n"(row), "n"(8 * (q)));                                    \
+    }                                                                                                                              \
     w_;                                                                                                                            \
   })
 #define ME8_CUR_WAIT(w0, w1, w2, w3, w4, w5, w6, w7, d0, d1, d2, d3, d4, d5, d6, d7, d8, d9, d10, d11, d12, d13, d14, d15)           \
