@@ -139,6 +139,7 @@ struct hmme_ctx {
   int out_cap = 0;
   int* d_flag = nullptr;
   bool lds_optin[8] = {false, false, false, false, false, false, false, false};
+  bool lds_optin_cpitch = false;   // the same for me_search16_kernel<1, 161, 8192>
   int num_cus = 0;
   bool frac_lds_optin[3][2] = {{false, false}, {false, false}, {false, false}};   // [8-bit | u16 | u16 weighted][hadamard]
   int frac_wg_per_cu[2][2] = {{0, 0}, {0, 0}};   // [wide][hadamard] workgroups of me_frac_kernel a CU holds (runtime occupancy query, first use)
@@ -334,6 +335,21 @@ int strips_for(int pdw, int wy_max) {
 template <int FEN, int PDW>
 int launch16_t(hmme_ctx* ctx, const RefSet& cur, int cur_pitch, const RefSet& ref, int ref_pitch, const MeJob16* d_jobs, int n_wg,
                size_t lds, int sh, unsigned long long* d_best, hipStream_t stream) {
+  // BASELINE config 5's shape -- 2160p planes of 16-bit samples (pitch 8192), search range 97..128, FEN -- has an instantiation with the pitch
+  // as a compile-time constant (me_kernels.hpp CPITCH); HMME_CPITCH=0 runs the general kernel
+  static const bool any_pitch = std::getenv("HMME_CPITCH") && std::atoi(std::getenv("HMME_CPITCH")) == 0;
+  if constexpr (FEN == 1 && PDW == 161) {
+    if (cur_pitch == 8192 && !any_pitch) {
+      if (!ctx->lds_optin_cpitch) {
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)hmme::me_search16_kernel<1, 161, 8192>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ctx->lds_optin_cpitch = true;
+      }
+      hipLaunchKernelGGL((hmme::me_search16_kernel<1, 161, 8192>), dim3(n_wg), dim3(hmme::kThreads16), lds, stream, cur, cur_pitch, ref,
+                         ref_pitch, d_jobs, ctx->lambda_q16, sh, d_best, fair_prio(ctx, n_wg, false));
+      HIP_TRY(ctx, hipGetLastError());
+      return HMME_OK;
+    }
+  }
   bool& attr_set = ctx->lds_optin[FEN * 4 + pdw16_index(PDW)];   // > 64 KiB of dynamic LDS: opt in once per
   if (!attr_set) {                                                            // kernel and device (= per context)
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)hmme::me_search16_kernel<FEN, PDW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

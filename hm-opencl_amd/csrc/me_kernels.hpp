@@ -684,7 +684,9 @@ __device__ __forceinline__ uint32_t me_keymin3_p(uint64_t s01, uint32_t s2, uint
 #ifdef ME_SEARCH_T_TIMELINE   // timing-only builds: per workgroup of me_search16_kernel -- start, [per pass: window staged, wave 0 dry, all dry], end (100 MHz wall clock), hardware id
 __device__ uint32_t g_timeline16[16384 * 12];
 #endif
-template <int FEN, int PDW>
+// CPITCH: the current picture's pitch in bytes as a compile-time constant (0 = any), as in me_search_kernel: no s_mul_i32 in front of the 512
+// current-block loads of a lane-iteration.  Instantiated for 2160p planes at search range 97..128 (BASELINE config 5: pitch 8192, PDW 161)
+template <int FEN, int PDW, int CPITCH = 0>
 __global__ void __launch_bounds__(kThreads16, 2)
 me_search16_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitch,
                    const MeJob16* __restrict__ jobs, uint32_t lambda_q16, int sh, unsigned long long* __restrict__ g_best, int fair_prio) {
@@ -733,9 +735,13 @@ me_search16_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_
 #define ME16_CUR(row, q)                                                                                                           \
   ({                                                                                                                               \
     u32x4_t w_;                                                                                                                    \
-    uint32_t o_;                                                                                                                   \
-    asm volatile("s_mul_i32 %1, %3, %4\n\ts_load_dwordx4 %0, %2, %1 offset:%5"                                                     \
-                 : "=s"(w_), "=&s"(o_) : "s"(curc), "s"(cur_pitch_s), "n"(row), "n"(16 * (q)));                                     \
+    if constexpr (CPITCH != 0) {                                                                                                   \
+      asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(w_) : "s"(curc), "n"((row) * CPITCH + 16 * (q)));                             \
+    } else {                                                                                                                       \
+      uint32_t o_;                                                                                                                 \
+      asm volatile("s_mul_i32 %1, %3, %4\n\ts_load_dwordx4 %0, %2, %1 offset:%5"                                                   \
+                   : "=s"(w_), "=&s"(o_) : "s"(curc), "s"(cur_pitch_s), "n"(row), "n"(16 * (q)));                                   \
+    }                                                                                                                              \
     w_;                                                                                                                            \
   })
 #define ME16_CUR_WAIT(w0, w1, w2, w3, d0, d1, d2, d3, d4, d5, d6, d7, d8, d9, d10, d11)                                               \
