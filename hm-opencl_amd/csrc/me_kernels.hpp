@@ -815,18 +815,21 @@ me_search16_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_
 #include "me_tree16_fen0.inc"
       }
     }
+    // where a winning candidate lies: the key names the lane that owned it, and that lane knows its row and first column -- one
+    // ds_bpermute_b32 (all lanes active here) instead of a division by `pairs` per running-minimum register (ten per task; the task
+    // is one lane-iteration of this kernel, and its time follows its instruction count)
+    const uint32_t my_yx = [&] {
+      const int q = it0 * 64 + lane, row = q / pairs;
+      return (uint32_t)(jb.y0 + row) << 16 | (uint32_t)(par + 6 * (q - row * pairs));
+    }();
 #define ME_FLUSH16(g, key_)                                                                                        \
     {                                                                                                              \
       const int slot = ME_SLOT_OF[g][lane];                                                                        \
       const uint32_t key = (key_);                                                                                 \
       const uint32_t cost = key >> kIdxBits16;                                                                     \
-      if (slot >= 0 && cost < kInvCost16) {                                                                        \
-        const int kq = it0 * 64 + (int)((key >> 2) & 63);                                                          \
-        const int krow = kq / pairs;                                                                               \
-        const int bx = par + 6 * (kq - krow * pairs) + 2 * (int)(key & 3);                                         \
-        atomicMin(&best64[slot], ((unsigned long long)cost << 32) | ((unsigned long long)(jb.y0 + krow) << 16) |   \
-                                     (unsigned long long)bx);                                                      \
-      }                                                                                                            \
+      const uint32_t yx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(key & 0xfcu), (int)my_yx);   /* lane (key >> 2) & 63, in bytes */ \
+      if (slot >= 0 && cost < kInvCost16)                                                                          \
+        atomicMin(&best64[slot], ((unsigned long long)cost << 32) | (unsigned long long)(yx + 2 * (key & 3)));     \
     }
     ME_FLUSH16(0, b0) ME_FLUSH16(1, b1) ME_FLUSH16(2, b2) ME_FLUSH16(3, b3) ME_FLUSH16(4, b4)
     ME_FLUSH16(5, b5) ME_FLUSH16(6, b6) ME_FLUSH16(7, b7) ME_FLUSH16(8, b8) ME_FLUSH16(9, b9)
