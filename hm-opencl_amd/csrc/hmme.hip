@@ -398,6 +398,9 @@ int check_frame_args(hmme_ctx* ctx, const hmme_plane* cur, const hmme_plane* ref
                      int* count) {
   if (!ctx) return HMME_ERR_ARG;
   if (!cur || !ref || !fp) return fail(ctx, HMME_ERR_ARG, "null plane / params");
+  // a launch ties the planes it reads to an event of THIS context's ring (plane_read_mark): a plane of another context would be left
+  // pointing into that ring after the context is gone
+  if (cur->ctx != ctx || ref->ctx != ctx) return fail(ctx, HMME_ERR_ARG, "plane belongs to another context (planes are used with the context that created them)");
   if (cur->width != ref->width || cur->height != ref->height) return fail(ctx, HMME_ERR_ARG, "cur/ref size mismatch");
   if (fp->bit_depth < 8 || fp->bit_depth > 12) return fail(ctx, HMME_ERR_UNSUPPORTED, "bit depth %d outside 8..12", fp->bit_depth);
   if (cur->bit_depth != fp->bit_depth || ref->bit_depth != fp->bit_depth)
@@ -538,7 +541,12 @@ void hmme_destroy(hmme_ctx* ctx) {
 }
 
 const char* hmme_last_error(const hmme_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
-void hmme_set_error_printing(hmme_ctx* ctx, int on) { if (ctx) ctx->print_errors = on != 0; }
+int hmme_set_error_printing(hmme_ctx* ctx, int on) {
+  if (!ctx) return 1;
+  const int was = ctx->print_errors ? 1 : 0;
+  ctx->print_errors = on != 0;
+  return was;
+}
 const char* hmme_device_info(const hmme_ctx* ctx) { return ctx ? ctx->info.c_str() : ""; }
 int hmme_device_index(const hmme_ctx* ctx) { return ctx ? ctx->device : -1; }
 

@@ -25,7 +25,7 @@ SYMBOLS = ["hmme_create", "hmme_destroy", "hmme_last_error", "hmme_device_info",
            "hmme_upload_status", "hmme_abi_version", "hmme_build_id", "hmme_device_index", "hmme_set_error_printing"]
 # test / measurement entry points (include/hmme_test.h): not part of the boundary
 TEST_SYMBOLS = ["hmme_test_time_search_kernel", "hmme_test_device_address", "hmme_test_frac_deal"]
-ABI_VERSION = 5   # HMME_ABI_VERSION of the include/hmme.h these bindings were written against
+ABI_VERSION = 6   # HMME_ABI_VERSION of the include/hmme.h these bindings were written against
 
 
 class HmmeError(RuntimeError):
@@ -74,6 +74,8 @@ def load():
     L.hmme_destroy.restype = None
     L.hmme_last_error.argtypes = [vp]
     L.hmme_last_error.restype = C.c_char_p
+    L.hmme_set_error_printing.argtypes = [vp, i]
+    L.hmme_set_error_printing.restype = i
     L.hmme_device_info.argtypes = [vp]
     L.hmme_device_info.restype = C.c_char_p
     L.hmme_set_lambda.argtypes = [vp, C.c_double]

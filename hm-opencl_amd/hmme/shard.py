@@ -56,9 +56,17 @@ class StartupWatchdog:
 
 def rendezvous_report(rank, world, timeout_s=120.0, key="hmme/ranks_seen", out=None):
     """Counts the ranks through the job's key-value store (TCP: no collective, no GPU) -- every rank adds itself, rank 0 waits until all
-    `world` have, or says which count it got stuck at.  Returns the number of ranks seen (rank 0) or None (other ranks)."""
+    `world` have, or says which count it got stuck at.  Returns the number of ranks seen (rank 0) or None (other ranks; also rank 0 when
+    this torch does not hand out the job's store -- the lookup is a private function -- in which case the count is skipped with a note and
+    the first barrier, under the watchdog, is the check)."""
     out = out or sys.stderr
-    store = dist.distributed_c10d._get_default_store()
+    try:
+        store = dist.distributed_c10d._get_default_store()
+    except (AttributeError, RuntimeError) as e:
+        if rank == 0:
+            out.write(f"hmme: the rendezvous store is not reachable through this torch ({e.__class__.__name__}: {e}): ranks are not counted before the first collective\n")
+            out.flush()
+        return None
     store.add(key, 1)
     if rank != 0:
         return None
@@ -248,6 +256,64 @@ class PipelinedGather:
     def last_gathered(self):
         """rank 0, after drain(): the [world, ...] block of the most recent step (None elsewhere / without a process group)"""
         return self.gathered[(self.k - 1) & 1]
+
+
+def sharded_sequence_job(run_share, pairs, passes=3, sync=None, reduce_device="cpu"):
+    """One open-loop pass over `pairs` as an N-rank job, timed as a job: pair p -> rank p % world, every rank runs ITS share
+    (run_share(my_pairs) -> dict with "mv" [k, n_ctu, 593, 2] int16, "sad" [k, n_ctu, 593] int32 and optionally "stages"), the tables are
+    gathered to rank 0 in pair order (gather_pair_results).  Each pass: barrier, the rank's share, the gather, barrier; its time is the
+    max over ranks.  One untimed pass first (allocations), then `passes` timed ones.  Every rank calls this (bench.py --gpus N
+    `configs.config4_sharded`; the gloo tests run it on the CPU with a stand-in for the engine).
+
+    Returns on rank 0 a dict: seconds (median pass), seconds_passes, pair_counts, per_rank (search / gather seconds and pair count of every
+    rank, of the last pass), crc32_tables_match_per_rank (CRC of each rank's tables BEFORE the transfer == CRC of what rank 0 holds for that
+    rank afterwards), mv / sad (the gathered tables of the last pass, pair order); on the other ranks None."""
+    import zlib
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    sync = sync or (lambda: None)
+    counts = pair_counts(len(pairs), world)
+    mine = [pairs[p] for p in pairs_for_rank(len(pairs), rank, world)]
+
+    def barrier():
+        if world > 1 or dist.is_initialized():
+            dist.barrier()
+
+    jobs, res, mv, sad, info = [], None, None, None, None
+    for i in range(passes + 1):
+        res = mv = sad = None                    # the previous pass's tables go before the next pass allocates
+        sync()
+        barrier()
+        t0 = time.perf_counter()
+        res = run_share(mine)
+        sync()
+        t1 = time.perf_counter()
+        mv, sad = gather_pair_results(res["mv"], res["sad"], len(pairs))
+        sync()
+        t2 = time.perf_counter()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist.is_initialized():
+            t = torch.tensor([dt], dtype=torch.float64, device=reduce_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        if i:
+            jobs.append(dt)
+        info = {"rank": rank, "pairs": len(mine), "search_s": round(t1 - t0, 4), "gather_s": round(t2 - t1, 4), "stages": res.get("stages")}
+    k = counts[rank]
+    mine_crc = [zlib.crc32(res["mv"][:k].contiguous().cpu().numpy().tobytes()), zlib.crc32(res["sad"][:k].contiguous().cpu().numpy().tobytes())]
+    if dist.is_initialized():
+        crc, per_rank = [None] * world, [None] * world
+        dist.all_gather_object(crc, mine_crc)
+        dist.all_gather_object(per_rank, info)
+    else:
+        crc, per_rank = [mine_crc], [info]
+    if rank != 0:
+        return None
+    crc_ok = [crc[r] == [zlib.crc32(mv[r::world].contiguous().cpu().numpy().tobytes()), zlib.crc32(sad[r::world].contiguous().cpu().numpy().tobytes())]
+              for r in range(world)]
+    return {"seconds": sorted(jobs)[len(jobs) // 2], "seconds_passes": jobs, "pair_counts": counts, "per_rank": per_rank,
+            "crc32_tables_match_per_rank": crc_ok, "mv": mv, "sad": sad}
 
 
 def search_sequence(search_pair, n_pairs, n_ctu, device):

@@ -188,9 +188,9 @@ Void TEncOpenCL::calcMotionVectors(Pel* pelCtu, Pel* pelSearch, Int iRefStride, 
   }
   if (rc != HMME_OK && !weighted) {
     const Bool probing = m_mode == ME_MODE_OCL_COMPAT && m_bitDepth <= 0 && p.bit_depth < 12;
-    if (probing) hmme_set_error_printing(m_ctx, 0);
+    const int printing = probing ? hmme_set_error_printing(m_ctx, 0) : 1;   // the caller's own setting comes back after the probe and its retry
     rc = hmme_search_ctu(m_ctx, pelCtu, iCtuStride, pelSearch, iRefStride, &p, reinterpret_cast<int16_t*>(m_engMv), reinterpret_cast<uint32_t*>(m_engCost));
-    if (probing) hmme_set_error_printing(m_ctx, 1);
+    if (probing && rc != HMME_ERR_RANGE) hmme_set_error_printing(m_ctx, printing);
     if (probing && rc == HMME_ERR_RANGE) {
       // Nothing in the reference tree tells this class the bit depth (createBuffers has no such argument), and cl/sad.cl works on
       // whatever Pel holds without a shift: the sample width comes from the samples of the call -- the reference window AND the current
@@ -212,6 +212,7 @@ Void TEncOpenCL::calcMotionVectors(Pel* pelCtu, Pel* pelSearch, Int iRefStride, 
       m_inferredDepth = d;
       p.bit_depth = d;
       rc = hmme_search_ctu(m_ctx, pelCtu, iCtuStride, pelSearch, iRefStride, &p, reinterpret_cast<int16_t*>(m_engMv), reinterpret_cast<uint32_t*>(m_engCost));
+      hmme_set_error_printing(m_ctx, printing);   // a failure of the retry is reported once, below, through hmme_last_error
     }
   }
   if (rc != HMME_OK) {

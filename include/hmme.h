@@ -63,8 +63,9 @@ extern "C" {
  * written against (hmme_search_params grew by `shift_free` in version 2: a caller built against version 1 would have the library
  * read 4 bytes past its struct).  3: hmme_search_pairs_device / hmme_refine_pairs_device, asynchronous uploads, bi-prediction
  * origins in the refinement calls.  4: hmme_search_ctu_w (explicit weighted prediction); hmme_time_search_kernel and
- * hmme_debug_device_address left this header (include/hmme_test.h).  5: hmme_set_error_printing. */
-#define HMME_ABI_VERSION 5
+ * hmme_debug_device_address left this header (include/hmme_test.h).  5: hmme_set_error_printing.  6: hmme_set_error_printing returns the
+ * previous setting; frame calls refuse planes of another context. */
+#define HMME_ABI_VERSION 6
 int hmme_abi_version(void);
 /* identifies the kernel sources + build flags the library was compiled from (bench.py ties committed counter summaries to it) */
 const char* hmme_build_id(void);
@@ -115,8 +116,9 @@ void hmme_destroy(hmme_ctx* ctx);
 const char* hmme_last_error(const hmme_ctx* ctx); /* ctx may be NULL: error of the calling thread's last failed hmme_create */
 /* A failed call prints its message on stderr (as TEncOpenCL::checkError does, TEncOpenCL.h:93-101) and keeps it for hmme_last_error.
  * on = 0 keeps it only -- for a caller that PROBES with a call it expects to be refused (TEncOpenCL's reference-mode call tries the
- * sample width it has latched and widens it on HMME_ERR_RANGE, instead of scanning every window for its largest sample first). */
-void hmme_set_error_printing(hmme_ctx* ctx, int on);
+ * sample width it has latched and widens it on HMME_ERR_RANGE, instead of scanning every window for its largest sample first).
+ * Returns the previous setting (1 / 0; 1 for a NULL context), so that a probe restores what its caller had chosen. */
+int hmme_set_error_printing(hmme_ctx* ctx, int on);
 const char* hmme_device_info(const hmme_ctx* ctx);
 int hmme_device_index(const hmme_ctx* ctx);   /* the HIP device the context lives on (host code that makes its own HIP calls beside the library's) */
 int hmme_set_lambda(hmme_ctx* ctx, double lambda);         /* m_lambda = floor(65536*sqrt(lambda)) */
@@ -194,7 +196,9 @@ int hmme_refine_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
                     const hmme_search_params* p, const int16_t* int_mv, int use_hadamard, int16_t* out_qmv, uint32_t* out_cost);
 
 /* ---- frame path ------------------------------------------------------------------------ */
-/* device-resident luma plane with edge-replicated margins; 8-bit planes store bytes, 9..12-bit planes u16 */
+/* device-resident luma plane with edge-replicated margins; 8-bit planes store bytes, 9..12-bit planes u16.
+ * A plane belongs to the context that created it: every frame call refuses planes of another context (HMME_ERR_ARG), and a
+ * context's planes are destroyed BEFORE the context (hmme_plane_destroy reads its context). */
 int hmme_plane_create(hmme_ctx* ctx, int width, int height, hmme_plane** out);   /* 8-bit */
 int hmme_plane_create_ex(hmme_ctx* ctx, int width, int height, int bit_depth, hmme_plane** out);
 void hmme_plane_destroy(hmme_plane* plane);

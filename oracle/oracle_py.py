@@ -369,3 +369,35 @@ def frac_refine_w(plane_cur, cur_xy, plane_ref, ref_xy, w, h, int_mv, pred, lam_
         oracle().hmo_frac_refine_w(org, cs, w, h, rf, rs, int_mv[0], int_mv[1], pred[0], pred[1], int(lam_or_q16), int(use_had), bit_depth,
                                    C.byref(ww), *[C.byref(v) for v in o], C.byref(cost))
     return tuple(v.value for v in o) + (cost.value,)
+
+
+def ref_full_search_ctus(cur, ref_plane, origin, pic_w, pic_h, sr, lam, fen, bit_depth, ctu_first, min_ctus=4, max_ctus=16, budget_s=3.0):
+    """the REFERENCE's own exhaustive search (TEncSearch::xPatternSearch, TEncSearch.cpp:3835-3897, in oracle/_ref/libhmref.so) for
+    every one of the 593 PU rectangles of consecutive CTUs starting at `ctu_first`, one PU at a time on ONE thread as HM runs it, with the
+    CTU's window (xSetSearchRange around predictor (0,0)) shared by all its PUs.  CTUs are added until `budget_s`
+    seconds have passed (at least min_ctus, at most max_ctus).  -> (x, y, sad) int arrays [n, 593], seconds"""
+    import time
+    L = ref()
+    table = slot_table()
+    cs, rs = cur.shape[1], ref_plane.shape[1]
+    ctus_x = (pic_w + 63) // 64
+    xs, ys, sads = [], [], []
+    lt = [C.c_int() for _ in range(4)]
+    mx, my, sad = C.c_int(), C.c_int(), C.c_uint32()
+    t0 = time.perf_counter()
+    n = 0
+    while n < max_ctus and (n < min_ctus or time.perf_counter() - t0 < budget_s):
+        ctu = ctu_first + n
+        cx, cy = (ctu % ctus_x) * 64, (ctu // ctus_x) * 64
+        oracle().hmo_set_search_range(0, 0, sr, cx, cy, pic_w, pic_h, 64, *[C.byref(v) for v in lt])
+        ox, oy, os_ = np.zeros(NUM_PARTS, np.int32), np.zeros(NUM_PARTS, np.int32), np.zeros(NUM_PARTS, np.uint32)
+        for s in range(NUM_PARTS):
+            x, y, bw, bh = (int(v) for v in table[s])
+            L.ref_pattern_search(_addr(cur, (origin[1] + cy + y) * cs + origin[0] + cx + x), cs, bw, bh,
+                                 _addr(ref_plane, (origin[1] + cy + y) * rs + origin[0] + cx + x), rs,
+                                 lt[0].value, lt[1].value, lt[2].value, lt[3].value, 0, 0, float(lam), int(fen), int(bit_depth),
+                                 C.byref(mx), C.byref(my), C.byref(sad))
+            ox[s], oy[s], os_[s] = mx.value, my.value, sad.value
+        xs.append(ox); ys.append(oy); sads.append(os_)
+        n += 1
+    return np.stack(xs), np.stack(ys), np.stack(sads), time.perf_counter() - t0

@@ -527,6 +527,40 @@ def test_engine_lifecycle_and_two_contexts(oracle_lib):
         e.close()
 
 
+def test_planes_of_another_context_are_refused_and_error_printing_is_restorable(oracle_lib):
+    """a launch ties the planes it reads to an event of the launching context (hmme.hip plane_read_mark): a plane created by context A
+    launched through context B would be left pointing at B's events after B is destroyed -- every frame call refuses it (HMME_ERR_ARG),
+    search and refinement, whichever of the two planes is the foreign one; A's own use of the plane is unaffected afterwards.
+    hmme_set_error_printing returns the previous setting (a probing caller restores what ITS caller had chosen)"""
+    from hmme import api, synth
+    w, h, sr = 128, 64, 8
+    cur, ref, _ = synth.make_pair(w, h, seed=5, max_mv=4, region=64)
+    m = synth.MARGIN
+    with api.Engine(0, 16) as a, api.Engine(0, 16) as b:
+        a.set_lambda(57.9); b.set_lambda(57.9)
+        assert a.L.hmme_set_error_printing(b.h, 0) == 1 and a.L.hmme_set_error_printing(b.h, 0) == 0      # quiet: the refusals below are expected
+        assert a.L.hmme_set_error_printing(None, 0) == 1
+        pa_c, pa_r, pb_c, pb_r = a.plane(w, h), a.plane(w, h), b.plane(w, h), b.plane(w, h)
+        for pl in (pa_c, pb_c):
+            pl.upload_pel(cur, (m, m))
+        for pl in (pa_r, pb_r):
+            pl.upload_pel(ref, (m, m))
+        want = a.search_frame(pa_c, pa_r, sr)
+        for pc, pr in ((pa_c, pb_r), (pb_c, pa_r), (pa_c, pa_r)):
+            with pytest.raises(api.HmmeError, match="another context"):
+                b.search_frame(pc, pr, sr)
+            with pytest.raises(api.HmmeError, match="another context"):
+                b.refine_frame(pc, pr, sr, want[0])
+        got_b = b.search_frame(pb_c, pb_r, sr)
+        assert a.L.hmme_set_error_printing(b.h, 1) == 0
+        for pl in (pb_c, pb_r):
+            pl.close()
+    # b is gone; a's planes were never tied to it
+    with api.Engine(0, 16) as a2:
+        pass
+    assert np.array_equal(want[0], got_b[0]) and np.array_equal(want[1], got_b[1])
+
+
 def test_sequence_driver_single_gpu(tmp_path):
     """tools/me_sequence.py (BASELINE config 4 driver) on one GPU with a small synthetic sequence"""
     import json
@@ -1073,6 +1107,18 @@ def test_bench_starts_its_own_ranks_two_rank_rehearsal_on_one_gpu(tmp_path):
     assert m["gather"]["bytes_received_by_rank0_per_step"] == 2 * n_ctu * 593 * 4           # rank 1's block, nothing else
     assert m["gather"]["bytes_received_in_timed_steps"] == 3 * 2 * n_ctu * 593 * 4
     assert m["verified_rank"]["rank"] == 1 and m["verified_rank"]["slots"] >= 593
+    # the exchange switched off: the same steps, per rank, and the difference to the steps with the gather
+    co, xc = m["compute_only"], m["exchange_cost"]
+    assert len(co["per_rank_step_ms"]) == 2 and min(co["per_rank_kernel_ms"]) > 0 and co["ms_per_step"] > 0 and co["gsad_per_s"] > 0
+    assert len(xc["per_rank_step_ms_delta"]) == 2 and len(xc["per_rank_kernel_ms_delta"]) == 2
+    assert abs(xc["job_ms_per_step_delta"] - (d["ms_per_step"] - co["ms_per_step"])) < 2e-3
+    # BASELINE config 4 as a sharded job: 124 pairs dealt p mod 2, gathered in pair order, CRCs per rank, a pair of rank 1 against the oracle
+    c4 = d["configs"]["config4_sharded"]
+    assert c4["pairs"] == 124 and c4["pair_counts"] == [62, 62] and c4["crc32_tables_match_per_rank"] == [True, True] and c4["scaling"] == "strong"
+    assert c4["pairs_per_s"] > 0 and c4["one_gpu_same_run"]["pairs_per_s"] > 0 and c4["speedup_vs_one_gpu"] > 0 and len(c4["seconds_passes"]) == 3
+    assert [e["pairs"] for e in c4["per_rank"]] == [62, 62]
+    assert c4["verified"]["searched_by_rank"] == 1 and c4["verified"]["pair_index"] == 1 and c4["verified"]["slots"] >= 593
+    assert c4["gathered_bytes"] == 62 * n_ctu * 593 * 8
     # the whole-job value counts both ranks' pictures
     assert abs(d["ctus_per_s"] - 2 * n_ctu * 3 / (d["ms_per_step"] * 3e-3)) / d["ctus_per_s"] < 0.01
     # without --share-gpu two ranks on a one-GPU box must refuse, not silently share the device
@@ -1081,6 +1127,28 @@ def test_bench_starts_its_own_ranks_two_rank_rehearsal_on_one_gpu(tmp_path):
                         cwd=str(tmp_path))
     assert r2.returncode != 0 and not [ln for ln in r2.stdout.splitlines() if ln.startswith("{")]
     assert "no GPU of its own" in r2.stderr
+
+
+def test_bench_four_rank_rehearsal_deals_config4_raggedly(tmp_path):
+    """`python bench.py --gpus 4 --share-gpu --backend gloo`: four ranks of one job on this one GPU.  124 pairs on 4 ranks are 31 each; the
+    line carries compute_only / exchange_cost for four ranks and config4_sharded with the pair of rank 3 checked against the oracle"""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--share-gpu", "--backend", "gloo", "--steps", "2",
+                        "--warmup", "1", "--size", "256x192", "--search-range", "16"], capture_output=True, text=True, timeout=900, env=env,
+                       cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    m = d["multi_gpu"]
+    assert d["n_gpus"] == 4 and m["ranks_seen"] == 4 and m["crc32_tables_match_per_rank"] == [True] * 4
+    assert len({e["pid"] for e in m["devices"]}) == 4 and len(m["compute_only"]["per_rank_step_ms"]) == 4
+    assert m["verified_rank"]["rank"] == 3
+    c4 = d["configs"]["config4_sharded"]
+    assert c4["pair_counts"] == [31, 31, 31, 31] and c4["crc32_tables_match_per_rank"] == [True] * 4
+    assert c4["verified"]["searched_by_rank"] == 3 and c4["ideal_speedup_at_this_deal"] == 4.0
 
 
 def test_profiling_tooling_produces_a_counter_summary(tmp_path):

@@ -116,3 +116,18 @@ def test_tz_search_over_whole_ctus_matches_reference(oracle_lib):
         rx, ry, rs = oracle_lib.ref_tz_frame(cur, ref, (m, m), w, h, sr, 57.9, 1, bd, 8, 9)
         _, _, ox, oy, os_ = oracle_lib.tz_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, bd, 8, 9, 4, True, True)
         assert np.array_equal(rx, ox) and np.array_equal(ry, oy) and np.array_equal(rs, os_)
+
+
+def test_full_search_over_whole_ctus_matches_reference(oracle_lib):
+    """bench.py's `cpu_baseline.reference_full_search` leg: the reference's own xPatternSearch for each of the 593 PUs of a CTU range (one
+    window per CTU, predictor (0,0)) == the oracle's whole-frame restatement, incl. a picture-edge CTU whose window clipMv cuts, 8 and 10 bit"""
+    from hmme import synth
+    for bd, sr, first in ((8, 12, 0), (10, 7, 8)):
+        w, h = 448, 320
+        cur, ref, _ = synth.make_pair(w, h, seed=70 + bd, bit_depth=bd)
+        m = synth.MARGIN
+        lq = oracle_lib.oracle().hmo_lambda_q16(57.9)
+        rx, ry, rs, dt = oracle_lib.ref_full_search_ctus(cur, ref, (m, m), w, h, sr, 57.9, 1, bd, first, min_ctus=2, max_ctus=2, budget_s=0.0)
+        ox, oy, os_ = oracle_lib.search_frame(cur, ref, (m, m), w, h, sr, None, lq, 1, bd, first, 2, 2)
+        assert rx.shape == (2, 593) and dt > 0
+        assert np.array_equal(rx, ox) and np.array_equal(ry, oy) and np.array_equal(rs, os_)

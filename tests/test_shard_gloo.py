@@ -6,6 +6,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -311,3 +312,116 @@ def test_startup_watchdog_ends_the_rank_that_waits_for_a_sleeping_one():
 def test_shard_docstring_names_the_exchange_that_is_used():
     from hmme import shard
     assert "gather_to_root" in shard.__doc__ and "all_gather_into_tensor" not in shard.__doc__
+
+
+def test_bench_parent_takes_its_ranks_down_when_it_is_terminated(tmp_path):
+    """`python bench.py --gpus N` started without a launcher runs the ranks in a session of their own; a SIGTERM that ends the parent (a
+    harness time-out) must end that session too and remove the status directory -- nothing stays behind on the GPUs.  The launcher is a
+    stand-in here (HMME_BENCH_TEST_LAUNCHER): a process that starts a grandchild, records both pids and the status directory, and sleeps."""
+    import json
+    import signal
+    import subprocess
+    import time
+    note = tmp_path / "pids.json"
+    standin = ("import json, os, subprocess, sys, time\n"
+               "g = subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(300)'])\n"
+               f"json.dump({{'child': os.getpid(), 'grandchild': g.pid, 'status': os.environ['HMME_BENCH_STATUS_DIR']}}, open({str(note)!r}, 'w'))\n"
+               "time.sleep(300)\n")
+    env = dict(os.environ, HMME_BENCH_TEST_LAUNCHER=json.dumps([sys.executable, "-c", standin]))
+    parent = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        t0 = time.time()
+        while not (note.exists() and note.stat().st_size > 0) and time.time() - t0 < 60:
+            time.sleep(0.1)
+        time.sleep(0.2)
+        info = json.loads(note.read_text())
+        assert os.path.isdir(info["status"])
+        parent.send_signal(signal.SIGTERM)
+        out, err = parent.communicate(timeout=60)
+    finally:
+        if parent.poll() is None:
+            parent.kill()
+    assert parent.returncode == 128 + signal.SIGTERM, (parent.returncode, err[-500:])
+    assert "ending the child process group" in err and out == ""
+
+    def alive(pid):
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            return False
+        try:                                   # a zombie of another parent still answers kill(0): look at its state
+            return open(f"/proc/{pid}/stat").read().rsplit(")", 1)[1].split()[0] != "Z"
+        except OSError:
+            return False
+    t0 = time.time()
+    while (alive(info["child"]) or alive(info["grandchild"])) and time.time() - t0 < 15:
+        time.sleep(0.1)
+    assert not alive(info["child"]) and not alive(info["grandchild"]), info
+    assert not os.path.exists(info["status"])
+
+
+# ---- BASELINE config 4 as an N-rank job (bench.py --gpus N `configs.config4_sharded`): 124 pairs dealt p mod N, gathered in pair order -------
+def _job_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "hm-opencl_amd"))
+    from hmme import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pairs = shard.gop_pairs(64, "randomaccess")
+        index = {pr: i for i, pr in enumerate(pairs)}
+        calls = []
+
+        def run_share(share):       # the engine's stand-in: the tables of pair p are a function of p and of the pair's two pictures
+            calls.append(len(share))
+            mv = torch.zeros((len(share), 2, 593, 2), dtype=torch.int16)
+            sad = torch.zeros((len(share), 2, 593), dtype=torch.int32)
+            for i, (c, r) in enumerate(share):
+                mv[i, :, :, 0] = index[(c, r)]
+                mv[i, :, :, 1] = c - r
+                sad[i] = 100000 * c + r
+            return {"mv": mv, "sad": sad, "stages": {"search_s": 0.0}}
+        job = shard.sharded_sequence_job(run_share, pairs, passes=2)
+        assert calls == [len(shard.pairs_for_rank(len(pairs), rank, world))] * 3      # one untimed pass, two timed ones, always this rank's share
+        if rank == 0:
+            mv, sad = job["mv"], job["sad"]
+            ok = tuple(mv.shape) == (124, 2, 593, 2) and tuple(sad.shape) == (124, 2, 593)
+            for p, (c, r) in enumerate(pairs):
+                ok = ok and bool((mv[p, :, :, 0] == p).all()) and bool((mv[p, :, :, 1] == c - r).all()) and bool((sad[p] == 100000 * c + r).all())
+            q.put((ok, job["pair_counts"], job["crc32_tables_match_per_rank"], [e["pairs"] for e in job["per_rank"]], len(job["seconds_passes"]),
+                   job["seconds"] in job["seconds_passes"]))
+        else:
+            assert job is None
+        dist.barrier()
+    except Exception as e:
+        if rank == 0:
+            q.put(repr(e))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+
+@pytest.mark.parametrize("world,counts", [(2, [62, 62]), (3, [42, 41, 41]), (8, [16, 16, 16, 16, 15, 15, 15, 15])])
+def test_config4_sharded_job_deals_124_pairs_and_gathers_them_in_pair_order(world, counts):
+    """the random-access GOP of 64 pictures is 124 pairs (cfg/encoder_randomaccess_main.cfg:28-31): dealt p mod N they are ragged on 3 ranks
+    and on the 8 of BASELINE config 4 (16 / 15); rank 0 ends up with all 124 tables in pair order, every rank's CRC matches what rank 0 holds"""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_job_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=90)
+        assert p.exitcode == 0
+    assert got == (True, counts, [True] * world, counts, 2, True), got
+
+
+def test_sharded_job_without_a_process_group_is_the_one_rank_job():
+    from hmme import shard
+    pairs = shard.gop_pairs(8, "randomaccess")
+    run = lambda share: {"mv": torch.full((len(share), 1, 593, 2), 3, dtype=torch.int16), "sad": torch.ones((len(share), 1, 593), dtype=torch.int32)}
+    job = shard.sharded_sequence_job(run, pairs, passes=1)
+    assert job["pair_counts"] == [len(pairs)] and job["crc32_tables_match_per_rank"] == [True] and tuple(job["mv"].shape) == (len(pairs), 1, 593, 2)

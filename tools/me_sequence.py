@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--dump-pairs", default=None, help="comma-separated pair indices to dump (default all)")
     ap.add_argument("--dump-ctus", default=None, help="first:count CTU range to dump (default all)")
     ap.add_argument("--repeat", type=int, default=1, help="run the pass this many times, report the last (the first includes allocations)")
+    ap.add_argument("--rank-timeout", type=float, default=600.0,
+                    help="N > 1: seconds a rank may take from its start to the end of its first barrier (rendezvous, RCCL communicator) before it "
+                         "gives up with exit code 3, naming itself and the stage it hung in; 0 = no limit")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -54,8 +57,25 @@ def main():
     dev = torch.device("cuda", local)
     use_dist = world > 1 or (os.environ.get("HMME_SEQ_FORCE_DIST") == "1" and "RANK" in os.environ)   # world 1: rehearses the RCCL gather
     if use_dist:
+        # the same start-up evidence and the same loud failure as bench.py --gpus N (hmme/shard.py): what this rank sees before rendezvous, the
+        # ranks counted through the job's store before the first collective, a watchdog that ends a rank stuck before its first barrier
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        watchdog = shard.StartupWatchdog(rank, world, args.rank_timeout, label="me_sequence.py")
+        props = torch.cuda.get_device_properties(local)
+        sys.stderr.write(f"me_sequence.py: rank {rank}/{world} pid {os.getpid()} local_rank {local}: hipGetDeviceCount {torch.cuda.device_count()}, device {props.name} "
+                         f"pci {getattr(props, 'pci_domain_id', 0):04x}:{getattr(props, 'pci_bus_id', 0):02x}:{getattr(props, 'pci_device_id', 0):02x}.0 uuid {getattr(props, 'uuid', '')}, "
+                         f"RCCL {'.'.join(str(v) for v in torch.cuda.nccl.version())}, MASTER {os.environ.get('MASTER_ADDR', '?')}:{os.environ.get('MASTER_PORT', '?')}\n")
+        sys.stderr.flush()
+        watchdog.stage("init_process_group (rendezvous)")
         dist.init_process_group("nccl", device_id=dev)
+        watchdog.stage("rendezvous store count")
+        seen = shard.rendezvous_report(rank, world, timeout_s=max(10.0, args.rank_timeout / 2) if args.rank_timeout > 0 else 120.0)
+        if rank == 0 and seen is not None and seen != world:
+            raise SystemExit(f"me_sequence.py: only {seen} of {world} ranks reached the rendezvous store: nothing reported")
+        watchdog.stage("first barrier (RCCL communicator)")
+        dist.barrier()
+        torch.cuda.synchronize()
+        watchdog.done()
     w, h = {"2160p": (3840, 2160), "1080p": (1920, 1080), "720p": (1280, 720)}.get(args.size) or tuple(int(v) for v in args.size.split("x"))
     bd = args.bit_depth
     pairs = shard.gop_pairs(args.frames, args.gop)
