@@ -122,11 +122,33 @@ class _Reader(threading.Thread):
             self.ready.put(None)
 
 
+class RankResources:
+    """What a pass of run_rank(stream_mode=True) allocates besides its tables -- the ring of plane slots, the page-locked host buffers, the
+    streams -- kept between passes by a caller that runs several (a long-running job allocates once; hipMalloc / hipFree / hipHostMalloc
+    of a pass cost ~10 ms, nothing beside a 0.3 s pass, a fifth of one rank's share of the same job on eight GPUs).  close() frees them."""
+
+    def __init__(self):
+        self.key, self.planes, self.bufs_t, self.streams = None, [], [], {}
+
+    def close(self):
+        for pl in self.planes:
+            pl.close()
+        self.key, self.planes, self.bufs_t = None, [], []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 def run_rank(eng, source, pairs, width, height, bit_depth, search_range, *, stream_mode=False, pairs_per_launch=1, refine=False,
-             download=False, n_slots=None, device=None, host_buffers=4):
+             download=False, n_slots=None, device=None, host_buffers=4, resources=None):
     """searches `pairs` [(cur_poc, ref_poc)] (this rank's share) -> dict with device tensors mv [n, n_ctu, 593, 2] int16,
     sad [n, n_ctu, 593] int32 (+ qmv / cost with refine, + host_* page-locked copies with download) and timings.
-    source: .read_into(poc, out) filling a (height, width) uint8 / uint16 array (hmme.yuv.LumaFile, hmme.synth.Sequence)."""
+    source: .read_into(poc, out) filling a (height, width) uint8 / uint16 array (hmme.yuv.LumaFile, hmme.synth.Sequence).
+    resources: a RankResources the caller keeps between passes of one geometry (streaming mode): plane slots, host buffers and streams are
+    then allocated by the first pass only and stay the caller's to close."""
     import torch
     from . import api
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -145,9 +167,14 @@ def run_rank(eng, source, pairs, width, height, bit_depth, search_range, *, stre
     if download:
         for k in list(out):
             out["host_" + k] = torch.empty(out[k].shape, dtype=out[k].dtype, pin_memory=True)
-    compute = torch.cuda.Stream(device=dev)
-    copy = torch.cuda.Stream(device=dev) if stream_mode else compute
-    dl = torch.cuda.Stream(device=dev) if download else None
+    keep = resources if (resources is not None and stream_mode) else None
+    streams = keep.streams if keep is not None else {}
+    for name in ("compute",) + (("copy",) if stream_mode else ()) + (("dl",) if download else ()):
+        if name not in streams:
+            streams[name] = torch.cuda.Stream(device=dev)
+    compute = streams["compute"]
+    copy = streams["copy"] if stream_mode else compute
+    dl = streams["dl"] if download else None
     stages = {"read_s": 0.0, "upload_s": 0.0, "search_s": 0.0, "refine_s": 0.0, "download_s": 0.0}
     ev_pairs = {k: [] for k in ("upload", "search", "refine", "download")}
 
@@ -205,8 +232,17 @@ def run_rank(eng, source, pairs, width, height, bit_depth, search_range, *, stre
             k = max(len(b) for b in batches) if batches else 1
             n_slots = n_slots or max(8, 2 * k + 2)
             loads, where = plan_plane_loads(pairs, batches, n_slots)
-            planes = [eng.plane(width, height, bit_depth) for _ in range(min(n_slots, max(1, len(pocs))))]
-            bufs_t = [torch.empty((height, width), dtype=t_dt, pin_memory=True) for _ in range(host_buffers)]
+            n_planes = min(n_slots, max(1, len(pocs)))
+            key = (id(eng), width, height, bit_depth, n_planes, host_buffers)
+            if keep is not None and keep.key == key:
+                planes, bufs_t = keep.planes, keep.bufs_t
+            else:
+                if keep is not None:
+                    keep.close()
+                planes = [eng.plane(width, height, bit_depth) for _ in range(n_planes)]
+                bufs_t = [torch.empty((height, width), dtype=t_dt, pin_memory=True) for _ in range(host_buffers)]
+                if keep is not None:
+                    keep.key, keep.planes, keep.bufs_t = key, planes, bufs_t
             bufs = [t.numpy().view(np_dt) for t in bufs_t]
             order = [p for l in loads for (p, _) in l]
             torch.cuda.synchronize(dev)
@@ -247,6 +283,7 @@ def run_rank(eng, source, pairs, width, height, bit_depth, search_range, *, stre
         if reader is not None and reader.is_alive():
             reader.free.put(None)              # unblocks a reader that waits for a buffer after an error on this side
         torch.cuda.synchronize(dev)
-        for pl in planes:
-            pl.close()
+        if keep is None or keep.planes is not planes:
+            for pl in planes:
+                pl.close()
     return out

@@ -260,19 +260,28 @@ def test_fuzz_streaming_configurations_equal_the_resident_run(engine, w, h, n, s
     want = {k: base[k].cpu() for k in ("mv", "sad", "qmv", "cost")}
     rng = np.random.default_rng(w + n)
     n_cfg = int(os.environ.get("HMME_STREAM_FUZZ_CASES", "10" if w < 1000 else "4"))
-    for it in range(n_cfg):
+    keep = sequence.RankResources()      # every other pass runs on plane slots / host buffers / streams kept from earlier passes (what holds a ring's
+    for it in range(n_cfg):              # planes from the pass before is stale and must be overwritten before it is read)
         k = int(rng.integers(1, 5))
         need = max(len({p for i in b for p in pairs[i]}) for b in sequence.plan_batches(pairs, k))
         slots = int(rng.integers(need, need + 4)) if it % 3 else need            # every third run on the smallest possible ring
         refine, download, hb = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), int(rng.integers(1, 5))
         got = sequence.run_rank(engine, seq, pairs, w, h, bd, sr, stream_mode=True, pairs_per_launch=k, refine=refine, download=download,
-                                n_slots=slots, device=dev, host_buffers=hb)
-        tag = dict(k=k, slots=slots, refine=refine, download=download, host_buffers=hb)
+                                n_slots=slots, device=dev, host_buffers=hb, resources=keep if it % 2 else None)
+        tag = dict(k=k, slots=slots, refine=refine, download=download, host_buffers=hb, kept=bool(it % 2))
         for name in ("mv", "sad") + (("qmv", "cost") if refine else ()):
             assert torch.equal(got[name].cpu(), want[name]), (tag, name)
             if download:
                 assert torch.equal(got["host_" + name], want[name]), (tag, "host_" + name)
         assert got["plane_slots"] <= slots and got["uploads"] >= len({p for pr in pairs for p in pr})
+    # the same geometry twice on kept resources, the second time a share of the pairs only (bench.py config4_sharded: rank 0 alone, then its share)
+    for share in (pairs, pairs[1::2]):
+        got = sequence.run_rank(engine, seq, share, w, h, bd, sr, stream_mode=True, device=dev, resources=keep)
+        idx = [pairs.index(p) for p in share]
+        assert torch.equal(got["mv"].cpu(), want["mv"][idx]) and torch.equal(got["sad"].cpu(), want["sad"][idx])
+    assert keep.planes and keep.key is not None
+    keep.close()
+    assert not keep.planes
 
 
 def _planes(engine, w, h, bd, imgs):
