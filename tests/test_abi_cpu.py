@@ -127,7 +127,7 @@ def test_generated_isa_has_no_dpp_hazard():
     csrc = os.path.join(ROOT, "hm-opencl_amd", "csrc")
     r = subprocess.run(["make", "-C", csrc, "check-isa"], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "0 hazard(s)" in r.stdout and "0 SGPR(s) touched" in r.stdout
+    assert "0 hazard(s)" in r.stdout and "0 SGPR(s) touched" in r.stdout and ", 0 out of range" in r.stdout
 
 
 def test_dpp_hazard_checker_treats_branch_targets_as_joins(tmp_path):
@@ -168,6 +168,42 @@ def test_isa_checker_flags_sgprs_touched_while_a_scalar_load_is_pending(tmp_path
     assert run(ld + "\ts_waitcnt lgkmcnt(1)\n\ts_add_u32 s2, s8, 1\n").returncode == 1                              # lgkmcnt(1) retires nothing
     assert run(ld + "\ts_mul_i32 s6, s3, 7\n\ts_load_dwordx2 s[8:9], s[4:5], s6 offset:80\n\ts_waitcnt lgkmcnt(0)\n").returncode == 0   # prefetch pattern
     assert run(ld + "\ts_load_dwordx2 s[10:11], s[4:5], s8 offset:80\n\ts_waitcnt lgkmcnt(0)\n").returncode == 1     # pending register as offset
+
+
+def test_isa_checker_flags_immediates_the_assembler_accepts_and_the_hardware_does_not(tmp_path):
+    """tools/check_dpp_hazard.py, third check: round 5's wrong-result build asked v_lshl_add_u64 for a shift by 6 and 7 -- it assembles, the
+    hardware shifts by 0..4 only.  The checker must flag that on the CPU (and the other hand-picked encodings whose fields have a range),
+    and must pass the forms the tree uses"""
+    import subprocess
+    import sys
+    tool = os.path.join(ROOT, "tools", "check_dpp_hazard.py")
+
+    def run(body):
+        p = tmp_path / "k.s"
+        p.write_text("kernel_a:\n" + body)
+        return subprocess.run([sys.executable, tool, str(p)], capture_output=True, text=True)
+    good = ("\tv_lshl_add_u64 v[6:7], v[6:7], 4, s[2:3]\n\tv_lshl_add_u64 v[0:1], v[0:1], 0, v[4:5]\n\tds_read2_b32 v[12:13], v132 offset0:98 offset1:255\n"
+            "\tds_read_b32 v1, v2 offset:65532\n\tv_mad_u32_u16 v62, v20, s29, v109 op_sel:[1,0,0,0]\n\ts_setprio 3\n\ts_nop 15\n"
+            "\tv_add_u32 v9, v3, v4\n\ts_nop 1\n\tv_min_u32_dpp v69, v27, v27 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0x3\n"
+            "\tv_min_u32_dpp v1, v2, v2 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_load_dwordx2 s[8:9], s[4:5], 0xff8\n\ts_waitcnt lgkmcnt(0)\n"
+            "\tv_alignbyte_b32 v1, v2, v3, 3\n\tv_alignbyte_b32 v1, v2, v3, v4\n")
+    r = run(good)
+    assert r.returncode == 0 and "0 out of range" in r.stdout, r.stdout
+    for bad, why in (("\tv_lshl_add_u64 v[6:7], v[6:7], 6, s[2:3]\n", "shifts by 0..4 only"),            # round 5's build
+                     ("\tv_lshl_add_u64 v[6:7], v[6:7], 7, v[2:3]\n", "shifts by 0..4 only"),
+                     ("\tds_read2_b32 v[12:13], v132 offset0:98 offset1:256\n", "outside 0..255"),
+                     ("\tds_write2_b64 v4, v[6:7], v[52:53] offset:8\n", "offset0 / offset1"),
+                     ("\tv_min_u32_dpp v69, v27, v27 row_ror:16 row_mask:0xf bank_mask:0xf\n", "outside 1..15"),
+                     ("\tv_min_u32_dpp v69, v27, v27 quad_perm:[1,0,4,2] row_mask:0xf bank_mask:0xf\n", "four digits 0..3"),
+                     ("\tv_min_u32_dpp v69, v27, v27 row_share:3 row_mask:0xf bank_mask:0xf\n", "not a DPP control"),
+                     ("\tv_min_u32_dpp v69, v27, v27 row_ror:8 row_mask:0x1f bank_mask:0xf\n", "outside 0..0xf"),
+                     ("\tv_mov_b32_dpp v1, v2 row_bcast:16 row_mask:0xf bank_mask:0xf\n", "only 15 and 31"),
+                     ("\tv_mad_u32_u16 v62, v20, s29, v109 op_sel:[2,0,0,0]\n", "0 or 1"),
+                     ("\ts_setprio 4\n", "outside 0..3"), ("\ts_nop 16\n", "outside 0..15"),
+                     ("\ts_load_dwordx2 s[8:9], s[4:5], s6 offset:-8\n\ts_waitcnt lgkmcnt(0)\n", "scalar-load offset"),
+                     ("\tv_alignbyte_b32 v1, v2, v3, 4\n", "outside 0..3")):
+        r = run(good + bad)
+        assert r.returncode == 1 and why in r.stdout and "1 out of range" in r.stdout, (bad, r.stdout)
 
 
 def test_cpu_side_code_is_clean_under_asan_and_ubsan(tmp_path):
