@@ -1006,8 +1006,8 @@ def main():
                                         "`traffic` is the MEASURED HBM bytes per launch (neighbouring windows hit the XCD's L2), "
                                         "`traffic_gbs` = traffic / kernel time",
                          "traffic_gbs": round(traffic / (kernel_ms * 1e-3) / 1e9, 2) if traffic is not None else None,
-                         "kernel": ("me_search_kernel<1, 0, CPITCH> (CPITCH = the planes' pitch, 4096 / 2304, where it has an instantiation; else 0)" if bd == 8
-                                    else "me_search16_kernel<1, PDW[, CPITCH]> (+ merge-table preset and finalize)"),
+                         "kernel": ("me_search_kernel<1, 0> (current picture read from the plane's CTU-blocked copy: one instantiation for every picture size)" if bd == 8
+                                    else "me_search16_kernel<1, PDW> (+ merge-table preset and finalize)"),
                          "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "kernel is VALU-bound (1664 abs-diff ops per unique input byte at SR 64, SURVEY 8d); "

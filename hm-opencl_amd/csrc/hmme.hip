@@ -139,7 +139,6 @@ struct hmme_ctx {
   int out_cap = 0;
   int* d_flag = nullptr;
   bool lds_optin[8] = {false, false, false, false, false, false, false, false};
-  bool lds_optin_cpitch = false;   // the same for me_search16_kernel<1, 161, 8192>
   int num_cus = 0;
   bool frac_lds_optin[3][2] = {{false, false}, {false, false}, {false, false}};   // [8-bit | u16 | u16 weighted][hadamard]
   int frac_wg_per_cu[2][2] = {{0, 0}, {0, 0}};   // [wide][hadamard] workgroups of me_frac_kernel a CU holds (runtime occupancy query, first use)
@@ -159,6 +158,11 @@ struct hmme_plane {
   int pitch = 0;          // bytes per row, multiple of 256
   int rows = 0;           // height + 2 * kMarginY
   uint8_t* d_data = nullptr;
+  // the picture area once more, CTU by CTU: block (cx, cy) = 64 rows x 64 samples, contiguous, raster order of CTUs, partial edge CTUs
+  // completed by edge replication -- what the search kernels read the CURRENT picture from (scalar loads at immediate offsets, whatever
+  // the picture's size: me_kernels.hpp me_prefetch_cur).  Written by every fill right behind the padded plane (plane_fill).
+  uint8_t* d_blocks = nullptr;
+  int ctus_x = 0, n_ctu = 0;
   void* d_stage = nullptr;  // device staging for uploads
   size_t stage_bytes = 0;
   hipEvent_t filled = nullptr;      // recorded after the last fill; readers on another stream wait for it
@@ -257,23 +261,15 @@ int fair_prio(const hmme_ctx* ctx, int workgroups, bool whole_jobs) {
   return (whole_jobs || workgroups <= 4 * ctx->wg_slots) ? 1 : 0;
 }
 
-int launch_search8(hmme_ctx* ctx, const RefSet& cur, int cur_pitch, const RefSet& ref, int ref_pitch, const MeJob* d_jobs,
+int launch_search8(hmme_ctx* ctx, const RefSet& cur, int cur_ctus_x, const RefSet& ref, int ref_pitch, const MeJob* d_jobs,
                    int n_jobs, int fen, int16_t* d_mv, uint32_t* d_sad, hipStream_t stream) {
   if (n_jobs <= 0) return HMME_OK;
   const int fair = fair_prio(ctx, n_jobs, true);
-  // (the pitches of 2160p and 1080p planes as compile-time constants: me_kernels.hpp CPITCH; HMME_CPITCH=0 forces the general kernel for A/B runs)
-  static const bool any_pitch = std::getenv("HMME_CPITCH") && std::atoi(std::getenv("HMME_CPITCH")) == 0;
-  if (fen && cur_pitch == 4096 && !any_pitch)
-    hipLaunchKernelGGL((hmme::me_search_kernel<1, 0, 4096>), dim3(n_jobs), dim3(hmme::kThreads), 0, stream, cur, cur_pitch, ref,
-                       ref_pitch, (const void*)d_jobs, ctx->lambda_q16, d_mv, d_sad, (unsigned long long*)nullptr, fair);
-  else if (fen && cur_pitch == 2304 && !any_pitch)
-    hipLaunchKernelGGL((hmme::me_search_kernel<1, 0, 2304>), dim3(n_jobs), dim3(hmme::kThreads), 0, stream, cur, cur_pitch, ref,
-                       ref_pitch, (const void*)d_jobs, ctx->lambda_q16, d_mv, d_sad, (unsigned long long*)nullptr, fair);
-  else if (fen)
-    hipLaunchKernelGGL((hmme::me_search_kernel<1, 0>), dim3(n_jobs), dim3(hmme::kThreads), 0, stream, cur, cur_pitch, ref,
+  if (fen)
+    hipLaunchKernelGGL((hmme::me_search_kernel<1, 0>), dim3(n_jobs), dim3(hmme::kThreads), 0, stream, cur, cur_ctus_x, ref,
                        ref_pitch, (const void*)d_jobs, ctx->lambda_q16, d_mv, d_sad, (unsigned long long*)nullptr, fair);
   else
-    hipLaunchKernelGGL((hmme::me_search_kernel<0, 0>), dim3(n_jobs), dim3(hmme::kThreads), 0, stream, cur, cur_pitch, ref,
+    hipLaunchKernelGGL((hmme::me_search_kernel<0, 0>), dim3(n_jobs), dim3(hmme::kThreads), 0, stream, cur, cur_ctus_x, ref,
                        ref_pitch, (const void*)d_jobs, ctx->lambda_q16, d_mv, d_sad, (unsigned long long*)nullptr, fair);
   HIP_TRY(ctx, hipGetLastError());
   return HMME_OK;
@@ -296,7 +292,7 @@ int merge_table(hmme_ctx* ctx, int n_jobs, unsigned long long* preset, hipStream
   return HMME_OK;
 }
 
-int launch_search8_split(hmme_ctx* ctx, const RefSet& cur, int cur_pitch, const RefSet& ref, int ref_pitch, const MeJob16* d_jobs,
+int launch_search8_split(hmme_ctx* ctx, const RefSet& cur, int cur_ctus_x, const RefSet& ref, int ref_pitch, const MeJob16* d_jobs,
                          const int* d_first_strip, int n_jobs, int n_split, int fen, int16_t* d_mv, uint32_t* d_sad,
                          hipStream_t stream, unsigned long long* preset_best = nullptr, bool finalize = true) {
   if (n_jobs <= 0) return HMME_OK;
@@ -305,10 +301,10 @@ int launch_search8_split(hmme_ctx* ctx, const RefSet& cur, int cur_pitch, const 
   if (rc) return rc;
   const int fair = fair_prio(ctx, n_jobs * n_split, false);
   if (fen)
-    hipLaunchKernelGGL((hmme::me_search_kernel<1, 1>), dim3(n_jobs * n_split), dim3(hmme::kThreads), 0, stream, cur, cur_pitch,
+    hipLaunchKernelGGL((hmme::me_search_kernel<1, 1>), dim3(n_jobs * n_split), dim3(hmme::kThreads), 0, stream, cur, cur_ctus_x,
                        ref, ref_pitch, (const void*)d_jobs, ctx->lambda_q16, (int16_t*)nullptr, (uint32_t*)nullptr, best, fair);
   else
-    hipLaunchKernelGGL((hmme::me_search_kernel<0, 1>), dim3(n_jobs * n_split), dim3(hmme::kThreads), 0, stream, cur, cur_pitch,
+    hipLaunchKernelGGL((hmme::me_search_kernel<0, 1>), dim3(n_jobs * n_split), dim3(hmme::kThreads), 0, stream, cur, cur_ctus_x,
                        ref, ref_pitch, (const void*)d_jobs, ctx->lambda_q16, (int16_t*)nullptr, (uint32_t*)nullptr, best, fair);
   HIP_TRY(ctx, hipGetLastError());
   return finalize ? finalize_best(ctx, best, d_jobs, d_first_strip, n_jobs, d_mv, d_sad, stream) : HMME_OK;
@@ -333,36 +329,21 @@ int strips_for(int pdw, int wy_max) {
 }
 
 template <int FEN, int PDW>
-int launch16_t(hmme_ctx* ctx, const RefSet& cur, int cur_pitch, const RefSet& ref, int ref_pitch, const MeJob16* d_jobs, int n_wg,
+int launch16_t(hmme_ctx* ctx, const RefSet& cur, int cur_ctus_x, const RefSet& ref, int ref_pitch, const MeJob16* d_jobs, int n_wg,
                size_t lds, int sh, unsigned long long* d_best, hipStream_t stream) {
-  // BASELINE config 5's shape -- 2160p planes of 16-bit samples (pitch 8192), search range 97..128, FEN -- has an instantiation with the pitch
-  // as a compile-time constant (me_kernels.hpp CPITCH); HMME_CPITCH=0 runs the general kernel
-  static const bool any_pitch = std::getenv("HMME_CPITCH") && std::atoi(std::getenv("HMME_CPITCH")) == 0;
-  if constexpr (FEN == 1 && PDW == 161) {
-    if (cur_pitch == 8192 && !any_pitch) {
-      if (!ctx->lds_optin_cpitch) {
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)hmme::me_search16_kernel<1, 161, 8192>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ctx->lds_optin_cpitch = true;
-      }
-      hipLaunchKernelGGL((hmme::me_search16_kernel<1, 161, 8192>), dim3(n_wg), dim3(hmme::kThreads16), lds, stream, cur, cur_pitch, ref,
-                         ref_pitch, d_jobs, ctx->lambda_q16, sh, d_best, fair_prio(ctx, n_wg, false));
-      HIP_TRY(ctx, hipGetLastError());
-      return HMME_OK;
-    }
-  }
   bool& attr_set = ctx->lds_optin[FEN * 4 + pdw16_index(PDW)];   // > 64 KiB of dynamic LDS: opt in once per
   if (!attr_set) {                                                            // kernel and device (= per context)
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)hmme::me_search16_kernel<FEN, PDW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((hmme::me_search16_kernel<FEN, PDW>), dim3(n_wg), dim3(hmme::kThreads16), lds, stream, cur, cur_pitch, ref,
+  hipLaunchKernelGGL((hmme::me_search16_kernel<FEN, PDW>), dim3(n_wg), dim3(hmme::kThreads16), lds, stream, cur, cur_ctus_x, ref,
                      ref_pitch, d_jobs, ctx->lambda_q16, sh, d_best, fair_prio(ctx, n_wg, false));
   HIP_TRY(ctx, hipGetLastError());
   return HMME_OK;
 }
 
 // d_jobs: n_jobs * n_strips MeJob16; results merged in ctx->d_best then decoded into d_mv / d_sad
-int launch_search16(hmme_ctx* ctx, const RefSet& cur, int cur_pitch, const RefSet& ref, int ref_pitch, const MeJob16* d_jobs,
+int launch_search16(hmme_ctx* ctx, const RefSet& cur, int cur_ctus_x, const RefSet& ref, int ref_pitch, const MeJob16* d_jobs,
                     const int* d_first_strip, int n_jobs, int n_wg, int pdw, int strip_rows_max, int fen, int bit_depth,
                     int16_t* d_mv, uint32_t* d_sad, hipStream_t stream, unsigned long long* preset_best = nullptr, bool finalize = true) {
   if (n_jobs <= 0) return HMME_OK;
@@ -372,8 +353,8 @@ int launch_search16(hmme_ctx* ctx, const RefSet& cur, int cur_pitch, const RefSe
   const size_t lds = lds_bytes16(pdw, strip_rows_max);
   const int sh = bit_depth - 8;
 #define LAUNCH16(I)                                                                                                       \
-  rc = fen ? launch16_t<1, kPdw16[I]>(ctx, cur, cur_pitch, ref, ref_pitch, d_jobs, n_wg, lds, sh, best, stream)            \
-           : launch16_t<0, kPdw16[I]>(ctx, cur, cur_pitch, ref, ref_pitch, d_jobs, n_wg, lds, sh, best, stream)
+  rc = fen ? launch16_t<1, kPdw16[I]>(ctx, cur, cur_ctus_x, ref, ref_pitch, d_jobs, n_wg, lds, sh, best, stream)            \
+           : launch16_t<0, kPdw16[I]>(ctx, cur, cur_ctus_x, ref, ref_pitch, d_jobs, n_wg, lds, sh, best, stream)
   switch (pdw16_index(pdw)) {
     case 0: LAUNCH16(0); break;
     case 1: LAUNCH16(1); break;
@@ -433,6 +414,11 @@ int plane_fill(hmme_plane* pl, const SrcT* d_src, int src_pitch_elems, hipStream
   dim3 grid((pl->pitch / 4 + 255) / 256, pl->rows);
   hipLaunchKernelGGL((hmme::me_fill_plane_kernel<SrcT, DstT>), grid, dim3(256), 0, s, pl->d_data, pl->pitch, kMarginX, kMarginY,
                      pl->width, pl->height, d_src, src_pitch_elems, (1 << pl->bit_depth) - 1, ctx->d_flag + (check ? 0 : 1));
+  HIP_TRY(ctx, hipGetLastError());
+  // ... and the CTU-blocked copy the searches read the current picture from (one more pass over the staged picture: 8 MB at 2160p)
+  const long blk_threads = (long)pl->n_ctu * (hmme::kBlkBytes8 * pl->bps / 4);
+  hipLaunchKernelGGL((hmme::me_fill_blocks_kernel<SrcT, DstT>), dim3((unsigned)((blk_threads + 255) / 256)), dim3(256), 0, s, pl->d_blocks, pl->ctus_x,
+                     pl->n_ctu, pl->width, pl->height, d_src, src_pitch_elems);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(pl->filled, s));
   pl->fill_stream = s; pl->fill_pending = true;
@@ -901,9 +887,9 @@ int ctu_call(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int16_t* r
   const uint32_t seq = ++ctx->call_seq ? ctx->call_seq : ++ctx->call_seq;   // never 0, the words' initial value
   if (do_search) {
   if (!wide)
-    rc = launch_search8_split(ctx, one_ref(ctx->d_call + kCallCtu), 64, one_ref(ref_base), kWinPitch, d_js, d_first, 1, n_wg, p->fen, d_mv1, d_sad1, s, d_best1, false);
+    rc = launch_search8_split(ctx, one_ref(ctx->d_call + kCallCtu), 1, one_ref(ref_base), kWinPitch, d_js, d_first, 1, n_wg, p->fen, d_mv1, d_sad1, s, d_best1, false);
   else
-    rc = launch_search16(ctx, one_ref(ctx->d_call + kCallCtu), 128, one_ref(ref_base_search), kWinPitch, d_js, d_first, 1, n_wg, pdw, smax, wp ? 0 : p->fen, shift_bd,   // xGetSADw reads every row
+    rc = launch_search16(ctx, one_ref(ctx->d_call + kCallCtu), 1, one_ref(ref_base_search), kWinPitch, d_js, d_first, 1, n_wg, pdw, smax, wp ? 0 : p->fen, shift_bd,   // xGetSADw reads every row
                          d_mv1, d_sad1, s, d_best1, false);
   if (rc) return rc;
   hipLaunchKernelGGL(hmme::me_finalize1_kernel, dim3(1), dim3(640), 0, s, d_best1, d_js, ctx->lambda_q16, d_mv1, d_sad1,
@@ -990,8 +976,10 @@ int hmme_plane_create_ex(hmme_ctx* ctx, int width, int height, int bit_depth, hm
   pl->bit_depth = bit_depth; pl->bps = bit_depth > 8 ? 2 : 1;
   pl->pitch = ((width + 2 * kMarginX) * pl->bps + 255) & ~255;
   pl->rows = height + 2 * kMarginY;
+  pl->ctus_x = (width + 63) / 64; pl->n_ctu = hmme_num_ctus(width, height);
   hipError_t e = hipMalloc(&pl->d_data, (size_t)pl->pitch * (pl->rows + 1));
-  if (e == hipSuccess && (e = hipEventCreateWithFlags(&pl->filled, hipEventDisableTiming)) != hipSuccess) hipFree(pl->d_data);
+  if (e == hipSuccess && (e = hipMalloc(&pl->d_blocks, (size_t)pl->n_ctu * hmme::kBlkBytes8 * pl->bps)) != hipSuccess) hipFree(pl->d_data);
+  if (e == hipSuccess && (e = hipEventCreateWithFlags(&pl->filled, hipEventDisableTiming)) != hipSuccess) { hipFree(pl->d_data); hipFree(pl->d_blocks); }
   if (e != hipSuccess) { delete pl; return fail(ctx, HMME_ERR_NOMEM, "plane allocation: %s", hipGetErrorString(e)); }
   *out = pl;
   return HMME_OK;
@@ -1005,6 +993,7 @@ void hmme_plane_destroy(hmme_plane* pl) {
   if (pl->read_pending) hipEventSynchronize(pl->read_done);
   if (pl->filled) hipEventDestroy(pl->filled);
   hipFree(pl->d_data);
+  hipFree(pl->d_blocks);
   hipFree(pl->d_stage);
   delete pl;
 }
@@ -1215,20 +1204,21 @@ static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_para
   return HMME_OK;
 }
 
-static int run_search(hmme_ctx* ctx, const RefSet& curs, int cur_pitch, const RefSet& refs, int ref_pitch, const hmme_frame_params* fp, const FramePlan& pl,
+// curs: the CTU-blocked copies of the current pictures (hmme_plane::d_blocks), cur_ctus_x their blocks per block row
+static int run_search(hmme_ctx* ctx, const RefSet& curs, int cur_ctus_x, const RefSet& refs, int ref_pitch, const hmme_frame_params* fp, const FramePlan& pl,
                       int16_t* d_mv, uint32_t* d_sad, hipStream_t s) {
   if (fp->bit_depth > 8)
-    return launch_search16(ctx, curs, cur_pitch, refs, ref_pitch, (const MeJob16*)ctx->d_jobs, ctx->d_first_strip, pl.jobs, pl.n_wg16,
+    return launch_search16(ctx, curs, cur_ctus_x, refs, ref_pitch, (const MeJob16*)ctx->d_jobs, ctx->d_first_strip, pl.jobs, pl.n_wg16,
                            pl.pdw, pl.strip_rows, fp->fen, fp->bit_depth, d_mv, d_sad, s);
   if (pl.tile8)
-    return launch_search8_split(ctx, curs, cur_pitch, refs, ref_pitch, (const MeJob16*)ctx->d_jobs, ctx->d_first_strip, pl.jobs, 4,
+    return launch_search8_split(ctx, curs, cur_ctus_x, refs, ref_pitch, (const MeJob16*)ctx->d_jobs, ctx->d_first_strip, pl.jobs, 4,
                                 fp->fen, d_mv, d_sad, s);
   const int head = pl.tail_first, n_tail = pl.jobs - head;
   unsigned long long* best = nullptr;
   int rc = n_tail ? merge_table(ctx, n_tail, nullptr, s, &best) : HMME_OK;   // the tail's merge table is preset before the head runs, not between the two
-  if (rc == HMME_OK) rc = launch_search8(ctx, curs, cur_pitch, refs, ref_pitch, (const MeJob*)ctx->d_jobs, head, fp->fen, d_mv, d_sad, s);
+  if (rc == HMME_OK) rc = launch_search8(ctx, curs, cur_ctus_x, refs, ref_pitch, (const MeJob*)ctx->d_jobs, head, fp->fen, d_mv, d_sad, s);
   if (rc || !n_tail) return rc;
-  return launch_search8_split(ctx, curs, cur_pitch, refs, ref_pitch, (const MeJob16*)((const uint8_t*)ctx->d_jobs + pl.tail_jobs_off), ctx->d_first_strip,
+  return launch_search8_split(ctx, curs, cur_ctus_x, refs, ref_pitch, (const MeJob16*)((const uint8_t*)ctx->d_jobs + pl.tail_jobs_off), ctx->d_first_strip,
                               n_tail, pl.tail_parts, fp->fen, d_mv + (size_t)head * 2 * HMME_NUM_CTU_PARTS, d_sad + (size_t)head * HMME_NUM_CTU_PARTS, s, best);
 }
 
@@ -1236,18 +1226,20 @@ static int run_search(hmme_ctx* ctx, const RefSet& curs, int cur_pitch, const Re
 namespace {
 struct PairLaunch {
   RefSet curs, refs;
+  RefSet cur_blocks;   // the current pictures' CTU-blocked copies: what the search kernels read (the refinement reads the padded planes)
   int first = 0, count = 0;
 };
 int pairs_begin(hmme_ctx* ctx, const hmme_plane* const* curs, const hmme_plane* const* refs, int n_pairs, const hmme_frame_params* fp,
                 hipStream_t s, PairLaunch* pl) {
   if (!curs || !refs || n_pairs < 1 || n_pairs > hmme::kMaxRefs) return fail(ctx, HMME_ERR_ARG, "%d picture pairs outside 1..%d", n_pairs, hmme::kMaxRefs);
-  pl->curs = one_ref(nullptr); pl->refs = one_ref(nullptr);
+  pl->curs = one_ref(nullptr); pl->refs = one_ref(nullptr); pl->cur_blocks = one_ref(nullptr);
   for (int r = 0; r < n_pairs; ++r) {
     int rc = check_frame_args(ctx, curs[r], refs[r], fp, &pl->first, &pl->count);
     if (rc) return rc;
     if (refs[r]->pitch != refs[0]->pitch || curs[r]->pitch != curs[0]->pitch || curs[r]->width != curs[0]->width || curs[r]->height != curs[0]->height)
       return fail(ctx, HMME_ERR_ARG, "the planes of one launch differ in size");
     pl->curs.base[r] = curs[r]->origin();
+    pl->cur_blocks.base[r] = curs[r]->d_blocks;
     pl->refs.base[r] = refs[r]->origin();
   }
   if (pl->count == 0) return HMME_OK;
@@ -1284,7 +1276,7 @@ int hmme_search_pairs_device(hmme_ctx* ctx, const hmme_plane* const* curs, const
   if (rc || pl.count == 0) return rc;
   FramePlan plan;
   rc = prep_jobs(ctx, curs[0], fp, d_pred_q, pl.first, pl.count, n_pairs, s, &plan);
-  if (rc == HMME_OK) rc = run_search(ctx, pl.curs, curs[0]->pitch, pl.refs, refs[0]->pitch, fp, plan, (int16_t*)d_out_mv, (uint32_t*)d_out_sad, s);
+  if (rc == HMME_OK) rc = run_search(ctx, pl.cur_blocks, curs[0]->ctus_x, pl.refs, refs[0]->pitch, fp, plan, (int16_t*)d_out_mv, (uint32_t*)d_out_sad, s);
   return pairs_end(ctx, curs, refs, n_pairs, s, rc);
 }
 
@@ -1486,7 +1478,7 @@ int hmme_test_time_search_kernel(hmme_ctx* ctx, const hmme_plane* cur, const hmm
   if (rc == HMME_OK && (e = hipEventCreate(&e0)) == hipSuccess && (e = hipEventCreate(&e1)) == hipSuccess) {
     e = hipEventRecord(e0, s);
     for (int i = 0; i < reps && rc == HMME_OK && e == hipSuccess; ++i)
-      rc = run_search(ctx, pl.curs, cur->pitch, pl.refs, ref->pitch, fp, plan, (int16_t*)d_out_mv, (uint32_t*)d_out_sad, s);
+      rc = run_search(ctx, pl.cur_blocks, cur->ctus_x, pl.refs, ref->pitch, fp, plan, (int16_t*)d_out_mv, (uint32_t*)d_out_sad, s);
     if (rc == HMME_OK && e == hipSuccess) e = hipEventRecord(e1, s);
     if (rc == HMME_OK && e == hipSuccess) e = hipEventSynchronize(e1);
     if (rc == HMME_OK && e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);

@@ -263,22 +263,25 @@ __host__ __device__ inline int me_strip_rows16(int wx, int wy, int rows_max, int
   return best_h;
 }
 
-// Pulls the 64 rows of a workgroup's current block (LINES 64-byte lines each) into the scalar cache while the window is being staged:
+// The current picture is read from its CTU-BLOCKED copy (hmme_plane::d_blocks, written by me_fill_blocks_kernel beside the padded plane): CTU
+// (cx, cy) is one contiguous block of 64 rows x 64 samples, blocks in raster order, partial edge CTUs completed by edge replication.  A
+// current-block load of the search kernels is then `s_load_dwordx2 / x4` at the IMMEDIATE offset row * 64 * BPS + 8 * BPS * q from the block's
+// address, whatever the picture's size: no pitch in the kernel, no s_mul_i32 in front of the 512 loads of a lane-iteration (5.5 % of its
+// instructions -- round 5 removed them for the pitches of 2160p and 1080p planes only, by compile-time pitch instantiations that this
+// layout replaces), the block's 64 (128) cache lines consecutive instead of one per plane row.  The per-CTU call hands over a dense
+// 64 x 64 block already: one block, the same kernels.
+constexpr int kBlkBytes8 = 64 * 64, kBlkBytes16 = 2 * 64 * 64;
+// Pulls a workgroup's current block (64 * LINES consecutive 64-byte lines) into the scalar cache while the window is being staged:
 // the first lane-iteration would otherwise meet every line cold, one CU at a time -- visible where a workgroup runs only a few
 // iterations (the per-CTU call: 64 workgroups per search).  One wave issues the loads; nothing reads the results.
 template <int LINES>
-__device__ __forceinline__ void me_prefetch_cur(uint64_t curc, uint32_t pitch) {
+__device__ __forceinline__ void me_prefetch_cur(uint64_t curc) {
   // every load targets the SAME register `d`, an in-out operand of each statement and of the final wait: it stays allocated for the
-  // whole sequence, so the compiler can never hand it to another value (the offset temporary `o` of a later statement, say) while
-  // loads into it are still in flight -- the inline scalar loads are invisible to its own waitcnt / liveness tracking
+  // whole sequence, so the compiler can never hand it to another value while loads into it are still in flight -- the inline scalar
+  // loads are invisible to its own waitcnt / liveness tracking
   uint32_t d = 0;
 #pragma unroll
-  for (int r = 0; r < 64; ++r)
-#pragma unroll
-    for (int l = 0; l < LINES; ++l) {
-      uint32_t o;
-      asm volatile("s_mul_i32 %1, %3, %4\n\ts_load_dword %0, %2, %1 offset:%5" : "+s"(d), "=&s"(o) : "s"(curc), "s"(pitch), "n"(r), "n"(64 * l));
-    }
+  for (int l = 0; l < 64 * LINES; ++l) asm volatile("s_load_dword %0, %1, %2" : "+s"(d) : "s"(curc), "n"(64 * l));
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d));
 }
 
@@ -313,13 +316,10 @@ constexpr int kTileStep = 129, kTileJobMask = 0x1fffffff;
 // SPLIT = 0: one workgroup searches the whole window of jobs[blockIdx.x] (MeJob) and writes its 593 results.
 // SPLIT = 1: jobs are MeJob16; the workgroup runs tasks [y0, y1) only and merges into g_best with 64-bit atomicMin
 //            (decoded afterwards by me_finalize16_kernel) -- used where one CTU must fill many CUs.
-// CPITCH: the current picture's pitch in bytes as a compile-time constant (0 = any pitch).  A current-block load is s_load_dwordx2 at
-// row * pitch + 8 * q: with the pitch known the offset is an immediate; without, every one of the 512 loads of a lane-iteration is
-// preceded by an s_mul_i32 -- 5.5 % of the instructions of the body, and this kernel's time follows its instruction count.  The pitches of
-// the BASELINE pictures (2160p: 4096, 1080p: 2304) have instantiations of their own (hmme.hip launch_search8); any other picture runs CPITCH 0.
-template <int FEN, int SPLIT, int CPITCH = 0>
+// curs: the CTU-blocked copies of the current pictures (above me_prefetch_cur), cur_ctus_x: CTUs per picture row (blocks per block row).
+template <int FEN, int SPLIT>
 __global__ void __launch_bounds__(kThreads, 2)
-me_search_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitch,
+me_search_kernel(const RefSet curs, int cur_ctus_x, const RefSet refs, int ref_pitch,
                  const void* __restrict__ jobs_v, uint32_t lambda_q16, int16_t* __restrict__ out_mv,
                  uint32_t* __restrict__ out_sad, unsigned long long* __restrict__ g_best, int fair_prio) {
   __shared__ uint32_t win[kWinRowsMax * kPDW];
@@ -355,11 +355,10 @@ me_search_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pi
 
   // -- 0. the current block is read through the scalar cache straight into SGPRs (v_qsad_pk_u16_u8 takes its 4 current-block bytes
   //       from one): no LDS copy, no wave-uniform ds_read_b64 (each cost a full LDS slot), 35 VGPRs fewer
-  const uintptr_t cur_addr = (uintptr_t)(cur_base + (long)job.ctu_y * cur_pitch + job.ctu_x);
+  const uintptr_t cur_addr = (uintptr_t)(cur_base + ((long)(job.ctu_y >> 6) * cur_ctus_x + (job.ctu_x >> 6)) * kBlkBytes8);
   const uint64_t curc = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)cur_addr) |
                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(cur_addr >> 32)) << 32;
-  const uint32_t cur_pitch_s = (uint32_t)__builtin_amdgcn_readfirstlane(cur_pitch);
-  if (tid < 64) me_prefetch_cur<1>(curc, cur_pitch_s);
+  if (tid < 64) me_prefetch_cur<1>(curc);
   // -- 1. stage the reference window: LDS row r, byte b  <->  ref(ctu_x + lt_x + b, ctu_y + lt_y + r)
   {
     const uint8_t* src = ref_base + (long)(job.ctu_y + job.lt_y) * ref_pitch + (job.ctu_x + job.lt_x);
@@ -484,13 +483,7 @@ me_search_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pi
 #define ME8_CUR(row, q)                                                                                                            \
   ({                                                                                                                               \
     uint64_t w_;                                                                                                                   \
-    if constexpr (CPITCH != 0) {                                                                                                   \
-      asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(w_) : "s"(curc), "n"((row) * CPITCH + 8 * (q)));                              \
-    } else {                                                                                                                       \
-      uint32_t o_;                                                                                                                 \
-      asm volatile("s_mul_i32 %1, %3, %4\n\ts_load_dwordx2 %0, %2, %1 offset:%5"                                                   \
-                   : "=s"(w_), "=&s"(o_) : "s"(curc), "s"(cur_pitch_s), "n"(row), "n"(8 * (q)));                                    \
-    }                                                                                                                              \
+    asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(w_) : "s"(curc), "n"((row) * 64 + 8 * (q)));                                    \
     w_;                                                                                                                            \
   })
 #define ME8_CUR_WAIT(w0, w1, w2, w3, w4, w5, w6, w7, d0, d1, d2, d3, d4, d5, d6, d7, d8, d9, d10, d11, d12, d13, d14, d15)           \
@@ -640,6 +633,27 @@ __global__ void me_fill_plane_kernel(uint8_t* __restrict__ dst, int dst_pitch, i
   if (bad) atomicOr(flag, 1);
 }
 
+// the same picture area -> the plane's CTU-blocked copy (see me_prefetch_cur): block (cx, cy) holds samples (64 cx + c, 64 cy + r) at
+// [r][c], coordinates beyond the picture clamped to its last column / row (what the padded plane holds there).  One thread per 4 output
+// bytes, a row of a block per 16 (32) threads: 64-byte (128-byte) contiguous writes.  Range violations are the padded fill's to report.
+template <typename SrcT, typename DstT>
+__global__ void me_fill_blocks_kernel(uint8_t* __restrict__ dst, int ctus_x, int n_ctu, int w, int h, const SrcT* __restrict__ src, int src_pitch) {
+  constexpr int N = 4 / (int)sizeof(DstT);                        // samples per thread
+  constexpr int PER_ROW = 64 / N, PER_BLK = 64 * PER_ROW;         // threads per block row / per block
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int blk = (int)(t / PER_BLK), in = (int)(t - (long)blk * PER_BLK);
+  if (blk >= n_ctu) return;
+  const int r = in / PER_ROW, c0 = (in - r * PER_ROW) * N;
+  const int sy = min((blk / ctus_x) * 64 + r, h - 1), x0 = (blk % ctus_x) * 64 + c0;
+  uint32_t packed = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int v = (int)src[(long)sy * src_pitch + min(x0 + i, w - 1)];
+    packed |= (uint32_t)(v & (sizeof(DstT) == 1 ? 0xff : 0xffff)) << (8 * (int)sizeof(DstT) * i);
+  }
+  *(uint32_t*)(dst + t * 4) = packed;
+}
+
 // ---- 16-bit sample path (bit depth 9..12, bi-prediction origins of any depth) -----------------------------------------------
 // Same task / key / butterfly / merge machinery as me_search_kernel; differences (see tools/gen_me_tree.py, class Tree16):
 // v_sad_u16 leaves on u16 samples, three candidates per lane (x, x+2, x+4), exact 32-bit sums (candidates 0 and 1 as one 64-bit
@@ -684,11 +698,10 @@ __device__ __forceinline__ uint32_t me_keymin3_p(uint64_t s01, uint32_t s2, uint
 #ifdef ME_SEARCH_T_TIMELINE   // timing-only builds: per workgroup of me_search16_kernel -- start, [per pass: window staged, wave 0 dry, all dry], end (100 MHz wall clock), hardware id
 __device__ uint32_t g_timeline16[16384 * 12];
 #endif
-// CPITCH: the current picture's pitch in bytes as a compile-time constant (0 = any), as in me_search_kernel: no s_mul_i32 in front of the 512
-// current-block loads of a lane-iteration.  Instantiated for 2160p planes at search range 97..128 (BASELINE config 5: pitch 8192, PDW 161)
-template <int FEN, int PDW, int CPITCH = 0>
+// curs / cur_ctus_x: the CTU-blocked copies of the current pictures (u16 samples: 8 KiB per block), as in me_search_kernel
+template <int FEN, int PDW>
 __global__ void __launch_bounds__(kThreads16, 2)
-me_search16_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitch,
+me_search16_kernel(const RefSet curs, int cur_ctus_x, const RefSet refs, int ref_pitch,
                    const MeJob16* __restrict__ jobs, uint32_t lambda_q16, int sh, unsigned long long* __restrict__ g_best, int fair_prio) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   unsigned long long* best64 = (unsigned long long*)smem;              // [593] (+1 pad)
@@ -727,21 +740,14 @@ me_search16_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_
   // time.  Scalar loads complete out of order: ME16_CUR_WAIT (placed by the generator half a CU after the loads, before the next
   // batch is issued) waits for the whole batch and ties the loaded quads to the wait; the window dwords of the same batch are
   // named as inputs so that the compiler's own LDS wait lands in front of it, not behind the next batch.
-  const uintptr_t cur_addr = (uintptr_t)(cur_base + (long)job.ctu_y * cur_pitch + 2 * job.ctu_x);
+  const uintptr_t cur_addr = (uintptr_t)(cur_base + ((long)(job.ctu_y >> 6) * cur_ctus_x + (job.ctu_x >> 6)) * kBlkBytes16);
   const uint64_t curc = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)cur_addr) |
                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(cur_addr >> 32)) << 32;
-  const uint32_t cur_pitch_s = (uint32_t)__builtin_amdgcn_readfirstlane(cur_pitch);
-  if (tid < 64) me_prefetch_cur<2>(curc, cur_pitch_s);
+  if (tid < 64) me_prefetch_cur<2>(curc);
 #define ME16_CUR(row, q)                                                                                                           \
   ({                                                                                                                               \
     u32x4_t w_;                                                                                                                    \
-    if constexpr (CPITCH != 0) {                                                                                                   \
-      asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(w_) : "s"(curc), "n"((row) * CPITCH + 16 * (q)));                             \
-    } else {                                                                                                                       \
-      uint32_t o_;                                                                                                                 \
-      asm volatile("s_mul_i32 %1, %3, %4\n\ts_load_dwordx4 %0, %2, %1 offset:%5"                                                   \
-                   : "=s"(w_), "=&s"(o_) : "s"(curc), "s"(cur_pitch_s), "n"(row), "n"(16 * (q)));                                   \
-    }                                                                                                                              \
+    asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(w_) : "s"(curc), "n"((row) * 128 + 16 * (q)));                                  \
     w_;                                                                                                                            \
   })
 #define ME16_CUR_WAIT(w0, w1, w2, w3, d0, d1, d2, d3, d4, d5, d6, d7, d8, d9, d10, d11)                                               \

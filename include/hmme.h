@@ -285,8 +285,6 @@ int hmme_refine_pairs_device(hmme_ctx* ctx, const hmme_plane* const* curs, const
  *                         same stream as the one before it reuses the table that is still in place)
  *   HMME_FAIR_PRIO=<0|1>  search kernels: wave priorities that fall with a wave's progress off / on whatever the launch size (default: on
  *                         for whole-CTU workgroups, and for split / strip launches of up to four rounds of workgroups)
- *   HMME_CPITCH=0         search kernels: the general kernel also for pictures whose pitch has an instantiation of its own (2160p and 1080p
- *                         8-bit planes; 2160p 16-bit planes at search range 97..128): me_kernels.hpp CPITCH
  *   HMME_TAIL_PARTS=<n>   pieces per job of a launch's last, partial round of workgroups: default = the planner's choice
  *                         (DESIGN.md 5 "rounds of workgroups"); 1 = no tail plan
  *   HMME_STRIPS16=<n>     16-bit search kernel: that many equal window strips per job instead of the planner's number
