@@ -131,8 +131,10 @@ struct hmme_ctx {
   int wg_slots = 512;     // search workgroups resident at once: 2 per CU (VGPRs of the search kernels, LDS of the 16-bit one)
   int* d_first_strip = nullptr;
   int first_strip_cap = 0;
-  unsigned long long* d_best = nullptr;   // 16-bit path: [jobs][593] merge table
+  unsigned long long* d_best = nullptr;   // [jobs][593] merge table of the split / strip / segment launches
   size_t best_cap = 0;
+  bool best_clean = false;   // every entry of d_best is all ones: me_finalize16_kernel resets what it decodes, so only a table that is new, has
+                             // grown or was left behind by a failed launch needs the preset (merge_table)
   int16_t* d_pred = nullptr;
   int16_t* d_mv = nullptr;
   uint32_t* d_sad = nullptr;
@@ -267,15 +269,15 @@ int launch_search8(hmme_ctx* ctx, const RefSet& cur, int cur_ctus_x, const RefSe
   const int fair = fair_prio(ctx, n_jobs, true);
   if (fen)
     hipLaunchKernelGGL((hmme::me_search_kernel<1, 0>), dim3(n_jobs), dim3(hmme::kThreads), 0, stream, cur, cur_ctus_x, ref,
-                       ref_pitch, (const void*)d_jobs, ctx->lambda_q16, d_mv, d_sad, (unsigned long long*)nullptr, fair);
+                       ref_pitch, (const void*)d_jobs, ctx->lambda_q16, d_mv, d_sad, (unsigned long long*)nullptr, fair, 0);
   else
     hipLaunchKernelGGL((hmme::me_search_kernel<0, 0>), dim3(n_jobs), dim3(hmme::kThreads), 0, stream, cur, cur_ctus_x, ref,
-                       ref_pitch, (const void*)d_jobs, ctx->lambda_q16, d_mv, d_sad, (unsigned long long*)nullptr, fair);
+                       ref_pitch, (const void*)d_jobs, ctx->lambda_q16, d_mv, d_sad, (unsigned long long*)nullptr, fair, 0);
   HIP_TRY(ctx, hipGetLastError());
   return HMME_OK;
 }
 
-int finalize_best(hmme_ctx* ctx, const unsigned long long* d_best, const MeJob16* d_jobs, const int* d_first_strip, int n_jobs, int16_t* d_mv,
+int finalize_best(hmme_ctx* ctx, unsigned long long* d_best, const MeJob16* d_jobs, const int* d_first_strip, int n_jobs, int16_t* d_mv,
                   uint32_t* d_sad, hipStream_t stream);
 
 // 8-bit split mode: n_jobs * n_split workgroups, each runs a slice of its CTU's tasks and merges through ctx->d_best
@@ -285,9 +287,11 @@ int merge_table(hmme_ctx* ctx, int n_jobs, unsigned long long* preset, hipStream
   size_t cap = ctx->best_cap;
   int rc = ensure(ctx, &ctx->d_best, &cap, sizeof(unsigned long long) * HMME_NUM_CTU_PARTS * (size_t)n_jobs,
                   n_jobs > 64 ? sizeof(unsigned long long) * HMME_NUM_CTU_PARTS * (size_t)n_jobs * 2 : 0);
+  if (cap != ctx->best_cap) ctx->best_clean = false;
   ctx->best_cap = cap;
   if (rc) return rc;
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_best, 0xFF, sizeof(unsigned long long) * HMME_NUM_CTU_PARTS * (size_t)n_jobs, stream));
+  if (!ctx->best_clean) HIP_TRY(ctx, hipMemsetAsync(ctx->d_best, 0xFF, ctx->best_cap, stream));
+  ctx->best_clean = false;   // until the launch's finalize_best has been enqueued (it sets every entry it decodes back to all ones)
   *table = ctx->d_best;
   return HMME_OK;
 }
@@ -302,12 +306,28 @@ int launch_search8_split(hmme_ctx* ctx, const RefSet& cur, int cur_ctus_x, const
   const int fair = fair_prio(ctx, n_jobs * n_split, false);
   if (fen)
     hipLaunchKernelGGL((hmme::me_search_kernel<1, 1>), dim3(n_jobs * n_split), dim3(hmme::kThreads), 0, stream, cur, cur_ctus_x,
-                       ref, ref_pitch, (const void*)d_jobs, ctx->lambda_q16, (int16_t*)nullptr, (uint32_t*)nullptr, best, fair);
+                       ref, ref_pitch, (const void*)d_jobs, ctx->lambda_q16, (int16_t*)nullptr, (uint32_t*)nullptr, best, fair, 0);
   else
     hipLaunchKernelGGL((hmme::me_search_kernel<0, 1>), dim3(n_jobs * n_split), dim3(hmme::kThreads), 0, stream, cur, cur_ctus_x,
-                       ref, ref_pitch, (const void*)d_jobs, ctx->lambda_q16, (int16_t*)nullptr, (uint32_t*)nullptr, best, fair);
+                       ref, ref_pitch, (const void*)d_jobs, ctx->lambda_q16, (int16_t*)nullptr, (uint32_t*)nullptr, best, fair, 0);
   HIP_TRY(ctx, hipGetLastError());
   return finalize ? finalize_best(ctx, best, d_jobs, d_first_strip, n_jobs, d_mv, d_sad, stream) : HMME_OK;
+}
+
+// 8-bit segment mode: the tasks of n_jobs jobs in n_wg equal segments (table: me_seg_table_*), merged through `best` (preset by the caller)
+int launch_search8_segments(hmme_ctx* ctx, const RefSet& cur, int cur_ctus_x, const RefSet& ref, int ref_pitch, const void* d_table,
+                            const int* d_first_strip, int n_jobs, int n_wg, int fen, int16_t* d_mv, uint32_t* d_sad, hipStream_t stream,
+                            unsigned long long* best) {
+  if (n_jobs <= 0 || n_wg <= 0) return HMME_OK;
+  const int fair = fair_prio(ctx, n_wg, false);
+  if (fen)
+    hipLaunchKernelGGL((hmme::me_search_kernel<1, 2>), dim3(n_wg), dim3(hmme::kThreads), 0, stream, cur, cur_ctus_x, ref, ref_pitch, d_table,
+                       ctx->lambda_q16, (int16_t*)nullptr, (uint32_t*)nullptr, best, fair, n_jobs);
+  else
+    hipLaunchKernelGGL((hmme::me_search_kernel<0, 2>), dim3(n_wg), dim3(hmme::kThreads), 0, stream, cur, cur_ctus_x, ref, ref_pitch, d_table,
+                       ctx->lambda_q16, (int16_t*)nullptr, (uint32_t*)nullptr, best, fair, n_jobs);
+  HIP_TRY(ctx, hipGetLastError());
+  return finalize_best(ctx, best, hmme::me_seg_table_jobs(d_table, n_wg), d_first_strip, n_jobs, d_mv, d_sad, stream);
 }
 
 // ---- 16-bit path -------------------------------------------------------------------------------------
@@ -366,12 +386,13 @@ int launch_search16(hmme_ctx* ctx, const RefSet& cur, int cur_ctus_x, const RefS
   return finalize ? finalize_best(ctx, best, d_jobs, d_first_strip, n_jobs, d_mv, d_sad, stream) : HMME_OK;
 }
 
-int finalize_best(hmme_ctx* ctx, const unsigned long long* d_best, const MeJob16* d_jobs, const int* d_first_strip, int n_jobs, int16_t* d_mv,
+int finalize_best(hmme_ctx* ctx, unsigned long long* d_best, const MeJob16* d_jobs, const int* d_first_strip, int n_jobs, int16_t* d_mv,
                   uint32_t* d_sad, hipStream_t stream) {
   const long total = (long)n_jobs * HMME_NUM_CTU_PARTS;
   hipLaunchKernelGGL(hmme::me_finalize16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d_best, d_jobs,
                      d_first_strip, n_jobs, ctx->lambda_q16, d_mv, d_sad);
   HIP_TRY(ctx, hipGetLastError());
+  if (d_best == ctx->d_best) ctx->best_clean = true;   // the launches of a context are one chain (scratch_acquire): the next one finds the table reset
   return HMME_OK;
 }
 
@@ -1076,8 +1097,11 @@ int hmme_plane_set_device_u8(hmme_plane* pl, const void* d_src, int src_pitch, v
 // and a launch runs in rounds of that many: 2 040 CTU searches are 3.98 rounds of 512, but 570 (1920 x 1200) are 1.11 -- the second
 // round would keep 58 slots busy and cost as much as the first (measured before this plan existed: 2 340 GSAD/s against 3 339 at
 // 2160p).  So the jobs beyond the last full round ("tail", from job tail_first on) are dealt in finer pieces:
-//   8-bit:  jobs [0, tail_first) run whole (me_search_kernel<FEN, 0>), the tail runs through the split kernel, tail_parts task ranges
-//           per job merged through the 64-bit atomicMin table (a second launch on the same stream);
+//   8-bit:  jobs [0, tail_first) run whole (me_search_kernel<FEN, 0>); the tail's tasks -- all its jobs' lane-iterations as ONE list --
+//           are cut into tail_wgs equal segments, one per workgroup of a second launch (me_search_kernel<FEN, 2>; a segment may end one
+//           job and begin the next), merged through the 64-bit atomicMin table.  Until round 6 every tail job was cut into the same
+//           number of pieces: 240 jobs (720p) in 2 pieces each filled 480 of 512 slots with 34 or 33 lane-iterations -- 9 for the
+//           slowest wave where 7.85 would do -- and the clipped windows of edge CTUs made shorter pieces still;
 //   16-bit: one launch; jobs [0, tail_first) are cut into n_strips strips, tail jobs into tail_parts (>= n_strips).
 // A launch of fewer jobs than slots is all tail (the small-picture split mode of round 1).  8-bit windows beyond 129 x 129 (four tiles
 // per job through the split kernel) are not re-planned.
@@ -1086,10 +1110,11 @@ struct FramePlan {
   int n_strips = 1;        // 16-bit: strips of a head job; 8-bit: 4 when tiled, else 1
   int pdw = 0, strip_rows = 0;
   int tail_first = 0;      // == jobs: no tail
-  int tail_parts = 1;
+  int tail_parts = 1;      // 16-bit: strips of a tail job
+  int tail_wgs = 0;        // 8-bit: workgroups (= segments) of the tail's launch
   bool tile8 = false;
   int n_wg16 = 0;          // 16-bit: workgroups of the launch
-  size_t tail_jobs_off = 0;   // 8-bit: byte offset of the tail's MeJob16[] inside ctx->d_jobs
+  size_t tail_jobs_off = 0;   // 8-bit: byte offset of the tail's segment table (me_seg_table_*) inside ctx->d_jobs
 };
 
 // pieces per tail job that finish `tail` jobs soonest: rounds of `slots` workgroups, each as long as its piece of a whole job
@@ -1144,14 +1169,29 @@ static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_para
   } else if (pl->tile8) {
     pl->n_strips = 4;
   } else if (tail && tail_knob != 1) {
-    // a piece of a job costs its share of the job's iterations plus what every workgroup pays: window load, flush, merge
-    const int nt = hmme::me_num_tasks(w, w);
-    const int k_max = std::max(1, (nt + 3) / 4);   // never below 4 tasks (one per wave) per workgroup
-    // in lane-iterations of the slowest wave (4 waves share a piece's tasks); a quarter iteration per workgroup for window load, flush
-    // and merge fits the sweeps of profiles/archive/r02Q_tail_sweeps.txt (1440p: 5 pieces beat 1 and 3; 1200p: 17 beat 8; 720p: 2..6 alike)
-    auto part_cost = [&](int k) { return (double)(((nt + k - 1) / k + 3) / 4) + 0.25; };
-    const int k = tail_knob > 1 ? std::min(tail_knob, k_max) : plan_tail(tail, slots, 1, k_max, part_cost);
-    if (k > 1) { pl->tail_first = jobs - tail; pl->tail_parts = k; }
+    // the tail's units in `rounds` rounds of `slots` equal segments.  A round costs the lane-iterations of its slowest wave plus what
+    // every workgroup pays per job it touches -- window load, flush, merge: a quarter iteration fits the sweeps of
+    // profiles/archive/r02Q_tail_sweeps.txt -- and a segment of u units touches 1 + (u - 1) / units jobs on average.  Full windows are
+    // assumed (the device counts the clipped ones' units itself: me_prep_segments_kernel).  Never below one unit per workgroup: tiny
+    // windows get fewer workgroups than slots.
+    // Segments are whole units of kSegUnit = 4 tasks (one per wave), so a segment of u units costs u lane-iterations.  Against that stands
+    // the tail run WHOLE in the head's launch -- ceil(nt / 4) lane-iterations per wave for one more round of workgroups, which flow in
+    // behind the head's without a launch boundary, with the large tasks of whole jobs and without merge table, preset and decode: the
+    // segment launch is taken only where the model says it wins by 8 % plus half a lane-iteration (1080p's 510 jobs and the 504 left over
+    // at 2160p stay whole: measured 10 % and 4 % slower as segments, profiles/r06d_tail_segments.txt).
+    const int nt = hmme::me_num_tasks(w, w), units = (nt + hmme::kSegUnit - 1) / hmme::kSegUnit;
+    const long total = (long)tail * units;
+    int best_wgs = 0;
+    double best = (double)units + 0.25;   // the tail as whole jobs
+    for (int rounds = 1; rounds <= 4; ++rounds) {
+      const long wgs = std::max<long>(1, std::min<long>((long)rounds * slots, total));
+      const double per_wg = (double)total / wgs;
+      const double t = 1.08 * rounds * (std::ceil(per_wg) + 0.25 * (1.0 + (per_wg - 1.0) / units)) + 0.5;
+      if (t < best * 0.999) { best = t; best_wgs = (int)wgs; }
+      if (wgs < (long)rounds * slots) break;
+    }
+    if (tail_knob > 1) best_wgs = (int)std::max<long>(1, std::min<long>((long)tail * tail_knob, total));   // A/B: tail_knob workgroups per tail job
+    if (best_wgs > 0 && tail <= hmme::kSegPrepThreads) { pl->tail_first = jobs - tail; pl->tail_wgs = best_wgs; }
   }
   const int head = pl->tail_first, n_tail = jobs - head;
   size_t need;
@@ -1159,7 +1199,7 @@ static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_para
   else if (pl->tile8) need = sizeof(MeJob16) * (size_t)jobs * 4;
   else {
     pl->tail_jobs_off = (sizeof(MeJob) * (size_t)head + 255) & ~(size_t)255;
-    need = pl->tail_jobs_off + sizeof(MeJob16) * (size_t)n_tail * pl->tail_parts;
+    need = pl->tail_jobs_off + hmme::me_seg_table_bytes(pl->tail_wgs, n_tail);
   }
   size_t cap = ctx->jobs_bytes;
   const size_t per_ref = n_refs > 0 ? (need + n_refs - 1) / n_refs : need;   // what kMaxRefs pairs of this picture size would ask for
@@ -1196,8 +1236,8 @@ static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_para
       hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, grid(head), block, 0, s, (MeJob*)ctx->d_jobs, (const int16_t*)d_pred_q, first, count,
                          n_refs, cur->width, cur->height, fp->search_range, 0, head, 1, (uint32_t*)nullptr);
     if (n_tail)
-      hipLaunchKernelGGL(hmme::me_prep_jobs_split_kernel, grid(n_tail), block, 0, s, (MeJob16*)((uint8_t*)ctx->d_jobs + pl->tail_jobs_off), ctx->d_first_strip,
-                         (const int16_t*)d_pred_q, first, count, n_refs, cur->width, cur->height, fp->search_range, pl->tail_parts, head, n_tail);
+      hipLaunchKernelGGL(hmme::me_prep_segments_kernel, dim3(1), dim3(hmme::kSegPrepThreads), 0, s, (void*)((uint8_t*)ctx->d_jobs + pl->tail_jobs_off), ctx->d_first_strip,
+                         (const int16_t*)d_pred_q, first, count, n_refs, cur->width, cur->height, fp->search_range, pl->tail_wgs, head, n_tail);
   }
   HIP_TRY(ctx, hipGetLastError());
   ctx->jobs_tag = tag;
@@ -1218,8 +1258,8 @@ static int run_search(hmme_ctx* ctx, const RefSet& curs, int cur_ctus_x, const R
   int rc = n_tail ? merge_table(ctx, n_tail, nullptr, s, &best) : HMME_OK;   // the tail's merge table is preset before the head runs, not between the two
   if (rc == HMME_OK) rc = launch_search8(ctx, curs, cur_ctus_x, refs, ref_pitch, (const MeJob*)ctx->d_jobs, head, fp->fen, d_mv, d_sad, s);
   if (rc || !n_tail) return rc;
-  return launch_search8_split(ctx, curs, cur_ctus_x, refs, ref_pitch, (const MeJob16*)((const uint8_t*)ctx->d_jobs + pl.tail_jobs_off), ctx->d_first_strip,
-                              n_tail, pl.tail_parts, fp->fen, d_mv + (size_t)head * 2 * HMME_NUM_CTU_PARTS, d_sad + (size_t)head * HMME_NUM_CTU_PARTS, s, best);
+  return launch_search8_segments(ctx, curs, cur_ctus_x, refs, ref_pitch, (const uint8_t*)ctx->d_jobs + pl.tail_jobs_off, ctx->d_first_strip, n_tail, pl.tail_wgs,
+                                 fp->fen, d_mv + (size_t)head * 2 * HMME_NUM_CTU_PARTS, d_sad + (size_t)head * HMME_NUM_CTU_PARTS, s, best);
 }
 
 // n_pairs (current, reference) picture pairs of one size in one launch: validates, orders the streams, fills the two plane sets

@@ -309,6 +309,19 @@ __device__ __forceinline__ void me_stage_window(uint32_t* win, const uint32_t* _
   }
 }
 
+// Segment table of a SPLIT = 2 launch of me_search_kernel (written by me_prep_segments_kernel), one allocation:
+//   int4    segs[W]        per workgroup: (job its segment starts in, first unit, end unit) in the launch's list of UNITS; .w unused
+//   MeJob16 jobs[n]        the jobs (y0 / y1 unused; `job` = index into the result arrays); me_finalize16_kernel decodes against them
+//   int     prefix[n + 1]  units of the jobs before job j: job j owns the list's units [prefix[j], prefix[j + 1])
+// A unit is kSegUnit = 4 consecutive tasks (lane-iterations) of one job -- one per wave of the workgroup; a job's last unit may be short.
+// Segments are cut at unit boundaries: where a segment leaves one job and enters the next the four waves meet at a barrier, and a piece
+// of a job that is not a multiple of four tasks would leave waves idle in its last round on BOTH sides of every such boundary.
+constexpr int kSegUnit = 4;
+__host__ __device__ inline size_t me_seg_table_bytes(int n_wg, int n_jobs) { return sizeof(int4) * (size_t)n_wg + sizeof(MeJob16) * (size_t)n_jobs + sizeof(int) * ((size_t)n_jobs + 1); }
+__host__ __device__ inline const int4* me_seg_table_segs(const void* t) { return (const int4*)t; }
+__host__ __device__ inline const MeJob16* me_seg_table_jobs(const void* t, int n_wg) { return (const MeJob16*)((const int4*)t + n_wg); }
+__host__ __device__ inline const int* me_seg_table_prefix(const void* t, int n_wg, int n_jobs) { return (const int*)(me_seg_table_jobs(t, n_wg) + n_jobs); }
+
 // ---- the search kernel --------------------------------------------------------------------------
 // windows wider or taller than 129 candidates (8-bit planes, search range 65..128) are cut into up to 2 x 2 tiles of at most
 // 129 x 129: MeJob16::job carries the tile's (x, y) index in bits 30 and 29 above the output job index
@@ -316,12 +329,18 @@ constexpr int kTileStep = 129, kTileJobMask = 0x1fffffff;
 // SPLIT = 0: one workgroup searches the whole window of jobs[blockIdx.x] (MeJob) and writes its 593 results.
 // SPLIT = 1: jobs are MeJob16; the workgroup runs tasks [y0, y1) only and merges into g_best with 64-bit atomicMin
 //            (decoded afterwards by me_finalize16_kernel) -- used where one CTU must fill many CUs.
+// SPLIT = 2: the tasks of ALL jobs of the launch form one list (job after job), cut into gridDim.x equal SEGMENTS (me_prep_segments_kernel);
+//            the workgroup runs segment blockIdx.x, which may end one job and begin the next (window staged again, table merged per job).
+//            A launch that does not fill whole rounds of the chip's workgroup slots -- a small picture, the jobs beyond the last full
+//            round of a larger one -- is dealt this way: every workgroup gets the same number of lane-iterations, whatever the number
+//            of jobs and however the picture's edge clips their windows.  jobs_v: MeSegTable layout (below).
+// n_seg_jobs: SPLIT = 2 only, the number of jobs the segment table covers
 // curs: the CTU-blocked copies of the current pictures (above me_prefetch_cur), cur_ctus_x: CTUs per picture row (blocks per block row).
 template <int FEN, int SPLIT>
 __global__ void __launch_bounds__(kThreads, 2)
 me_search_kernel(const RefSet curs, int cur_ctus_x, const RefSet refs, int ref_pitch,
                  const void* __restrict__ jobs_v, uint32_t lambda_q16, int16_t* __restrict__ out_mv,
-                 uint32_t* __restrict__ out_sad, unsigned long long* __restrict__ g_best, int fair_prio) {
+                 uint32_t* __restrict__ out_sad, unsigned long long* __restrict__ g_best, int fair_prio, int n_seg_jobs) {
   __shared__ uint32_t win[kWinRowsMax * kPDW];
   __shared__ unsigned long long best64[kParts];
   __shared__ int task_ctr;
@@ -331,13 +350,15 @@ me_search_kernel(const RefSet curs, int cur_ctus_x, const RefSet refs, int ref_p
 #ifdef ME_SEARCH_T_TIMELINE   // timing-only build (results are overwritten): when each workgroup starts, has its window staged, runs dry, ends (100 MHz wall clock)
   const unsigned long long tl_start = wall_clock64();
 #endif
-#if ME_FAIR_PRIO
-  if (fair_prio) __builtin_amdgcn_s_setprio(3);   // a new workgroup comes first: its window loads go out at once, its first tasks run ahead of the older workgroup's last
-#endif
   MeJob job;
   int t_first = 0, t_end = 0x7fffffff, out_job = blockIdx.x;
   unsigned long long tile_off = 0;   // SPLIT, tiled windows: (y, x) of this tile's first candidate in the CTU's whole window
-  if constexpr (SPLIT) {
+  int seg_j = 0, seg_g = 0, seg_end = 0;   // SPLIT = 2: the job the segment is in, the next task of the launch's list, the segment's end
+  if constexpr (SPLIT == 2) {
+    const int4 sg = me_seg_table_segs(jobs_v)[blockIdx.x];
+    seg_j = sg.x; seg_g = sg.y; seg_end = sg.z;
+    if (seg_g >= seg_end) return;      // fewer tasks than workgroups (tiny windows): nothing for this one
+  } else if constexpr (SPLIT == 1) {
     const MeJob16 jb = ((const MeJob16*)jobs_v)[blockIdx.x];
     job = jb.j; t_first = jb.y0; t_end = jb.y1; out_job = jb.job & kTileJobMask;
     tile_off = (unsigned long long)(((jb.job >> 29) & 1) * kTileStep) << 16 | (unsigned long long)(((jb.job >> 30) & 1) * kTileStep);
@@ -345,6 +366,19 @@ me_search_kernel(const RefSet curs, int cur_ctus_x, const RefSet refs, int ref_p
     job = ((const MeJob*)jobs_v)[blockIdx.x];
     out_job = me_xcd_unit(blockIdx.x, gridDim.x);   // the job table of a whole-job launch is in XCD order (me_prep_jobs_kernel)
   }
+#pragma unroll 1
+  for (bool first_job = true;; first_job = false) {   // one pass, except SPLIT = 2: one pass per job the segment reaches into
+  if constexpr (SPLIT == 2) {
+    const int* prefix = me_seg_table_prefix(jobs_v, gridDim.x, n_seg_jobs);
+    const int p0 = prefix[seg_j], p1 = prefix[seg_j + 1];
+    job = me_seg_table_jobs(jobs_v, gridDim.x)[seg_j].j;
+    t_first = (seg_g - p0) * kSegUnit; t_end = (min(seg_end, p1) - p0) * kSegUnit; out_job = seg_j;   // the job's last unit may be short: n_tasks clips
+    seg_g = p1; ++seg_j;
+    if (!first_job) __syncthreads();   // every thread has merged the previous job's table; window and table are free again
+  }
+#if ME_FAIR_PRIO
+  if (fair_prio) __builtin_amdgcn_s_setprio(3);   // a new workgroup comes first: its window loads go out at once, its first tasks run ahead of the older workgroup's last
+#endif
   const uint8_t* __restrict__ ref_base = refs.base[job.ctu_x & 63];
   const uint8_t* __restrict__ cur_base = curs.base[job.ctu_x & 63];
   job.ctu_x &= ~63;
@@ -407,11 +441,32 @@ me_search_kernel(const RefSet curs, int cur_ctus_x, const RefSet refs, int ref_p
   int prio_state = prio_quarter << 2;
 #endif
 
+  static_assert(SPLIT != 2 || kIterPerTaskSplit == 1, "segment mode counts tasks in lane-iterations");
+  int grab_next = 0, grab_end = 0;   // SPLIT = 2: the tasks this wave has drawn and not yet run
   while (true) {
     int t = 0;
-    if (lane == 0) t = atomicAdd(&task_ctr, 1);
-    t = __builtin_amdgcn_readfirstlane(t);
-    if (t >= n_tasks) break;
+    if constexpr (SPLIT == 2) {
+      // a wave draws a quarter of what is left, at most 4 tasks, and runs them as ONE task of that many lane-iterations where they lie in
+      // one part of the window (one flush of the running minima for up to four lane-iterations instead of one each); guided
+      // self-scheduling over the four waves ends them level: 12 tasks go 3 + 3 + 2 + 1, + 1 + 1 + 1 = three each
+      if (grab_next >= grab_end) {
+        int want = 0;
+        if (lane == 0) {
+          const int left = n_tasks - *(volatile int*)&task_ctr;
+          want = min(4, max(1, (left + 3) >> 2));
+          t = atomicAdd(&task_ctr, want);
+        }
+        t = __builtin_amdgcn_readfirstlane(t);
+        want = __builtin_amdgcn_readfirstlane(want);
+        if (t >= n_tasks) break;
+        grab_next = t; grab_end = min(t + want, n_tasks);
+      }
+      t = grab_next;
+    } else {
+      if (lane == 0) t = atomicAdd(&task_ctr, 1);
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t >= n_tasks) break;
+    }
 #if ME_FAIR_PRIO
     if (prio_state < 4 && (prio_state & 3) < 3) {   // the level's share is used up: one step down
       prio_state += (prio_quarter << 2) + 1;
@@ -441,7 +496,11 @@ me_search_kernel(const RefSet curs, int cur_ctus_x, const RefSet refs, int ref_p
           }
         } else {
           nt = (iters + kIt - 1) / kIt;
-          if (rem < nt) { x0 = xq * 4; k = kk; it0 = rem * kIt; n_it = min(kIt, iters - it0); break; }
+          if (rem < nt) {
+            x0 = xq * 4; k = kk; it0 = rem * kIt; n_it = min(kIt, iters - it0);
+            if constexpr (SPLIT == 2) { n_it = min(grab_end - grab_next, iters - it0); grab_next += n_it; }   // kIt = 1: tasks are lane-iterations
+            break;
+          }
         }
         rem -= nt;
         xq += 1 << kk;
@@ -531,6 +590,9 @@ me_search_kernel(const RefSet curs, int cur_ctus_x, const RefSet refs, int ref_p
       const unsigned long long v = best64[s];
       if (v != ~0ull) atomicMin(&g_best[(long)out_job * kParts + s], v + tile_off);
     }
+    if constexpr (SPLIT == 2) {
+      if (seg_g < seg_end) continue;   // the segment goes on in the next job
+    }
     return;
   }
   for (int s = tid; s < kParts; s += kThreads) {
@@ -559,6 +621,8 @@ me_search_kernel(const RefSet curs, int cur_ctus_x, const RefSet refs, int ref_p
     o[8 + wv] = (uint32_t)(tl_dry - tl_start);
   }
 #endif
+  break;   // SPLIT = 0: the one job is done (SPLIT = 1 returned above, SPLIT = 2 went on or returned)
+  }
 }
 
 // ---- frame helpers ---------------------------------------------------------------------------------
@@ -864,14 +928,16 @@ me_search16_kernel(const RefSet curs, int cur_ctus_x, const RefSet refs, int ref
 #undef ME16_STAMP
 }
 
-// strips of one CTU have merged into g_best: decode (cost, y, x) -> TComMv + pure SAD
-__global__ void me_finalize16_kernel(const unsigned long long* __restrict__ g_best, const MeJob16* __restrict__ jobs,
+// strips of one CTU have merged into g_best: decode (cost, y, x) -> TComMv + pure SAD.  Every entry read is set back to all ones: the
+// table is left as the next launch needs it (hmme.hip merge_table: no preset launch in front of every split / strip / segment launch)
+__global__ void me_finalize16_kernel(unsigned long long* __restrict__ g_best, const MeJob16* __restrict__ jobs,
                                      const int* __restrict__ first_strip_of_job, int n_jobs, uint32_t lambda_q16,
                                      int16_t* __restrict__ out_mv, uint32_t* __restrict__ out_sad) {
   const long o = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= (long)n_jobs * kParts) return;
   const MeJob job = jobs[first_strip_of_job[o / kParts]].j;
   const unsigned long long v = g_best[o];
+  g_best[o] = ~0ull;
   const int mvx = job.lt_x + (int)(v & 0xffff), mvy = job.lt_y + (int)((v >> 16) & 0xffff);
   out_mv[2 * o] = (int16_t)mvx;
   out_mv[2 * o + 1] = (int16_t)mvy;
@@ -1000,6 +1066,61 @@ __global__ void me_prep_jobs_split_kernel(MeJob16* jobs, int* first_strip_of_job
     js.y1 = (int16_t)((long)nt * (s + 1) / n_split);
     js.job = li;
     jobs[li * n_split + s] = js;
+  }
+}
+
+// 8-bit segment mode (me_search_kernel SPLIT = 2): the jobs' units (kSegUnit tasks) as one list, cut into n_wg equal segments.  ONE workgroup of
+// kSegPrepThreads threads writes the whole table (n_jobs <= kSegPrepThreads: a tail is shorter than one round of the chip's workgroup slots):
+// a job and its unit count per thread, an inclusive scan in LDS, then the segments -- segment s owns units [N s / n_wg, N (s + 1) / n_wg)
+// and starts in the job whose range holds its first unit (binary search in the prefix sums).
+constexpr int kSegPrepThreads = 512;
+__global__ void __launch_bounds__(kSegPrepThreads)
+me_prep_segments_kernel(void* table, int* first_strip_of_job, const int16_t* __restrict__ pred_q, int ctu_first, int ctu_count, int n_refs,
+                        int pic_w, int pic_h, int sr, int n_wg, int job0, int n_jobs) {
+  __shared__ int scan[kSegPrepThreads + 1];
+  const int li = threadIdx.x;
+  int nt = 0;
+  if (li < n_jobs) {
+    const int i = job0 + li;              // which (CTU, reference); jobs[], first_strip_of_job[] and MeJob16::job count from job0
+    const int r = i / ctu_count;
+    const int ctus_x = (pic_w + 63) >> 6, n_ctu = ctus_x * ((pic_h + 63) >> 6);
+    const int ctu = ctu_first + (i - r * ctu_count);
+    const int cu_x = (ctu % ctus_x) * 64, cu_y = (ctu / ctus_x) * 64;
+    const long pq = 2 * ((long)r * n_ctu + ctu);
+    const int px = pred_q ? pred_q[pq] : 0, py = pred_q ? pred_q[pq + 1] : 0;
+    int ltx, lty, rbx, rby;
+    set_search_range(px, py, sr, cu_x, cu_y, pic_w, pic_h, ltx, lty, rbx, rby);
+    MeJob16 js;
+    js.j.ctu_x = (int16_t)(cu_x | r); js.j.ctu_y = (int16_t)cu_y;
+    js.j.lt_x = (int16_t)ltx; js.j.lt_y = (int16_t)lty; js.j.rb_x = (int16_t)rbx; js.j.rb_y = (int16_t)rby;
+    js.j.pred_x = (int16_t)px; js.j.pred_y = (int16_t)py;
+    nt = me_num_tasks(rbx - ltx + 1, rby - lty + 1);
+    js.y0 = 0; js.y1 = (int16_t)nt; js.job = li;
+    nt = (nt + kSegUnit - 1) / kSegUnit;   // from here on: units
+    ((MeJob16*)me_seg_table_jobs(table, n_wg))[li] = js;
+    first_strip_of_job[li] = li;          // me_finalize16_kernel: job li decodes against jobs[li]
+  }
+  scan[li + 1] = nt;
+  if (li == 0) scan[0] = 0;
+  __syncthreads();
+  for (int d = 1; d < kSegPrepThreads; d <<= 1) {   // inclusive scan over scan[1 ..]
+    const int v = li + 1 > d ? scan[li + 1 - d] : 0;
+    __syncthreads();
+    scan[li + 1] += v;
+    __syncthreads();
+  }
+  int* prefix = (int*)me_seg_table_prefix(table, n_wg, n_jobs);
+  if (li <= n_jobs) prefix[li] = scan[li];
+  const long total = scan[n_jobs];
+  int4* segs = (int4*)me_seg_table_segs(table);
+  for (int s = li; s < n_wg; s += kSegPrepThreads) {
+    const int g0 = (int)(total * s / n_wg), g1 = (int)(total * (s + 1) / n_wg);
+    int lo = 0, hi = n_jobs;                         // the job j with scan[j] <= g0 < scan[j + 1] (every job has at least one task)
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (scan[mid] <= g0) lo = mid; else hi = mid;
+    }
+    segs[s] = make_int4(lo, g0, g1, 0);
   }
 }
 
