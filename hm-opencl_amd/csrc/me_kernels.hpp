@@ -1190,12 +1190,23 @@ constexpr int frac_threads(int bps) { return 256; }
 #else
 #define ME_FRAC_RIDE_LISTED 0
 #endif
+// ME_FRAC_TREE=1: the implicit items of a wave whose positions share one key add their sums over groups of positions, one add per (slot,
+// group), instead of every lane adding to every slot of its position (me_frac_tree_add).  Built and measured in round 6, left OFF:
+// on content whose slots share their motion it took the kernel's LDS bank-conflict cycles from 0.63 to 0.19 of its LDS cycles and its LDS
+// activity from 0.19 to 0.10 of the CU cycles -- and its time from 0.133 to 0.136 ms per 2160p pair, because those conflicts never were what
+// the launch waited for: the exchanges, the packing and the designated lanes' slot arithmetic are 12 % more VALU instructions in a kernel
+// whose time follows its instruction count.  10-bit Hadamard gained 3.6 % (nine 32-bit adds per slot saved instead of three 64-bit ones),
+// but the u16 SAD variants went past 256 VGPRs with it (55..96 spilled dwords).  profiles/r06h_frac_tree_ab.txt
+#ifndef ME_FRAC_TREE
+#define ME_FRAC_TREE 0
+#endif
 #ifndef ME_FRAC_GLDS   // measured: no faster than plain loads on any content (profiles/r05j_frac_glds_ab.txt) -- the items do not wait for their rows
 #define ME_FRAC_GLDS 0
 #endif
 constexpr bool frac_glds(int bps) { return ME_FRAC_GLDS && bps == 1; }
 constexpr int frac_pf_dw(int bps) { return frac_glds(bps) ? 12 * 4 * 256 : 0; }
-constexpr size_t frac_lds_bytes(int bps) { return (size_t)(frac_acc_dw(bps) + 600 + 160 + (64 * 18 + 256 * 6) / 2 + 1024 * bps + (64 * 18 + 256 * 6) / 2 + frac_pf_dw(bps)) * 4 + ME_FRAC_T_LDS_PAD; }
+constexpr size_t frac_org_bytes(int bps) { return bps == 2 ? 16 + 4 * 256 * 16 : 0; }   // u16 planes: the lanes' current samples as floats (FracOrgLds) + alignment
+constexpr size_t frac_lds_bytes(int bps) { return (size_t)(frac_acc_dw(bps) + 600 + 160 + (64 * 18 + 256 * 6) / 2 + 1024 * bps + (64 * 18 + 256 * 6) / 2 + frac_pf_dw(bps)) * 4 + frac_org_bytes(bps) + ME_FRAC_T_LDS_PAD; }
 
 __device__ __forceinline__ uint32_t me_mv_cost_q(uint32_t lambda_q16, int vx_q, int vy_q, int pred_x, int pred_y) {
   return (lambda_q16 * (me_component_bits(vx_q - pred_x) + me_component_bits(vy_q - pred_y))) >> 16;
@@ -1415,6 +1426,26 @@ __device__ __forceinline__ uint32_t me_frac_had_pk(const v2f (&P)[4][2], float s
 // ws = w0 * 2^-shift, rs = round * 2^-shift: fma(ws, p, rs) IS (w0 * p + round) / 2^shift exactly (|w0 * p + round| < 2^24), v_floor_f32
 // the shift; org_sub = what to take off a staged current sample: its staging bias + offset.  WP = 0: none of this is compiled in.
 struct FracWp { float ws, rs, org_sub; };
+// The item's sixteen current samples (+ kRoundMagic) as the evaluation reads them, row by row.  8-bit planes: sixteen registers.  u16 planes:
+// a block of LDS the lane wrote itself (me_frac_compute) -- the u16 kernels sit at the 256-VGPR limit, these sixteen values are live from
+// the first filtered sample to the last point, and with them in registers the three u16 variants spilled 5..9 dwords per lane to scratch;
+// four ds_read_b128 per point cost nothing beside the ~300 VALU instructions of a point.
+struct FracOrgRegs {
+  const float (&m)[16];
+  __device__ __forceinline__ float4 row(int r) const { return make_float4(m[4 * r], m[4 * r + 1], m[4 * r + 2], m[4 * r + 3]); }
+};
+struct FracOrgLds {
+  const float4* p;   // row r of this lane at p[r * 256]
+  // The pointer is made opaque per read: a plain load from `p` is read ONCE by the compiler and kept -- sixteen registers live across the
+  // evaluation, which is what this block exists to avoid (that build spilled 11..55 dwords) -- while a load the compiler cannot prove equal
+  // to an earlier one is issued where the point needs it and scheduled like any other LDS read.  (ds_read_b128 + s_waitcnt in one asm
+  // statement was tried first: 36 full LDS round trips per item with nothing issued behind them, 9 % slower than the spilling build.)
+  __device__ __forceinline__ float4 row(int r) const {
+    const float4* q = p;
+    asm volatile("" : "+v"(q));
+    return q[r * 256];
+  }
+};
 // a whole-picture launch derives each job's window itself (what me_prep_jobs_kernel writes into a job table: pair, CTU, predictor,
 // xSetSearchRange + clipMv) -- one kernel launch less per refinement; the per-CTU call hands over the job the host prepared
 struct FracPrep { const int16_t* pred_q; uint32_t ctus, dims; int sr; };   // ctus: ctu_first | ctu_count << 16; dims: width | height << 16 (few scalar registers: they stay live across the kernel)
@@ -1428,8 +1459,8 @@ __device__ __forceinline__ int me_dot4_magic(uint32_t p, uint32_t t) { return __
 // STAGE 1 as the kernel runs it: the eight quarter-pel points around the half-pel winner (h3x - 1, h3y - 1) from the 11 x 11 patch that
 // starts at the shared window's first sample (me_tap8): HM's two filter passes sample for sample -- the taps left out are zeros.
 // P: 11 rows x 11 samples; tab_h / tab_v: [h3 * 3 + offset] rows of 8 taps.
-template <int HAD, int BPS, int KIND8, int WP>
-__device__ __forceinline__ void me_frac_eval1(const uint32_t (&P)[kFracRows1][3 * BPS], const float (&orgM)[16], int h3x, int h3y, int role, int bd,
+template <int HAD, int BPS, int KIND8, int WP, class Org>
+__device__ __forceinline__ void me_frac_eval1(const uint32_t (&P)[kFracRows1][3 * BPS], const Org orgM, int h3x, int h3y, int role, int bd,
                                               float clip_lo, const uint32_t* tab_h, const float* tab_v, bool want4, const FracWp wp,
                                               uint32_t (&out)[9], uint32_t (&out4)[9]) {
   constexpr int PW = 3 * BPS;
@@ -1506,7 +1537,8 @@ __device__ __forceinline__ void me_frac_eval1(const uint32_t (&P)[kFracRows1][3 
       v2f dp[4][2];
       if constexpr (!WP) {   // two columns per instruction: v_pk_fma_f32 / v_pk_add_f32
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r) {
+          const float4 org = orgM.row(r);
 #pragma unroll
           for (int cp = 0; cp < 2; ++cp) {
             v2f a = {524288.5f * sc2, 524288.5f * sc2};
@@ -1516,22 +1548,26 @@ __device__ __forceinline__ void me_frac_eval1(const uint32_t (&P)[kFracRows1][3 
               a = __builtin_elementwise_fma(cc, t, a);
             }
             const v2f y = v2f{__builtin_amdgcn_fmed3f(a.x, clip_lo, maxv), __builtin_amdgcn_fmed3f(a.y, clip_lo, maxv)} + v2f{kRoundMagic, kRoundMagic};
-            const v2f dd = v2f{orgM[4 * r + 2 * cp], orgM[4 * r + 2 * cp + 1]} - y;
+            const v2f dd = (cp ? v2f{org.z, org.w} : v2f{org.x, org.y}) - y;
             d[4 * r + 2 * cp] = dd.x; d[4 * r + 2 * cp + 1] = dd.y;
             dp[r][cp] = dd;
           }
+        }
       } else
 #endif
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < 4; ++r) {
+        const float4 org = orgM.row(r);
+        const float og[4] = {org.x, org.y, org.z, org.w};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           float a = 524288.5f * sc2;   // second pass (TComInterpolationFilter.cpp:195-212)
 #pragma unroll
           for (int j = 0; j < 8; ++j) a = __builtin_fmaf(cv[j], tmp[r + j][c], a);
           const float y = __builtin_amdgcn_fmed3f(a, clip_lo, maxv) + kRoundMagic;   // clip, then round (the bounds are integers)
-          d[4 * r + c] = orgM[4 * r + c] - (WP ? __builtin_floorf(__builtin_fmaf(wp.ws, y - kRoundMagic, wp.rs)) : y);
+          d[4 * r + c] = og[c] - (WP ? __builtin_floorf(__builtin_fmaf(wp.ws, y - kRoundMagic, wp.rs)) : y);
         }
+      }
       uint32_t own4 = 0;
 #ifndef ME_FRAC_SCALAR_STAGE1
       const uint32_t contrib = (HAD && !WP) ? me_frac_had_pk<KIND8>(dp, s1, s2, want4, own4) : me_frac_dist<HAD, KIND8>(d, s1, s2, want4, own4);
@@ -1564,8 +1600,8 @@ constexpr uint32_t kFracKey0 = 0x3ffffu, kFracKey1 = 0x3fffffu;
 // five rows of each column (rows above 0..3 and below 3) instead of 2 x 4, and every filtered value is rounded and clipped once, not once
 // per point that reads it: 396 second-pass FMAs instead of 816, 165 first-pass dot products instead of 264.  Same values as nine
 // separate evaluations bit for bit: every intermediate is exact in fp32 (above), so the order of summation is free.
-template <int HAD, int BPS, int KIND8, int WP>
-__device__ __forceinline__ void me_frac_eval0(const uint32_t (&P)[12][3 * BPS], const float (&orgM)[16], int role, int bd, float clip_lo,
+template <int HAD, int BPS, int KIND8, int WP, class Org>
+__device__ __forceinline__ void me_frac_eval0(const uint32_t (&P)[12][3 * BPS], const Org orgM, int role, int bd, float clip_lo,
                                               bool want4, const FracWp wp, uint32_t (&out)[9], uint32_t (&out4)[9]) {
   constexpr int PW = 3 * BPS;
   constexpr int idxH[3][3] = {{5, 1, 6}, {3, 0, 4}, {7, 2, 8}};   // [dy+1][dx+1], s_acMvRefineH order (TEncSearch.cpp:51-75)
@@ -1615,8 +1651,11 @@ __device__ __forceinline__ void me_frac_eval0(const uint32_t (&P)[12][3 * BPS], 
 #define ME_FRAC_POINT(Y, R0, C0, DYI, DXI)                                                   \
   {                                                                                          \
     float d[16];                                                                             \
-    _Pragma("unroll") for (int r = 0; r < 4; ++r)                                            \
-      _Pragma("unroll") for (int c = 0; c < 4; ++c) d[4 * r + c] = orgM[4 * r + c] - Y[(R0) + r][(C0) + c]; \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                          \
+      const float4 org_ = orgM.row(r);                                                       \
+      const float og_[4] = {org_.x, org_.y, org_.z, org_.w};                                 \
+      _Pragma("unroll") for (int c = 0; c < 4; ++c) d[4 * r + c] = og_[c] - Y[(R0) + r][(C0) + c]; \
+    }                                                                                        \
     uint32_t own4 = 0;                                                                       \
     out[idxH[DYI][DXI]] = me_frac_dist<HAD, KIND8>(d, s1, s2, want4, own4);                  \
     out4[idxH[DYI][DXI]] = own4;                                                             \
@@ -1711,6 +1750,155 @@ __device__ __forceinline__ void me_frac_eval0(const uint32_t (&P)[12][3 * BPS], 
 #undef ME_FRAC_POINT
 }
 
+// ---- tree-shaped accumulation of a wave whose sixteen implicit items share ONE key -------------------------------------------------------
+// The per-entry walk (me_frac_compute) adds an item's nine distortions to every slot of its position that shares its key, slot by slot:
+// 64 x 18 + 256 x 6 = 2 688 lane adds per CTU and stage, and because the large slots cover many positions up to sixteen lanes of a
+// wave add to the same LDS address in one instruction (0.63 of the kernel's LDS cycles were bank-conflict cycles on content whose slots
+// share their motion, profiles/r05l_frac_counters_by_content.txt).  Where all sixteen 8x8 positions of a wave -- two position rows, a
+// 64 x 16 strip of the CTU -- carry the same key K, what a slot with key K gets from the wave is the SUM of the values of the strip's
+// positions inside it: sums over aligned groups of positions, formed once with six lane exchanges (A .. G below; a .. f for the slots made
+// of 4x4 blocks), each added by ONE lane of its group -- 744 adds per CTU and stage, no two lanes of an instruction at one address.
+// A slot whose key is not K takes nothing here: its positions are listed items of their own (me_frac_dedupe), as before.
+// Lane bits inside the wave: 0 rx, 1 ry (quadrant), 2 x0, 3 x1, 4 x2 (position column), 5 y0 (position row).  The designated lanes and
+// the slot numbers are tools/frac_tree_model.py's, which checks them against the slot table: every slot is tiled exactly once.
+template <int BPS> struct FracSum;
+template <> struct FracSum<1> { unsigned long long p[3]; };     // three 21-bit fields per word (frac_pack3)
+template <> struct FracSum<2> { uint32_t d[9]; };
+template <int BIT>
+__device__ __forceinline__ uint32_t me_lane_xor_get(uint32_t v) {   // the value of lane (l ^ (1 << BIT)), BIT = 0..3
+  if constexpr (BIT == 0) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);        // quad_perm [1,0,3,2]
+  else if constexpr (BIT == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+  else if constexpr (BIT == 2) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);                     // bit mode: and 0x1f, or 0, xor 4
+  else return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);                          // row_ror:8
+}
+template <int BIT>
+__device__ __forceinline__ uint32_t me_lane_xor_sum(uint32_t v) {   // v + the value of lane (l ^ (1 << BIT)), BIT = 0..5
+  if constexpr (BIT == 4) { const u32x2_t r = __builtin_amdgcn_permlane16_swap(v, v, false, false); return r.x + r.y; }
+  else if constexpr (BIT == 5) { const u32x2_t r = __builtin_amdgcn_permlane32_swap(v, v, false, false); return r.x + r.y; }
+  else return v + me_lane_xor_get<BIT>(v);
+}
+template <int BIT>
+__device__ __forceinline__ unsigned long long me_lane_xor_sum(unsigned long long v) {
+  const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  if constexpr (BIT == 4) {
+    const u32x2_t a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return ((unsigned long long)a.x | (unsigned long long)b.x << 32) + ((unsigned long long)a.y | (unsigned long long)b.y << 32);
+  } else if constexpr (BIT == 5) {
+    const u32x2_t a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return ((unsigned long long)a.x | (unsigned long long)b.x << 32) + ((unsigned long long)a.y | (unsigned long long)b.y << 32);
+  } else {
+    return v + ((unsigned long long)me_lane_xor_get<BIT>(lo) | (unsigned long long)me_lane_xor_get<BIT>(hi) << 32);
+  }
+}
+template <int BIT, int STAGE>
+__device__ __forceinline__ FracSum<1> me_frac_xsum(const FracSum<1>& v) {
+  FracSum<1> r;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) r.p[k] = me_lane_xor_sum<BIT>(v.p[k]);
+  return r;
+}
+template <int BIT, int STAGE>
+__device__ __forceinline__ FracSum<2> me_frac_xsum(const FracSum<2>& v) {
+  FracSum<2> r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.d[i] = i < STAGE ? 0u : me_lane_xor_sum<BIT>(v.d[i]);   // stage 1: point 0 is carried over, nothing adds to it
+  return r;
+}
+template <int STAGE, int BPS>
+__device__ __forceinline__ void me_frac_tree_add(const uint32_t (&dist)[9], const uint32_t (&dist4)[9], bool want4, uint32_t key, const uint32_t* st,
+                                                 uint32_t* acc, int tid) {
+  constexpr uint32_t keymask = STAGE ? kFracKey1 : kFracKey0;
+  // everything below depends on the lane's place alone: without this the compiler computes the designated-lane masks and the slot numbers
+  // once per kernel and keeps them -- 28 SGPRs and 16 VGPRs -- across the item evaluation, which has none to spare (56 B of scratch per lane)
+  asm volatile("" : "+v"(tid));
+  const int role = tid & 3, rx = role & 1, ry = role >> 1, x = (tid >> 2) & 7, y = tid >> 5;
+  const int w = y >> 1, x0 = x & 1, y0 = y & 1, r16 = (y >> 1) * 4 + (x >> 1), r32 = (y >> 2) * 2 + (x >> 2);
+  auto amp_row = [](int r) { return (4 - r) & 3; };        // row (of a CU's four) -> 2NxnU.p0, 2NxnU.p1, 2NxnD.p0, 2NxnD.p1 = sub-families 0, 3, 2, 1
+  auto amp_col = [](int c) { return 4 + ((4 - c) & 3); };  // column -> nLx2N.p0, nLx2N.p1, nRx2N.p0, nRx2N.p1 = 4, 7, 6, 5
+  auto pack = [](const uint32_t (&d)[9]) {
+    FracSum<BPS> v;
+    if constexpr (BPS == 1) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        v.p[k] = (unsigned long long)(d[3 * k] | d[3 * k + 1] << 21) | (unsigned long long)(d[3 * k + 1] >> 11 | d[3 * k + 2] << 10) << 32;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) v.d[i] = d[i];
+    }
+    return v;
+  };
+  auto put = [&](bool mine, int slot, const FracSum<BPS>& v) {   // the designated lane adds the group's sum if the slot shares the wave's key
+    if (mine && ((st[slot] ^ key) & keymask) == 0) {
+      if constexpr (BPS == 1) {
+        unsigned long long* a = (unsigned long long*)acc + slot * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) atomicAdd(&a[k], v.p[k]);
+      } else {
+#pragma unroll
+        for (int i = STAGE; i < 9; ++i) atomicAdd(&acc[slot * 9 + i], v.d[i]);
+      }
+    }
+  };
+  // ---- slots made of 8x8 blocks: the quad's value (the same in its four lanes)
+  const FracSum<BPS> A = pack(dist);
+  put(role == 0, 384 + y * 8 + x, A);                                                            //  8: 2Nx2N
+  const FracSum<BPS> C = me_frac_xsum<5, STAGE>(A);                                              // 8 x 16
+  put(y0 == 0 && role >= 2, role == 2 ? 480 + (y >> 1) * 8 + x                                   // 16: Nx2N part x & 1
+                                      : 512 + amp_col(x & 3) * 4 + r32, C);                      // 32: the AMP part this column belongs to (alone or as a piece)
+  const FracSum<BPS> B = me_frac_xsum<2, STAGE>(A);                                              // 16 x 8
+  put(x0 == 0 && role == 1, 448 + (y >> 1) * 8 + y0 * 4 + (x >> 1), B);                          // 16: 2NxN part y & 1
+  const FracSum<BPS> E = me_frac_xsum<3, STAGE>(B);                                              // 32 x 8
+  put((x & 3) == 1 && role == 1, 512 + amp_row(y & 3) * 4 + r32, E);                             // 32: the AMP part this position row belongs to
+  const FracSum<BPS> D = me_frac_xsum<5, STAGE>(B);                                              // 16 x 16
+  {
+    const int cx = x >> 1;
+    const int slot = role == 0 ? 544 + r16                                                       // 16: 2Nx2N
+                   : role == 1 ? 568 + (y >> 2) * 4 + 2 * (x >> 2) + (cx & 1)                    // 32: Nx2N part
+                   : role == 2 ? 512 + ((cx & 1) ? 7 : 6) * 4 + r32                              // 32: the two-column piece of nLx2N.p1 / nRx2N.p0
+                               : 576 + amp_col(cx);                                              // 64: the AMP part this 16-column belongs to
+    put(x0 == 1 && y0 == 1, slot, D);
+  }
+  const FracSum<BPS> F = me_frac_xsum<3, STAGE>(D);                                              // 32 x 16
+  {
+    const int slot = role == 0 ? 584 + r32                                                       // 32: 2Nx2N
+                   : role == 1 ? 560 + (y >> 2) * 4 + ((y >> 1) & 1) * 2 + (x >> 2)              // 32: 2NxN part
+                   : role == 2 ? 512 + ((w & 1) ? 3 : 2) * 4 + r32                               // 32: the two-row piece of 2NxnU.p1 / 2NxnD.p0
+                               : 590 + (x >> 2);                                                 // 64: Nx2N part
+    put((x & 3) == 2 && y0 == 0, slot, F);
+    put((x & 3) == 3 && y0 == 0 && role == 0, 576 + ((x >> 2) ? 7 : 6), F);                     // 64: the 32-column piece of nLx2N.p1 / nRx2N.p0
+  }
+  const FracSum<BPS> G = me_frac_xsum<4, STAGE>(F);                                              // 64 x 16: the wave's strip
+  {
+    const int slot = role == 0 ? 592 : role == 1 ? 588 + (w >> 1) : role == 2 ? 576 + (w == 0 ? 0 : 3) : 576 + (w == 3 ? 1 : 2);
+    put(x == 7 && y0 == 1, slot, G);
+  }
+  // ---- slots made of 4x4 blocks: the lane's own 4x4 value
+  if (want4) {   // wave-uniform
+    const FracSum<BPS> u = pack(dist4);
+    const FracSum<BPS> a = me_frac_xsum<0, STAGE>(u), b = me_frac_xsum<1, STAGE>(u);             // 8 x 4, 4 x 8
+    {
+      FracSum<BPS> ab;   // element by element: a select between the two structs goes through the stack (56 B of scratch per lane)
+      if constexpr (BPS == 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ab.p[k] = rx == ry ? a.p[k] : b.p[k];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) ab.d[i] = rx == ry ? a.d[i] : b.d[i];
+      }
+      put(true, rx == ry ? y * 16 + ry * 8 + x : 128 + y * 16 + 2 * x + rx, ab);
+    }
+    const int r = 2 * y0 + ry, c = 2 * x0 + rx;                                                  // 4x4 row / column inside the 16x16 CU
+    const FracSum<BPS> cs = me_frac_xsum<2, STAGE>(a);                                           // 16 x 4
+    put(rx == 0 && x0 == 1, 256 + amp_row(r) * 16 + r16, cs);
+    const FracSum<BPS> ds = me_frac_xsum<5, STAGE>(b);                                           // 4 x 16
+    put(ry == 1 && y0 == 1, 256 + amp_col(c) * 16 + r16, ds);
+    const FracSum<BPS> es = me_frac_xsum<1, STAGE>(cs);                                          // 16 x 8: rows 2,3 of 2NxnU.p1 / rows 0,1 of 2NxnD.p0
+    put(rx == 1 && ry == 1 && x0 == 0, 256 + (y0 ? 3 : 2) * 16 + r16, es);
+    const FracSum<BPS> fs = me_frac_xsum<0, STAGE>(ds);                                          // 8 x 16: columns 2,3 of nLx2N.p1 / columns 0,1 of nRx2N.p0
+    put(rx == 1 && ry == 0 && y0 == 0, 256 + (x0 ? 7 : 6) * 16 + r16, fs);
+  }
+}
+
 // One work item = one 4x4 block of one (position, MV) pair; `pair` indexes the cover table (kind-8 pairs first), `role` is the lane's
 // quadrant of an 8x8 Hadamard block.  An item is handled in two steps:
 //   me_frac_fetch    slot state + address -> 12 raw rows of PW + 1 aligned dwords each (global_load_dwordx4 / x3), nothing waited for
@@ -1793,7 +1981,8 @@ __device__ __forceinline__ void me_frac_fetch(const uint8_t* __restrict__ src, i
 
 template <int STAGE, int HAD, int BPS, int KIND8, int WP>
 __device__ __forceinline__ void me_frac_compute(const FracRaw<BPS>& R, const uint32_t* curl, const uint32_t* st, const uint16_t* cover, int pair, int role,
-                                                int bd, float clip_lo, const FracWp wp, const uint32_t* tab_h, const float* tab_v, uint32_t* acc, bool ride) {
+                                                int bd, float clip_lo, const FracWp wp, const uint32_t* tab_h, const float* tab_v, uint32_t* acc, bool ride,
+                                                float4* org_lds) {   // org_lds: u16 planes only -- this lane's block of the current-sample floats (FracOrgLds)
   constexpr int PW = 3 * BPS, NCOV = KIND8 ? kFracCover8 : kFracCover4;
   constexpr uint32_t keymask = STAGE ? kFracKey1 : kFracKey0;
   const int q = KIND8 ? pair : pair - kFracPairs8;
@@ -1835,12 +2024,29 @@ __device__ __forceinline__ void me_frac_compute(const FracRaw<BPS>& R, const uin
     for (int k = 0; k < kFracCover4; ++k) match4 |= (((st[cov4[k]] ^ sv) & keymask) == 0 ? 1u : 0u) << k;
   }
   const bool want4 = KIND8 && __any(match4 != 0);
-  if constexpr (STAGE == 0) {
-    me_frac_eval0<HAD, BPS, KIND8, WP>(P, orgM, role, bd, clip_lo, want4, wp, dist, dist4);
+  if constexpr (BPS == 2) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) org_lds[r * 256] = make_float4(orgM[4 * r], orgM[4 * r + 1], orgM[4 * r + 2], orgM[4 * r + 3]);
+    const FracOrgLds org = {org_lds};
+    if constexpr (STAGE == 0) me_frac_eval0<HAD, BPS, KIND8, WP>(P, org, role, bd, clip_lo, want4, wp, dist, dist4);
+    else me_frac_eval1<HAD, BPS, KIND8, WP>(P, org, (int)((sv >> 18) & 3), (int)((sv >> 20) & 3), role, bd, clip_lo, tab_h, tab_v, want4, wp, dist, dist4);
   } else {
-    me_frac_eval1<HAD, BPS, KIND8, WP>(P, orgM, (int)((sv >> 18) & 3), (int)((sv >> 20) & 3), role, bd, clip_lo, tab_h, tab_v, want4, wp, dist, dist4);
+    const FracOrgRegs org = {orgM};
+    if constexpr (STAGE == 0) me_frac_eval0<HAD, BPS, KIND8, WP>(P, org, role, bd, clip_lo, want4, wp, dist, dist4);
+    else me_frac_eval1<HAD, BPS, KIND8, WP>(P, org, (int)((sv >> 18) & 3), (int)((sv >> 20) & 3), role, bd, clip_lo, tab_h, tab_v, want4, wp, dist, dist4);
   }
 #ifndef ME_FRAC_T_NOATOMICS   // timing-only builds (tools/r04_frac_breakdown.sh; results are wrong by design): ME_FRAC_T_NOATOMICS, ME_FRAC_T_NOITEMS
+#if ME_FRAC_TREE && !ME_FRAC_RIDE_LISTED   // (with riders on listed items `ride` no longer means "the implicit item")
+  if constexpr (KIND8) {
+    // the implicit items (lane tid = position tid >> 2, quadrant tid & 3) of a wave whose sixteen positions share one key: sums over
+    // groups of positions, one add per (slot, group)
+    static_assert(BPS == 2 || frac_pack3(1), "me_frac_tree_add adds the packed sums of 8-bit planes");
+    if (ride && __all(((sv ^ (uint32_t)__builtin_amdgcn_readfirstlane((int)sv)) & keymask) == 0)) {
+      me_frac_tree_add<STAGE, BPS>(dist, dist4, want4, sv, st, acc, pos * 4 + role);
+      return;
+    }
+  }
+#endif
   // the nine (stage 1: eight, point 0 is carried over, not evaluated -- its distortion here is 0) distortions as they are added to a slot
   unsigned long long pk[3], pk4[3];
   if constexpr (frac_pack3(BPS)) {
@@ -1966,7 +2172,7 @@ __device__ __forceinline__ void me_frac_dedupe4(const uint32_t* st, const uint16
 template <int STAGE, int HAD, int BPS, int WP>
 __device__ __forceinline__ void me_frac_stage(const uint8_t* __restrict__ src, int gpitch, const uint32_t* curl, const uint32_t* st, const uint16_t* cover,
                                               uint16_t* list8, uint16_t* list4, uint32_t* counter, uint32_t* pf, int tid, int bd, float clip_lo,
-                                              const FracWp wp, const uint32_t* tab_h, const float* tab_v, uint32_t* acc) {
+                                              const FracWp wp, const uint32_t* tab_h, const float* tab_v, uint32_t* acc, float4* org_lds) {
   constexpr int NT = frac_threads(BPS);
   static_assert(NT == 256, "me_frac_stage: one implicit item per lane (64 positions x 4 quadrants), the work-list pass on 4 waves");
   constexpr uint32_t keymask = STAGE ? kFracKey1 : kFracKey0;
@@ -2010,7 +2216,7 @@ __device__ __forceinline__ void me_frac_stage(const uint8_t* __restrict__ src, i
         meta = me_frac_prefetch<STAGE, 1>(src, gpitch, st, cover, pair, role, pf_wave);
       }
 #ifndef ME_FRAC_T_NOITEMS
-      me_frac_compute<STAGE, HAD, BPS, 1, WP>(R, curl, st, cover, cur, role, bd, clip_lo, wp, tab_h, tab_v, acc, ME_FRAC_RIDE_LISTED || i8 < NT);
+      me_frac_compute<STAGE, HAD, BPS, 1, WP>(R, curl, st, cover, cur, role, bd, clip_lo, wp, tab_h, tab_v, acc, ME_FRAC_RIDE_LISTED || i8 < NT, org_lds);
 #endif
       if (!more) break;
     }
@@ -2030,7 +2236,7 @@ __device__ __forceinline__ void me_frac_stage(const uint8_t* __restrict__ src, i
           meta = me_frac_prefetch<STAGE, 0>(src, gpitch, st, cover, pair, 0, pf_wave);
         }
 #ifndef ME_FRAC_T_NOITEMS
-        me_frac_compute<STAGE, HAD, BPS, 0, WP>(R, curl, st, cover, cur, 0, bd, clip_lo, wp, tab_h, tab_v, acc, false);
+        me_frac_compute<STAGE, HAD, BPS, 0, WP>(R, curl, st, cover, cur, 0, bd, clip_lo, wp, tab_h, tab_v, acc, false, org_lds);
 #endif
         if (!more) break;
       }
@@ -2055,7 +2261,7 @@ __device__ __forceinline__ void me_frac_stage(const uint8_t* __restrict__ src, i
 #endif
       }
 #ifndef ME_FRAC_T_NOITEMS
-      me_frac_compute<STAGE, HAD, BPS, 1, WP>(R, curl, st, cover, pair, role, bd, clip_lo, wp, tab_h, tab_v, acc, ME_FRAC_RIDE_LISTED || i8 < 0);
+      me_frac_compute<STAGE, HAD, BPS, 1, WP>(R, curl, st, cover, pair, role, bd, clip_lo, wp, tab_h, tab_v, acc, ME_FRAC_RIDE_LISTED || i8 < 0, org_lds);
 #endif
       if (i8 < 0) {
         __syncthreads();   // the work lists are complete
@@ -2071,7 +2277,7 @@ __device__ __forceinline__ void me_frac_stage(const uint8_t* __restrict__ src, i
       const int pair = list4[i4];
       FracRaw<BPS> R;
       me_frac_fetch<STAGE, BPS, 0>(src, gpitch, st, cover, pair, 0, R);
-      me_frac_compute<STAGE, HAD, BPS, 0, WP>(R, curl, st, cover, pair, 0, bd, clip_lo, wp, tab_h, tab_v, acc, false);
+      me_frac_compute<STAGE, HAD, BPS, 0, WP>(R, curl, st, cover, pair, 0, bd, clip_lo, wp, tab_h, tab_v, acc, false, org_lds);
     }
 #endif
   }
@@ -2134,6 +2340,8 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
   uint32_t* curl = tab_h + 160 + (kFracPairs8 + kFracPairs4) / 2;   // 64 x 64 current block
   uint16_t* cover = (uint16_t*)(curl + 1024 * BPS);   // the cover table (uint16 [64][18] then [256][6]): read per item and per dedupe, so it lives here
   uint32_t* pf = (uint32_t*)(cover + kFracPairs8 + kFracPairs4);   // 8-bit planes: [4 waves][12 rows][64 lanes][16 B] patch rows in flight (me_frac_stage)
+  // u16 planes: [4 rows][256 lanes] float4 -- every lane's sixteen current samples as floats (FracOrgLds), written and read by that lane alone
+  float4* org_lds = BPS == 2 ? (float4*)(((uintptr_t)(pf + frac_pf_dw(BPS)) + 15) & ~(uintptr_t)15) + threadIdx.x : nullptr;
 
   const int tid = threadIdx.x;
   const int bd = BPS == 1 ? 8 : bit_depth;
@@ -2232,8 +2440,8 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
 #pragma unroll 1
   for (int stage = 0; stage < 2; ++stage) {
     ME_FRAC_STAMP();   // (timeline builds: the list phase is no phase of its own any more -- its stamp is the stage's start)
-    if (stage == 0) me_frac_stage<0, HAD, BPS, WP>(src, ref_pitch, curl, st, cover, list8, list4, counter, pf, tid, bd, clip_lo, wp, tab_h, tab_v, acc);
-    else me_frac_stage<1, HAD, BPS, WP>(src, ref_pitch, curl, st, cover, list8, list4, counter, pf, tid, bd, clip_lo, wp, tab_h, tab_v, acc);
+    if (stage == 0) me_frac_stage<0, HAD, BPS, WP>(src, ref_pitch, curl, st, cover, list8, list4, counter, pf, tid, bd, clip_lo, wp, tab_h, tab_v, acc, org_lds);
+    else me_frac_stage<1, HAD, BPS, WP>(src, ref_pitch, curl, st, cover, list8, list4, counter, pf, tid, bd, clip_lo, wp, tab_h, tab_v, acc, org_lds);
     __syncthreads();
     ME_FRAC_STAMP();
     if (tid < 2) counter[tid] = 0;

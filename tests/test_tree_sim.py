@@ -179,3 +179,17 @@ def test_generated_16bit_tree_reproduces_reference_goldens(case):
                          (m["origin_x"], m["origin_y"]), (m["lt_x"], m["lt_y"]), (m["rb_x"], m["rb_y"]),
                          (m["pred_x"], m["pred_y"]), m["lambda_q16"], m["bit_depth"])
     assert np.array_equal(got, d["out"][case])
+
+
+def test_refinement_tree_accumulation_tiles_every_slot_exactly_once():
+    """tools/frac_tree_model.py restates the designated lanes and slot numbers of me_frac_tree_add (the refinement kernel's ME_FRAC_TREE build):
+    the pieces the four waves add to a slot must tile its rectangle exactly once, for all 593 slots of the reference's layout"""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import frac_tree_model
+    from hmme import api
+    api.build()
+    n = frac_tree_model.check(api.slot_rect)
+    assert n == 744          # 296 sums over 8x8 positions + 448 over 4x4 blocks, against 2 688 lane adds of the entry-by-entry walk
