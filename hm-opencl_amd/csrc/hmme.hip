@@ -1097,9 +1097,10 @@ int hmme_plane_set_device_u8(hmme_plane* pl, const void* d_src, int src_pitch, v
 // and a launch runs in rounds of that many: 2 040 CTU searches are 3.98 rounds of 512, but 570 (1920 x 1200) are 1.11 -- the second
 // round would keep 58 slots busy and cost as much as the first (measured before this plan existed: 2 340 GSAD/s against 3 339 at
 // 2160p).  So the jobs beyond the last full round ("tail", from job tail_first on) are dealt in finer pieces:
-//   8-bit:  jobs [0, tail_first) run whole (me_search_kernel<FEN, 0>); the tail's tasks -- all its jobs' lane-iterations as ONE list --
-//           are cut into tail_wgs equal segments, one per workgroup of a second launch (me_search_kernel<FEN, 2>; a segment may end one
-//           job and begin the next), merged through the 64-bit atomicMin table.  Until round 6 every tail job was cut into the same
+//   8-bit:  a launch without a tail runs whole jobs (me_search_kernel<FEN, 0>).  With one, ONE launch of me_search_kernel<FEN, 2>: jobs
+//           [0, tail_first) whole, one workgroup each and first in the grid; the tail's tasks -- all its jobs' lane-iterations as ONE list --
+//           cut into tail_wgs equal segments, one per workgroup (a segment may end one job and begin the next); everything merged
+//           through the 64-bit atomicMin table and decoded by me_finalize16_kernel.  Until round 6 every tail job was cut into the same
 //           number of pieces: 240 jobs (720p) in 2 pieces each filled 480 of 512 slots with 34 or 33 lane-iterations -- 9 for the
 //           slowest wave where 7.85 would do -- and the clipped windows of edge CTUs made shorter pieces still;
 //   16-bit: one launch; jobs [0, tail_first) are cut into n_strips strips, tail jobs into tail_parts (>= n_strips).
@@ -1111,10 +1112,11 @@ struct FramePlan {
   int pdw = 0, strip_rows = 0;
   int tail_first = 0;      // == jobs: no tail
   int tail_parts = 1;      // 16-bit: strips of a tail job
-  int tail_wgs = 0;        // 8-bit: workgroups (= segments) of the tail's launch
+  int tail_wgs = 0;        // 8-bit: workgroups (= segments) of the tail
+  bool one_launch = true;  // 8-bit with a tail: head and tail in one segment launch (else the head whole, then the tail's segments: HMME_TAIL_LAUNCHES=2)
   bool tile8 = false;
   int n_wg16 = 0;          // 16-bit: workgroups of the launch
-  size_t tail_jobs_off = 0;   // 8-bit: byte offset of the tail's segment table (me_seg_table_*) inside ctx->d_jobs
+  size_t tail_jobs_off = 0;   // (8-bit segment launches: the table, me_seg_table_*, starts at ctx->d_jobs)
 };
 
 // pieces per tail job that finish `tail` jobs soonest: rounds of `slots` workgroups, each as long as its piece of a whole job
@@ -1198,8 +1200,14 @@ static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_para
   if (wide) need = sizeof(MeJob16) * (size_t)pl->n_wg16;
   else if (pl->tile8) need = sizeof(MeJob16) * (size_t)jobs * 4;
   else {
-    pl->tail_jobs_off = (sizeof(MeJob) * (size_t)head + 255) & ~(size_t)255;
-    need = pl->tail_jobs_off + hmme::me_seg_table_bytes(pl->tail_wgs, n_tail);
+    // One launch lets the tail's segments start on the slots the head's short jobs (clipped windows at the picture's edge) leave first, but sends
+    // the head's jobs through the merge table and its decode as well: worth it where the tail is a good part of the launch (1440p, 408 tail
+    // jobs behind 512: +0.4 %; 2560 x 1088, 168: +0.5 %), not for a few jobs behind a full round (1200p, 58: -3 %).  profiles/r06n_tail_one_or_two_launches.txt
+    static const int launches_knob = std::getenv("HMME_TAIL_LAUNCHES") ? std::atoi(std::getenv("HMME_TAIL_LAUNCHES")) : 0;   // A/B knob: 1 | 2
+    pl->one_launch = launches_knob == 1 || (launches_knob != 2 && 3 * n_tail >= head);
+    pl->tail_jobs_off = pl->one_launch ? 0 : (sizeof(MeJob) * (size_t)head + 255) & ~(size_t)255;
+    need = !n_tail ? sizeof(MeJob) * (size_t)head
+         : pl->one_launch ? hmme::me_seg_table_bytes(head + pl->tail_wgs, jobs) : pl->tail_jobs_off + hmme::me_seg_table_bytes(pl->tail_wgs, n_tail);
   }
   size_t cap = ctx->jobs_bytes;
   const size_t per_ref = n_refs > 0 ? (need + n_refs - 1) / n_refs : need;   // what kMaxRefs pairs of this picture size would ask for
@@ -1232,12 +1240,20 @@ static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_para
                        (const int16_t*)d_pred_q, first, count, n_refs, cur->width, cur->height, fp->search_range, pl->n_strips, pl->strip_rows,
                        pl->tail_first, pl->tail_parts);
   else {
-    if (head)
-      hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, grid(head), block, 0, s, (MeJob*)ctx->d_jobs, (const int16_t*)d_pred_q, first, count,
-                         n_refs, cur->width, cur->height, fp->search_range, 0, head, 1, (uint32_t*)nullptr);
-    if (n_tail)
-      hipLaunchKernelGGL(hmme::me_prep_segments_kernel, dim3(1), dim3(hmme::kSegPrepThreads), 0, s, (void*)((uint8_t*)ctx->d_jobs + pl->tail_jobs_off), ctx->d_first_strip,
-                         (const int16_t*)d_pred_q, first, count, n_refs, cur->width, cur->height, fp->search_range, pl->tail_wgs, head, n_tail);
+    if (!n_tail || !pl->one_launch) {
+      if (head)
+        hipLaunchKernelGGL(hmme::me_prep_jobs_kernel, grid(head), block, 0, s, (MeJob*)ctx->d_jobs, (const int16_t*)d_pred_q, first, count,
+                           n_refs, cur->width, cur->height, fp->search_range, 0, head, 1, (uint32_t*)nullptr);
+      if (n_tail)
+        hipLaunchKernelGGL(hmme::me_prep_segments_kernel, dim3(1), dim3(hmme::kSegPrepThreads), 0, s, (void*)((uint8_t*)ctx->d_jobs + pl->tail_jobs_off), ctx->d_first_strip,
+                           (const int16_t*)d_pred_q, first, count, n_refs, cur->width, cur->height, fp->search_range, pl->tail_wgs, head, n_tail, 0);
+    } else {   // one segment table for the whole launch: the head's jobs whole, then the tail's segments
+      if (head)
+        hipLaunchKernelGGL(hmme::me_prep_whole_segments_kernel, grid(head), block, 0, s, ctx->d_jobs, ctx->d_first_strip, (const int16_t*)d_pred_q, first, count,
+                           n_refs, cur->width, cur->height, fp->search_range, head + pl->tail_wgs, head);
+      hipLaunchKernelGGL(hmme::me_prep_segments_kernel, dim3(1), dim3(hmme::kSegPrepThreads), 0, s, ctx->d_jobs, ctx->d_first_strip,
+                         (const int16_t*)d_pred_q, first, count, n_refs, cur->width, cur->height, fp->search_range, head + pl->tail_wgs, head, n_tail, head);
+    }
   }
   HIP_TRY(ctx, hipGetLastError());
   ctx->jobs_tag = tag;
@@ -1254,10 +1270,14 @@ static int run_search(hmme_ctx* ctx, const RefSet& curs, int cur_ctus_x, const R
     return launch_search8_split(ctx, curs, cur_ctus_x, refs, ref_pitch, (const MeJob16*)ctx->d_jobs, ctx->d_first_strip, pl.jobs, 4,
                                 fp->fen, d_mv, d_sad, s);
   const int head = pl.tail_first, n_tail = pl.jobs - head;
+  if (!n_tail) return launch_search8(ctx, curs, cur_ctus_x, refs, ref_pitch, (const MeJob*)ctx->d_jobs, head, fp->fen, d_mv, d_sad, s);
   unsigned long long* best = nullptr;
-  int rc = n_tail ? merge_table(ctx, n_tail, nullptr, s, &best) : HMME_OK;   // the tail's merge table is preset before the head runs, not between the two
-  if (rc == HMME_OK) rc = launch_search8(ctx, curs, cur_ctus_x, refs, ref_pitch, (const MeJob*)ctx->d_jobs, head, fp->fen, d_mv, d_sad, s);
-  if (rc || !n_tail) return rc;
+  int rc = merge_table(ctx, pl.one_launch ? pl.jobs : n_tail, nullptr, s, &best);   // (preset, if it has to be, before the head runs, not between the two)
+  if (rc) return rc;
+  if (pl.one_launch)
+    return launch_search8_segments(ctx, curs, cur_ctus_x, refs, ref_pitch, ctx->d_jobs, ctx->d_first_strip, pl.jobs, head + pl.tail_wgs, fp->fen, d_mv, d_sad, s, best);
+  rc = launch_search8(ctx, curs, cur_ctus_x, refs, ref_pitch, (const MeJob*)ctx->d_jobs, head, fp->fen, d_mv, d_sad, s);
+  if (rc) return rc;
   return launch_search8_segments(ctx, curs, cur_ctus_x, refs, ref_pitch, (const uint8_t*)ctx->d_jobs + pl.tail_jobs_off, ctx->d_first_strip, n_tail, pl.tail_wgs,
                                  fp->fen, d_mv + (size_t)head * 2 * HMME_NUM_CTU_PARTS, d_sad + (size_t)head * HMME_NUM_CTU_PARTS, s, best);
 }

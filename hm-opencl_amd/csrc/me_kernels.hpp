@@ -310,9 +310,12 @@ __device__ __forceinline__ void me_stage_window(uint32_t* win, const uint32_t* _
 }
 
 // Segment table of a SPLIT = 2 launch of me_search_kernel (written by me_prep_segments_kernel), one allocation:
-//   int4    segs[W]        per workgroup: (job its segment starts in, first unit, end unit) in the launch's list of UNITS; .w unused
+//   int4    segs[W]        per workgroup: (job its segment starts in, first unit, end unit, h) in the list of UNITS of the launch's TAIL jobs
+//                          (jobs h .. n - 1), or (job, 0, 0, -1): the workgroup searches that job whole (the head jobs 0 .. h - 1, one each)
 //   MeJob16 jobs[n]        the jobs (y0 / y1 unused; `job` = index into the result arrays); me_finalize16_kernel decodes against them
-//   int     prefix[n + 1]  units of the jobs before job j: job j owns the list's units [prefix[j], prefix[j + 1])
+//   int     prefix[n + 1]  entry j - h: units of the tail jobs before job j -- job j >= h owns the list's units [prefix[j - h], prefix[j - h + 1])
+// Head and tail in ONE launch: the head's workgroups come first in the grid, and a segment starts on whichever slot a head job (the clipped
+// windows of the picture's edge CTUs make short ones) leaves first -- as two launches the tail waited for the head's last workgroup.
 // A unit is kSegUnit = 4 consecutive tasks (lane-iterations) of one job -- one per wave of the workgroup; a job's last unit may be short.
 // Segments are cut at unit boundaries: where a segment leaves one job and enters the next the four waves meet at a barrier, and a piece
 // of a job that is not a multiple of four tasks would leave waves idle in its last round on BOTH sides of every such boundary.
@@ -353,11 +356,11 @@ me_search_kernel(const RefSet curs, int cur_ctus_x, const RefSet refs, int ref_p
   MeJob job;
   int t_first = 0, t_end = 0x7fffffff, out_job = blockIdx.x;
   unsigned long long tile_off = 0;   // SPLIT, tiled windows: (y, x) of this tile's first candidate in the CTU's whole window
-  int seg_j = 0, seg_g = 0, seg_end = 0;   // SPLIT = 2: the job the segment is in, the next task of the launch's list, the segment's end
+  int seg_j = 0, seg_g = 0, seg_end = 0, seg_head = 0;   // SPLIT = 2: the job the segment is in, the next unit of the tail's list, the segment's end; the number of head jobs (-1: this workgroup searches job seg_j whole)
   if constexpr (SPLIT == 2) {
     const int4 sg = me_seg_table_segs(jobs_v)[blockIdx.x];
-    seg_j = sg.x; seg_g = sg.y; seg_end = sg.z;
-    if (seg_g >= seg_end) return;      // fewer tasks than workgroups (tiny windows): nothing for this one
+    seg_j = sg.x; seg_g = sg.y; seg_end = sg.z; seg_head = sg.w;
+    if (seg_head >= 0 && seg_g >= seg_end) return;      // fewer units than workgroups (tiny windows): nothing for this one
   } else if constexpr (SPLIT == 1) {
     const MeJob16 jb = ((const MeJob16*)jobs_v)[blockIdx.x];
     job = jb.j; t_first = jb.y0; t_end = jb.y1; out_job = jb.job & kTileJobMask;
@@ -369,11 +372,14 @@ me_search_kernel(const RefSet curs, int cur_ctus_x, const RefSet refs, int ref_p
 #pragma unroll 1
   for (bool first_job = true;; first_job = false) {   // one pass, except SPLIT = 2: one pass per job the segment reaches into
   if constexpr (SPLIT == 2) {
-    const int* prefix = me_seg_table_prefix(jobs_v, gridDim.x, n_seg_jobs);
-    const int p0 = prefix[seg_j], p1 = prefix[seg_j + 1];
     job = me_seg_table_jobs(jobs_v, gridDim.x)[seg_j].j;
-    t_first = (seg_g - p0) * kSegUnit; t_end = (min(seg_end, p1) - p0) * kSegUnit; out_job = seg_j;   // the job's last unit may be short: n_tasks clips
-    seg_g = p1; ++seg_j;
+    out_job = seg_j;
+    if (seg_head >= 0) {
+      const int* prefix = me_seg_table_prefix(jobs_v, gridDim.x, n_seg_jobs) - seg_head;
+      const int p0 = prefix[seg_j], p1 = prefix[seg_j + 1];
+      t_first = (seg_g - p0) * kSegUnit; t_end = (min(seg_end, p1) - p0) * kSegUnit;   // the job's last unit may be short: n_tasks clips
+      seg_g = p1; ++seg_j;
+    }                                  // else: a head job, whole (t_first = 0, t_end = everything; seg_g == seg_end: one pass)
     if (!first_job) __syncthreads();   // every thread has merged the previous job's table; window and table are free again
   }
 #if ME_FAIR_PRIO
@@ -1038,50 +1044,43 @@ __global__ void me_prep_jobs16_kernel(MeJob16* jobs, int* first_strip_of_job, co
   }
 }
 
-// 8-bit split mode: each CTU's tasks are dealt to n_split workgroups (4 tasks = one per wave is the useful minimum)
-__global__ void me_prep_jobs_split_kernel(MeJob16* jobs, int* first_strip_of_job, const int16_t* __restrict__ pred_q,
-                                      int ctu_first, int ctu_count, int n_refs, int pic_w, int pic_h, int sr, int n_split,
-                                      int job0, int n_jobs) {
-  const int li = blockIdx.x * blockDim.x + threadIdx.x;
-  if (li >= n_jobs) return;
-  const int i = job0 + li;              // which (CTU, reference); jobs[], first_strip_of_job[] and MeJob16::job count from job0
-  const int r = i / ctu_count;
-  const int ctus_x = (pic_w + 63) >> 6, n_ctu = ctus_x * ((pic_h + 63) >> 6);
-  const int ctu = ctu_first + (i - r * ctu_count);
-  const int cu_x = (ctu % ctus_x) * 64, cu_y = (ctu / ctus_x) * 64;
-  const long pq = 2 * ((long)r * n_ctu + ctu);
-  const int px = pred_q ? pred_q[pq] : 0, py = pred_q ? pred_q[pq + 1] : 0;
-  int ltx, lty, rbx, rby;
-  set_search_range(px, py, sr, cu_x, cu_y, pic_w, pic_h, ltx, lty, rbx, rby);
-  MeJob j;
-  j.ctu_x = (int16_t)(cu_x | r); j.ctu_y = (int16_t)cu_y;
-  j.lt_x = (int16_t)ltx; j.lt_y = (int16_t)lty; j.rb_x = (int16_t)rbx; j.rb_y = (int16_t)rby;
-  j.pred_x = (int16_t)px; j.pred_y = (int16_t)py;
-  const int nt = me_num_tasks(rbx - ltx + 1, rby - lty + 1);
-  first_strip_of_job[li] = li * n_split;
-  for (int s = 0; s < n_split; ++s) {
-    MeJob16 js;
-    js.j = j;
-    js.y0 = (int16_t)((long)nt * s / n_split);
-    js.y1 = (int16_t)((long)nt * (s + 1) / n_split);
-    js.job = li;
-    jobs[li * n_split + s] = js;
-  }
-}
-
 // 8-bit segment mode (me_search_kernel SPLIT = 2): the jobs' units (kSegUnit tasks) as one list, cut into n_wg equal segments.  ONE workgroup of
 // kSegPrepThreads threads writes the whole table (n_jobs <= kSegPrepThreads: a tail is shorter than one round of the chip's workgroup slots):
 // a job and its unit count per thread, an inclusive scan in LDS, then the segments -- segment s owns units [N s / n_wg, N (s + 1) / n_wg)
 // and starts in the job whose range holds its first unit (binary search in the prefix sums).
 constexpr int kSegPrepThreads = 512;
+// the head of a segment launch: jobs 0 .. n_head - 1, one workgroup each, in the XCD-aware order of a whole-job launch (me_xcd_unit)
+__global__ void me_prep_whole_segments_kernel(void* table, int* first_strip_of_job, const int16_t* __restrict__ pred_q, int ctu_first, int ctu_count,
+                                              int n_refs, int pic_w, int pic_h, int sr, int n_wg, int n_head) {
+  const int li = blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= n_head) return;
+  const int r = li / ctu_count;
+  const int ctus_x = (pic_w + 63) >> 6, n_ctu = ctus_x * ((pic_h + 63) >> 6);
+  const int ctu = ctu_first + (li - r * ctu_count);
+  const int cu_x = (ctu % ctus_x) * 64, cu_y = (ctu / ctus_x) * 64;
+  const long pq = 2 * ((long)r * n_ctu + ctu);
+  const int px = pred_q ? pred_q[pq] : 0, py = pred_q ? pred_q[pq + 1] : 0;
+  int ltx, lty, rbx, rby;
+  set_search_range(px, py, sr, cu_x, cu_y, pic_w, pic_h, ltx, lty, rbx, rby);
+  MeJob16 js;
+  js.j.ctu_x = (int16_t)(cu_x | r); js.j.ctu_y = (int16_t)cu_y;
+  js.j.lt_x = (int16_t)ltx; js.j.lt_y = (int16_t)lty; js.j.rb_x = (int16_t)rbx; js.j.rb_y = (int16_t)rby;
+  js.j.pred_x = (int16_t)px; js.j.pred_y = (int16_t)py;
+  js.y0 = 0; js.y1 = 0x7fff; js.job = li;
+  ((MeJob16*)me_seg_table_jobs(table, n_wg))[li] = js;
+  first_strip_of_job[li] = li;
+  ((int4*)me_seg_table_segs(table))[me_xcd_position(li, n_head)] = make_int4(li, 0, 0, -1);
+}
+// the tail: the launch's jobs job0 .. job0 + n_jobs - 1 as entries idx0 .. of the table's jobs and as its segments idx0 .. n_wg - 1.
+// idx0 = job0: the head's jobs are entries / workgroups 0 .. job0 - 1 of the same table (one launch); idx0 = 0: a table of the tail alone
 __global__ void __launch_bounds__(kSegPrepThreads)
 me_prep_segments_kernel(void* table, int* first_strip_of_job, const int16_t* __restrict__ pred_q, int ctu_first, int ctu_count, int n_refs,
-                        int pic_w, int pic_h, int sr, int n_wg, int job0, int n_jobs) {
+                        int pic_w, int pic_h, int sr, int n_wg, int job0, int n_jobs, int idx0) {
   __shared__ int scan[kSegPrepThreads + 1];
   const int li = threadIdx.x;
   int nt = 0;
   if (li < n_jobs) {
-    const int i = job0 + li;              // which (CTU, reference); jobs[], first_strip_of_job[] and MeJob16::job count from job0
+    const int i = job0 + li;              // which (CTU, reference): the launch's job i
     const int r = i / ctu_count;
     const int ctus_x = (pic_w + 63) >> 6, n_ctu = ctus_x * ((pic_h + 63) >> 6);
     const int ctu = ctu_first + (i - r * ctu_count);
@@ -1095,10 +1094,10 @@ me_prep_segments_kernel(void* table, int* first_strip_of_job, const int16_t* __r
     js.j.lt_x = (int16_t)ltx; js.j.lt_y = (int16_t)lty; js.j.rb_x = (int16_t)rbx; js.j.rb_y = (int16_t)rby;
     js.j.pred_x = (int16_t)px; js.j.pred_y = (int16_t)py;
     nt = me_num_tasks(rbx - ltx + 1, rby - lty + 1);
-    js.y0 = 0; js.y1 = (int16_t)nt; js.job = li;
+    js.y0 = 0; js.y1 = (int16_t)nt; js.job = idx0 + li;
     nt = (nt + kSegUnit - 1) / kSegUnit;   // from here on: units
-    ((MeJob16*)me_seg_table_jobs(table, n_wg))[li] = js;
-    first_strip_of_job[li] = li;          // me_finalize16_kernel: job li decodes against jobs[li]
+    ((MeJob16*)me_seg_table_jobs(table, n_wg))[idx0 + li] = js;
+    first_strip_of_job[idx0 + li] = idx0 + li;   // me_finalize16_kernel: entry e decodes against jobs[e]
   }
   scan[li + 1] = nt;
   if (li == 0) scan[0] = 0;
@@ -1109,18 +1108,19 @@ me_prep_segments_kernel(void* table, int* first_strip_of_job, const int16_t* __r
     scan[li + 1] += v;
     __syncthreads();
   }
-  int* prefix = (int*)me_seg_table_prefix(table, n_wg, n_jobs);
+  int* prefix = (int*)me_seg_table_prefix(table, n_wg, idx0 + n_jobs);
   if (li <= n_jobs) prefix[li] = scan[li];
   const long total = scan[n_jobs];
-  int4* segs = (int4*)me_seg_table_segs(table);
-  for (int s = li; s < n_wg; s += kSegPrepThreads) {
-    const int g0 = (int)(total * s / n_wg), g1 = (int)(total * (s + 1) / n_wg);
+  int4* segs = (int4*)me_seg_table_segs(table) + idx0;
+  const int n_seg = n_wg - idx0;
+  for (int s = li; s < n_seg; s += kSegPrepThreads) {
+    const int g0 = (int)(total * s / n_seg), g1 = (int)(total * (s + 1) / n_seg);
     int lo = 0, hi = n_jobs;                         // the job j with scan[j] <= g0 < scan[j + 1] (every job has at least one task)
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
       if (scan[mid] <= g0) lo = mid; else hi = mid;
     }
-    segs[s] = make_int4(lo, g0, g1, 0);
+    segs[s] = make_int4(idx0 + lo, g0, g1, idx0);
   }
 }
 
@@ -1205,8 +1205,7 @@ constexpr int frac_threads(int bps) { return 256; }
 #endif
 constexpr bool frac_glds(int bps) { return ME_FRAC_GLDS && bps == 1; }
 constexpr int frac_pf_dw(int bps) { return frac_glds(bps) ? 12 * 4 * 256 : 0; }
-constexpr size_t frac_org_bytes(int bps) { return bps == 2 ? 16 + 4 * 256 * 16 : 0; }   // u16 planes: the lanes' current samples as floats (FracOrgLds) + alignment
-constexpr size_t frac_lds_bytes(int bps) { return (size_t)(frac_acc_dw(bps) + 600 + 160 + (64 * 18 + 256 * 6) / 2 + 1024 * bps + (64 * 18 + 256 * 6) / 2 + frac_pf_dw(bps)) * 4 + frac_org_bytes(bps) + ME_FRAC_T_LDS_PAD; }
+constexpr size_t frac_lds_bytes(int bps) { return (size_t)(frac_acc_dw(bps) + 600 + 160 + (64 * 18 + 256 * 6) / 2 + 1024 * bps + (64 * 18 + 256 * 6) / 2 + frac_pf_dw(bps)) * 4 + ME_FRAC_T_LDS_PAD; }
 
 __device__ __forceinline__ uint32_t me_mv_cost_q(uint32_t lambda_q16, int vx_q, int vy_q, int pred_x, int pred_y) {
   return (lambda_q16 * (me_component_bits(vx_q - pred_x) + me_component_bits(vy_q - pred_y))) >> 16;
@@ -1426,25 +1425,12 @@ __device__ __forceinline__ uint32_t me_frac_had_pk(const v2f (&P)[4][2], float s
 // ws = w0 * 2^-shift, rs = round * 2^-shift: fma(ws, p, rs) IS (w0 * p + round) / 2^shift exactly (|w0 * p + round| < 2^24), v_floor_f32
 // the shift; org_sub = what to take off a staged current sample: its staging bias + offset.  WP = 0: none of this is compiled in.
 struct FracWp { float ws, rs, org_sub; };
-// The item's sixteen current samples (+ kRoundMagic) as the evaluation reads them, row by row.  8-bit planes: sixteen registers.  u16 planes:
-// a block of LDS the lane wrote itself (me_frac_compute) -- the u16 kernels sit at the 256-VGPR limit, these sixteen values are live from
-// the first filtered sample to the last point, and with them in registers the three u16 variants spilled 5..9 dwords per lane to scratch;
-// four ds_read_b128 per point cost nothing beside the ~300 VALU instructions of a point.
+// The item's sixteen current samples (+ kRoundMagic) as the evaluation reads them, row by row: sixteen registers.  (Round 6 put them into a
+// block of LDS for the u16 variants, which sit at the 256-VGPR limit and spill 5..9 dwords: nothing spilled any more and 8-10 % slower --
+// 24-40 B of scratch per lane cost less than 36 more LDS reads per item.  profiles/r06h_frac_tree_ab.txt)
 struct FracOrgRegs {
   const float (&m)[16];
   __device__ __forceinline__ float4 row(int r) const { return make_float4(m[4 * r], m[4 * r + 1], m[4 * r + 2], m[4 * r + 3]); }
-};
-struct FracOrgLds {
-  const float4* p;   // row r of this lane at p[r * 256]
-  // The pointer is made opaque per read: a plain load from `p` is read ONCE by the compiler and kept -- sixteen registers live across the
-  // evaluation, which is what this block exists to avoid (that build spilled 11..55 dwords) -- while a load the compiler cannot prove equal
-  // to an earlier one is issued where the point needs it and scheduled like any other LDS read.  (ds_read_b128 + s_waitcnt in one asm
-  // statement was tried first: 36 full LDS round trips per item with nothing issued behind them, 9 % slower than the spilling build.)
-  __device__ __forceinline__ float4 row(int r) const {
-    const float4* q = p;
-    asm volatile("" : "+v"(q));
-    return q[r * 256];
-  }
 };
 // a whole-picture launch derives each job's window itself (what me_prep_jobs_kernel writes into a job table: pair, CTU, predictor,
 // xSetSearchRange + clipMv) -- one kernel launch less per refinement; the per-CTU call hands over the job the host prepared
@@ -1981,8 +1967,7 @@ __device__ __forceinline__ void me_frac_fetch(const uint8_t* __restrict__ src, i
 
 template <int STAGE, int HAD, int BPS, int KIND8, int WP>
 __device__ __forceinline__ void me_frac_compute(const FracRaw<BPS>& R, const uint32_t* curl, const uint32_t* st, const uint16_t* cover, int pair, int role,
-                                                int bd, float clip_lo, const FracWp wp, const uint32_t* tab_h, const float* tab_v, uint32_t* acc, bool ride,
-                                                float4* org_lds) {   // org_lds: u16 planes only -- this lane's block of the current-sample floats (FracOrgLds)
+                                                int bd, float clip_lo, const FracWp wp, const uint32_t* tab_h, const float* tab_v, uint32_t* acc, bool ride) {
   constexpr int PW = 3 * BPS, NCOV = KIND8 ? kFracCover8 : kFracCover4;
   constexpr uint32_t keymask = STAGE ? kFracKey1 : kFracKey0;
   const int q = KIND8 ? pair : pair - kFracPairs8;
@@ -2024,13 +2009,7 @@ __device__ __forceinline__ void me_frac_compute(const FracRaw<BPS>& R, const uin
     for (int k = 0; k < kFracCover4; ++k) match4 |= (((st[cov4[k]] ^ sv) & keymask) == 0 ? 1u : 0u) << k;
   }
   const bool want4 = KIND8 && __any(match4 != 0);
-  if constexpr (BPS == 2) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) org_lds[r * 256] = make_float4(orgM[4 * r], orgM[4 * r + 1], orgM[4 * r + 2], orgM[4 * r + 3]);
-    const FracOrgLds org = {org_lds};
-    if constexpr (STAGE == 0) me_frac_eval0<HAD, BPS, KIND8, WP>(P, org, role, bd, clip_lo, want4, wp, dist, dist4);
-    else me_frac_eval1<HAD, BPS, KIND8, WP>(P, org, (int)((sv >> 18) & 3), (int)((sv >> 20) & 3), role, bd, clip_lo, tab_h, tab_v, want4, wp, dist, dist4);
-  } else {
+  {
     const FracOrgRegs org = {orgM};
     if constexpr (STAGE == 0) me_frac_eval0<HAD, BPS, KIND8, WP>(P, org, role, bd, clip_lo, want4, wp, dist, dist4);
     else me_frac_eval1<HAD, BPS, KIND8, WP>(P, org, (int)((sv >> 18) & 3), (int)((sv >> 20) & 3), role, bd, clip_lo, tab_h, tab_v, want4, wp, dist, dist4);
@@ -2172,7 +2151,7 @@ __device__ __forceinline__ void me_frac_dedupe4(const uint32_t* st, const uint16
 template <int STAGE, int HAD, int BPS, int WP>
 __device__ __forceinline__ void me_frac_stage(const uint8_t* __restrict__ src, int gpitch, const uint32_t* curl, const uint32_t* st, const uint16_t* cover,
                                               uint16_t* list8, uint16_t* list4, uint32_t* counter, uint32_t* pf, int tid, int bd, float clip_lo,
-                                              const FracWp wp, const uint32_t* tab_h, const float* tab_v, uint32_t* acc, float4* org_lds) {
+                                              const FracWp wp, const uint32_t* tab_h, const float* tab_v, uint32_t* acc) {
   constexpr int NT = frac_threads(BPS);
   static_assert(NT == 256, "me_frac_stage: one implicit item per lane (64 positions x 4 quadrants), the work-list pass on 4 waves");
   constexpr uint32_t keymask = STAGE ? kFracKey1 : kFracKey0;
@@ -2216,7 +2195,7 @@ __device__ __forceinline__ void me_frac_stage(const uint8_t* __restrict__ src, i
         meta = me_frac_prefetch<STAGE, 1>(src, gpitch, st, cover, pair, role, pf_wave);
       }
 #ifndef ME_FRAC_T_NOITEMS
-      me_frac_compute<STAGE, HAD, BPS, 1, WP>(R, curl, st, cover, cur, role, bd, clip_lo, wp, tab_h, tab_v, acc, ME_FRAC_RIDE_LISTED || i8 < NT, org_lds);
+      me_frac_compute<STAGE, HAD, BPS, 1, WP>(R, curl, st, cover, cur, role, bd, clip_lo, wp, tab_h, tab_v, acc, ME_FRAC_RIDE_LISTED || i8 < NT);
 #endif
       if (!more) break;
     }
@@ -2236,7 +2215,7 @@ __device__ __forceinline__ void me_frac_stage(const uint8_t* __restrict__ src, i
           meta = me_frac_prefetch<STAGE, 0>(src, gpitch, st, cover, pair, 0, pf_wave);
         }
 #ifndef ME_FRAC_T_NOITEMS
-        me_frac_compute<STAGE, HAD, BPS, 0, WP>(R, curl, st, cover, cur, 0, bd, clip_lo, wp, tab_h, tab_v, acc, false, org_lds);
+        me_frac_compute<STAGE, HAD, BPS, 0, WP>(R, curl, st, cover, cur, 0, bd, clip_lo, wp, tab_h, tab_v, acc, false);
 #endif
         if (!more) break;
       }
@@ -2261,7 +2240,7 @@ __device__ __forceinline__ void me_frac_stage(const uint8_t* __restrict__ src, i
 #endif
       }
 #ifndef ME_FRAC_T_NOITEMS
-      me_frac_compute<STAGE, HAD, BPS, 1, WP>(R, curl, st, cover, pair, role, bd, clip_lo, wp, tab_h, tab_v, acc, ME_FRAC_RIDE_LISTED || i8 < 0, org_lds);
+      me_frac_compute<STAGE, HAD, BPS, 1, WP>(R, curl, st, cover, pair, role, bd, clip_lo, wp, tab_h, tab_v, acc, ME_FRAC_RIDE_LISTED || i8 < 0);
 #endif
       if (i8 < 0) {
         __syncthreads();   // the work lists are complete
@@ -2277,7 +2256,7 @@ __device__ __forceinline__ void me_frac_stage(const uint8_t* __restrict__ src, i
       const int pair = list4[i4];
       FracRaw<BPS> R;
       me_frac_fetch<STAGE, BPS, 0>(src, gpitch, st, cover, pair, 0, R);
-      me_frac_compute<STAGE, HAD, BPS, 0, WP>(R, curl, st, cover, pair, 0, bd, clip_lo, wp, tab_h, tab_v, acc, false, org_lds);
+      me_frac_compute<STAGE, HAD, BPS, 0, WP>(R, curl, st, cover, pair, 0, bd, clip_lo, wp, tab_h, tab_v, acc, false);
     }
 #endif
   }
@@ -2340,8 +2319,6 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
   uint32_t* curl = tab_h + 160 + (kFracPairs8 + kFracPairs4) / 2;   // 64 x 64 current block
   uint16_t* cover = (uint16_t*)(curl + 1024 * BPS);   // the cover table (uint16 [64][18] then [256][6]): read per item and per dedupe, so it lives here
   uint32_t* pf = (uint32_t*)(cover + kFracPairs8 + kFracPairs4);   // 8-bit planes: [4 waves][12 rows][64 lanes][16 B] patch rows in flight (me_frac_stage)
-  // u16 planes: [4 rows][256 lanes] float4 -- every lane's sixteen current samples as floats (FracOrgLds), written and read by that lane alone
-  float4* org_lds = BPS == 2 ? (float4*)(((uintptr_t)(pf + frac_pf_dw(BPS)) + 15) & ~(uintptr_t)15) + threadIdx.x : nullptr;
 
   const int tid = threadIdx.x;
   const int bd = BPS == 1 ? 8 : bit_depth;
@@ -2440,8 +2417,8 @@ me_frac_kernel(const RefSet curs, int cur_pitch, const RefSet refs, int ref_pitc
 #pragma unroll 1
   for (int stage = 0; stage < 2; ++stage) {
     ME_FRAC_STAMP();   // (timeline builds: the list phase is no phase of its own any more -- its stamp is the stage's start)
-    if (stage == 0) me_frac_stage<0, HAD, BPS, WP>(src, ref_pitch, curl, st, cover, list8, list4, counter, pf, tid, bd, clip_lo, wp, tab_h, tab_v, acc, org_lds);
-    else me_frac_stage<1, HAD, BPS, WP>(src, ref_pitch, curl, st, cover, list8, list4, counter, pf, tid, bd, clip_lo, wp, tab_h, tab_v, acc, org_lds);
+    if (stage == 0) me_frac_stage<0, HAD, BPS, WP>(src, ref_pitch, curl, st, cover, list8, list4, counter, pf, tid, bd, clip_lo, wp, tab_h, tab_v, acc);
+    else me_frac_stage<1, HAD, BPS, WP>(src, ref_pitch, curl, st, cover, list8, list4, counter, pf, tid, bd, clip_lo, wp, tab_h, tab_v, acc);
     __syncthreads();
     ME_FRAC_STAMP();
     if (tid < 2) counter[tid] = 0;

@@ -285,8 +285,11 @@ int hmme_refine_pairs_device(hmme_ctx* ctx, const hmme_plane* const* curs, const
  *                         same stream as the one before it reuses the table that is still in place)
  *   HMME_FAIR_PRIO=<0|1>  search kernels: wave priorities that fall with a wave's progress off / on whatever the launch size (default: on
  *                         for whole-CTU workgroups, and for split / strip launches of up to four rounds of workgroups)
- *   HMME_TAIL_PARTS=<n>   pieces per job of a launch's last, partial round of workgroups: default = the planner's choice
- *                         (DESIGN.md 5 "rounds of workgroups"); 1 = no tail plan
+ *   HMME_TAIL_PARTS=<n>   the jobs beyond a launch's last full round of workgroups ("tail"): 1 = no tail plan (they run whole, like the others);
+ *                         n > 1 = n workgroups per tail job (8-bit: equal segments of the tail's task list; 16-bit: n strips per tail job);
+ *                         default = the planner's choice (DESIGN.md 4.1 "tails")
+ *   HMME_TAIL_LAUNCHES=<1|2> 8-bit launches with a tail: head and tail in one segment launch / the head's whole jobs, then the tail's segments
+ *                         (default: one launch where the tail is at least a third of the head)
  *   HMME_STRIPS16=<n>     16-bit search kernel: that many equal window strips per job instead of the planner's number
  *   HMME_LDS_BUDGET16=<b> 16-bit search kernel: LDS bytes a strip's window rows may take (clamped to what the kernel can address)
  * Measurement and test entry points live in include/hmme_test.h, not here. */

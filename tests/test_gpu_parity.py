@@ -1523,6 +1523,61 @@ def test_tail_plan_pictures_whose_searches_do_not_fill_whole_rounds(engine, orac
             assert np.array_equal(mv[r, sl, :, 0], ox) and np.array_equal(mv[r, sl, :, 1], oy) and np.array_equal(sad[r, sl], osad), (r, row)
 
 
+_TAIL_KNOB_HELPER = """
+import sys, zlib, numpy as np
+sys.path.insert(0, sys.argv[1])
+from hmme import api, synth
+w, h, sr, refs, out = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+cur, ref, _ = synth.make_pair(w, h, seed=4321, max_mv=min(sr, 12), region=96, noise_sigma=1.5)
+m = synth.MARGIN
+ref2 = np.pad(np.roll(ref[m:m + h, m:m + w], (2, -3), axis=(0, 1)), m, mode="edge")
+n = api.load().hmme_num_ctus(w, h)
+pred = synth.random_predictors(n * refs, seed=5, max_pel=sr).reshape(refs, n, 2)
+with api.Engine(0, 64) as e:
+    e.set_lambda(33.0)
+    with e.plane(w, h) as pc, e.plane(w, h) as pr, e.plane(w, h) as pr2:
+        pc.upload_pel(cur, (m, m)); pr.upload_pel(ref, (m, m)); pr2.upload_pel(ref2, (m, m))
+        for fen in (1, 0):
+            mv, sad = e.search_frame_multi(pc, [pr, pr2][:refs], sr, pred, fen=fen)
+            np.savez(out + str(fen) + ".npz", mv=mv, sad=sad)
+"""
+
+
+@pytest.mark.parametrize("w,h,sr,refs", [(2560, 1440, 12, 1), (1344, 832, 16, 2), (1280, 720, 20, 1)])
+def test_tail_launch_modes_give_the_same_tables_as_whole_jobs_and_the_oracle(tmp_path, oracle_lib, w, h, sr, refs):
+    """a launch that does not fill whole rounds of workgroups: its tail as equal segments in ONE launch with the head (HMME_TAIL_LAUNCHES=1), as a
+    second launch behind the head's whole jobs (=2), with another number of segments (HMME_TAIL_PARTS=3), and no tail plan at all
+    (HMME_TAIL_PARTS=1: every job whole) -- 920 jobs = 512 + 408; two references of 273 = 512 + 34 (the tail inside the second
+    reference's jobs); 240 jobs = all tail.  FEN on and off.  All five give identical tables, and those equal the oracle on CTU rows of head and tail"""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from hmme import synth
+    modes = {"default": {}, "one": {"HMME_TAIL_LAUNCHES": "1"}, "two": {"HMME_TAIL_LAUNCHES": "2"}, "parts3": {"HMME_TAIL_PARTS": "3"}, "whole": {"HMME_TAIL_PARTS": "1"}}
+    for name, env in modes.items():
+        r = subprocess.run([sys.executable, "-c", _TAIL_KNOB_HELPER, os.path.join(ROOT, "hm-opencl_amd"), str(w), str(h), str(sr), str(refs), str(tmp_path / name)],
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+    cur, ref, _ = synth.make_pair(w, h, seed=4321, max_mv=min(sr, 12), region=96, noise_sigma=1.5)
+    m = synth.MARGIN
+    ref2 = np.pad(np.roll(ref[m:m + h, m:m + w], (2, -3), axis=(0, 1)), m, mode="edge")
+    ctus_x, ctus_y = (w + 63) // 64, (h + 63) // 64
+    n = ctus_x * ctus_y
+    pred = synth.random_predictors(n * refs, seed=5, max_pel=sr).reshape(refs, n, 2)
+    lq = oracle_lib.oracle().hmo_lambda_q16(33.0)
+    for fen in (1, 0):
+        base = np.load(str(tmp_path / "whole") + f"{fen}.npz")
+        for name in modes:
+            d = np.load(str(tmp_path / name) + f"{fen}.npz")
+            assert np.array_equal(d["mv"], base["mv"]) and np.array_equal(d["sad"], base["sad"]), (name, fen)
+        mv, sad = base["mv"].reshape(refs, n, 593, 2), base["sad"].reshape(refs, n, 593)
+        for r_, plane in enumerate([ref, ref2][:refs]):
+            for row in sorted({0, ctus_y // 2, ctus_y - 1}):
+                ox, oy, osad = oracle_lib.search_frame(cur, plane, (m, m), w, h, sr, pred[r_], lq, fen, 8, ctu_first=row * ctus_x, ctu_count=ctus_x, n_threads=16)
+                sl = slice(row * ctus_x, (row + 1) * ctus_x)
+                assert np.array_equal(mv[r_, sl, :, 0], ox) and np.array_equal(mv[r_, sl, :, 1], oy) and np.array_equal(sad[r_, sl], osad), (fen, r_, row)
+
+
 def test_fuzz_pictures_with_a_tail_vs_oracle(engine, oracle_lib):
     """random pictures of 300..1 300 CTUs (more than one round of 512 workgroups, or nearly one): head and tail of the frame plan,
     8- and 10/12-bit, one or two references, small search ranges so that the oracle checks EVERY CTU in seconds"""
