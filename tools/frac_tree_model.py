@@ -87,10 +87,9 @@ def region(tid, name):
         else:
             xs += [px + 4 * (role & 1), px + 4 * (role & 1) + 4]; ys += [py + 4 * (role >> 1), py + 4 * (role >> 1) + 4]
     x0, y0, x1, y1 = min(xs), min(ys), max(xs), max(ys)
-    n = len(lanes) * (64 if kind8 else 16) // (4 if kind8 else 1) if kind8 else len(lanes) * 16
-    if kind8:
-        n = len(lanes) * 64      # each lane stands for its whole position here (the four lanes of a quad hold the same value: counted once below)
-    assert (x1 - x0) * (y1 - y0) == n, (tid, name)
+    # the group's lanes tile a rectangle: each stands for its 8x8 position (kind 8: the quad's four lanes hold the same value, the group
+    # runs over position bits only) or for its own 4x4 block (kind 4)
+    assert (x1 - x0) * (y1 - y0) == len(lanes) * (64 if kind8 else 16), (tid, name)
     return x0, y0, x1 - x0, y1 - y0
 
 
