@@ -196,7 +196,9 @@ int hmme_refine_ctu(hmme_ctx* ctx, const int16_t* ctu, int ctu_stride, const int
                     const hmme_search_params* p, const int16_t* int_mv, int use_hadamard, int16_t* out_qmv, uint32_t* out_cost);
 
 /* ---- frame path ------------------------------------------------------------------------ */
-/* device-resident luma plane with edge-replicated margins; 8-bit planes store bytes, 9..12-bit planes u16.
+/* device-resident luma plane with edge-replicated margins; 8-bit planes store bytes, 9..12-bit planes u16.  Every plane also holds its picture
+ * area once more CTU by CTU (64 x 64 blocks, contiguous: what a search reads the CURRENT picture from), so a plane costs about
+ * (W + 256) x (H + 160) + W x H samples of device memory -- 17.9 MB for an 8-bit 2160p picture.
  * A plane belongs to the context that created it: every frame call refuses planes of another context (HMME_ERR_ARG), and a
  * context's planes are destroyed BEFORE the context (hmme_plane_destroy reads its context). */
 int hmme_plane_create(hmme_ctx* ctx, int width, int height, hmme_plane** out);   /* 8-bit */
