@@ -1054,6 +1054,17 @@ int hmme_test_timeline16(void* out, size_t bytes) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(hmme::g_timeline16), bytes < sizeof(hmme::g_timeline16) ? bytes : sizeof(hmme::g_timeline16)) == hipSuccess ? HMME_OK : HMME_ERR_DEVICE;
 }
 #endif
+static int plan_tail8(int tail, int slots, int w, int tail_knob);
+static bool tail_one_launch(int head, int n_tail, int launches_knob);
+int hmme_test_tail_plan(int width, int height, int search_range, int n_pairs, int slots, int* out) {
+  if (!out || width < 8 || height < 8 || width > 16384 || height > 16384 || search_range < 1 || search_range > 64 || n_pairs < 1 || slots < 1) return HMME_ERR_ARG;
+  const int jobs = hmme_num_ctus(width, height) * n_pairs, tail = jobs % slots, w = 2 * search_range + 1;
+  const int wgs = plan_tail8(tail, slots, w, 0);
+  const int head = wgs > 0 ? jobs - tail : jobs;
+  out[0] = jobs; out[1] = head; out[2] = wgs; out[3] = (wgs > 0 && tail_one_launch(head, jobs - head, 0)) ? 1 : 0;
+  return HMME_OK;
+}
+
 int hmme_test_frac_deal(int k, int n_pairs, int width, int height) {
   if (n_pairs < 1 || width < 8 || height < 8 || width > 16384 || height > 16384) return -1;
   const int n_ctu = hmme_num_ctus(width, height);
@@ -1131,6 +1142,37 @@ static int plan_tail(int tail, int slots, int k_min, int k_max, const std::funct
   return best_k;
 }
 
+// 8-bit launches: workgroups (= segments) for `tail` jobs of full w x w windows beyond the last full round of `slots` workgroups, or 0: the tail
+// runs whole in the head's launch.  (pure arithmetic: hmme_test_tail_plan exposes it to the CPU tests)
+// the tail's units in `rounds` rounds of `slots` equal segments.  A round costs the lane-iterations of its slowest wave plus what
+// every workgroup pays per job it touches -- window load, flush, merge: a quarter iteration fits the sweeps of
+// profiles/archive/r02Q_tail_sweeps.txt -- and a segment of u units touches 1 + (u - 1) / units jobs on average.  Full windows are
+// assumed (the device counts the clipped ones' units itself: me_prep_segments_kernel).  Never below one unit per workgroup: tiny
+// windows get fewer workgroups than slots.
+// Segments are whole units of kSegUnit = 4 tasks (one per wave), so a segment of u units costs u lane-iterations.  Against that stands
+// the tail run WHOLE in the head's launch -- ceil(nt / 4) lane-iterations per wave for one more round of workgroups, which flow in
+// behind the head's without a launch boundary, with the large tasks of whole jobs and without merge table, preset and decode: the
+// segment launch is taken only where the model says it wins by 8 % plus half a lane-iteration (1080p's 510 jobs and the 504 left over
+// at 2160p stay whole: measured 10 % and 4 % slower as segments, profiles/r06d_tail_segments.txt).
+static int plan_tail8(int tail, int slots, int w, int tail_knob) {
+  if (tail <= 0 || tail > hmme::kSegPrepThreads) return 0;
+  const int nt = hmme::me_num_tasks(w, w), units = (nt + hmme::kSegUnit - 1) / hmme::kSegUnit;
+  const long total = (long)tail * units;
+  int best_wgs = 0;
+  double best = (double)units + 0.25;   // the tail as whole jobs
+  for (int rounds = 1; rounds <= 4; ++rounds) {
+    const long wgs = std::max<long>(1, std::min<long>((long)rounds * slots, total));
+    const double per_wg = (double)total / wgs;
+    const double t = 1.08 * rounds * (std::ceil(per_wg) + 0.25 * (1.0 + (per_wg - 1.0) / units)) + 0.5;
+    if (t < best * 0.999) { best = t; best_wgs = (int)wgs; }
+    if (wgs < (long)rounds * slots) break;
+  }
+  if (tail_knob > 1) best_wgs = (int)std::max<long>(1, std::min<long>((long)tail * tail_knob, total));   // A/B: tail_knob workgroups per tail job
+  return best_wgs;
+}
+// head and tail of an 8-bit launch as one segment launch?  (see prep_jobs)
+static bool tail_one_launch(int head, int n_tail, int launches_knob) { return launches_knob == 1 || (launches_knob != 2 && 3 * n_tail >= head); }
+
 // builds the device job table of a picture search against n_refs reference pictures on `s`; job index =
 // ref * count + ctu.  8-bit: MeJob[head jobs] (+ MeJob16[tail jobs * parts]); 8-bit tiled / 16-bit: MeJob16[workgroups]
 static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_params* fp, const void* d_pred_q, int first, int count,
@@ -1171,29 +1213,8 @@ static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_para
   } else if (pl->tile8) {
     pl->n_strips = 4;
   } else if (tail && tail_knob != 1) {
-    // the tail's units in `rounds` rounds of `slots` equal segments.  A round costs the lane-iterations of its slowest wave plus what
-    // every workgroup pays per job it touches -- window load, flush, merge: a quarter iteration fits the sweeps of
-    // profiles/archive/r02Q_tail_sweeps.txt -- and a segment of u units touches 1 + (u - 1) / units jobs on average.  Full windows are
-    // assumed (the device counts the clipped ones' units itself: me_prep_segments_kernel).  Never below one unit per workgroup: tiny
-    // windows get fewer workgroups than slots.
-    // Segments are whole units of kSegUnit = 4 tasks (one per wave), so a segment of u units costs u lane-iterations.  Against that stands
-    // the tail run WHOLE in the head's launch -- ceil(nt / 4) lane-iterations per wave for one more round of workgroups, which flow in
-    // behind the head's without a launch boundary, with the large tasks of whole jobs and without merge table, preset and decode: the
-    // segment launch is taken only where the model says it wins by 8 % plus half a lane-iteration (1080p's 510 jobs and the 504 left over
-    // at 2160p stay whole: measured 10 % and 4 % slower as segments, profiles/r06d_tail_segments.txt).
-    const int nt = hmme::me_num_tasks(w, w), units = (nt + hmme::kSegUnit - 1) / hmme::kSegUnit;
-    const long total = (long)tail * units;
-    int best_wgs = 0;
-    double best = (double)units + 0.25;   // the tail as whole jobs
-    for (int rounds = 1; rounds <= 4; ++rounds) {
-      const long wgs = std::max<long>(1, std::min<long>((long)rounds * slots, total));
-      const double per_wg = (double)total / wgs;
-      const double t = 1.08 * rounds * (std::ceil(per_wg) + 0.25 * (1.0 + (per_wg - 1.0) / units)) + 0.5;
-      if (t < best * 0.999) { best = t; best_wgs = (int)wgs; }
-      if (wgs < (long)rounds * slots) break;
-    }
-    if (tail_knob > 1) best_wgs = (int)std::max<long>(1, std::min<long>((long)tail * tail_knob, total));   // A/B: tail_knob workgroups per tail job
-    if (best_wgs > 0 && tail <= hmme::kSegPrepThreads) { pl->tail_first = jobs - tail; pl->tail_wgs = best_wgs; }
+    const int wgs = plan_tail8(tail, slots, w, tail_knob);
+    if (wgs > 0) { pl->tail_first = jobs - tail; pl->tail_wgs = wgs; }
   }
   const int head = pl->tail_first, n_tail = jobs - head;
   size_t need;
@@ -1204,7 +1225,7 @@ static int prep_jobs(hmme_ctx* ctx, const hmme_plane* cur, const hmme_frame_para
     // the head's jobs through the merge table and its decode as well: worth it where the tail is a good part of the launch (1440p, 408 tail
     // jobs behind 512: +0.4 %; 2560 x 1088, 168: +0.5 %), not for a few jobs behind a full round (1200p, 58: -3 %).  profiles/r06n_tail_one_or_two_launches.txt
     static const int launches_knob = std::getenv("HMME_TAIL_LAUNCHES") ? std::atoi(std::getenv("HMME_TAIL_LAUNCHES")) : 0;   // A/B knob: 1 | 2
-    pl->one_launch = launches_knob == 1 || (launches_knob != 2 && 3 * n_tail >= head);
+    pl->one_launch = tail_one_launch(head, n_tail, launches_knob);
     pl->tail_jobs_off = pl->one_launch ? 0 : (sizeof(MeJob) * (size_t)head + 255) & ~(size_t)255;
     need = !n_tail ? sizeof(MeJob) * (size_t)head
          : pl->one_launch ? hmme::me_seg_table_bytes(head + pl->tail_wgs, jobs) : pl->tail_jobs_off + hmme::me_seg_table_bytes(pl->tail_wgs, n_tail);

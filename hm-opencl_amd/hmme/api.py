@@ -24,7 +24,7 @@ SYMBOLS = ["hmme_create", "hmme_destroy", "hmme_last_error", "hmme_device_info",
            "hmme_search_pairs_device", "hmme_refine_pairs_device", "hmme_plane_upload_async",
            "hmme_upload_status", "hmme_abi_version", "hmme_build_id", "hmme_device_index", "hmme_set_error_printing"]
 # test / measurement entry points (include/hmme_test.h): not part of the boundary
-TEST_SYMBOLS = ["hmme_test_time_search_kernel", "hmme_test_device_address", "hmme_test_frac_deal"]
+TEST_SYMBOLS = ["hmme_test_time_search_kernel", "hmme_test_device_address", "hmme_test_frac_deal", "hmme_test_tail_plan"]
 ABI_VERSION = 6   # HMME_ABI_VERSION of the include/hmme.h these bindings were written against
 
 

@@ -18,6 +18,11 @@ int hmme_test_time_search_kernel(hmme_ctx* ctx, const hmme_plane* cur, const hmm
                                  const void* d_pred_q, void* d_out_mv, void* d_out_sad, void* stream, int reps,
                                  float* avg_ms);
 
+/* how an 8-bit whole-picture search of n_pairs pictures of width x height at `search_range` (<= 64) is dealt to a chip of `slots` workgroup slots
+ * (hmme.hip prep_jobs; host arithmetic, needs no device): out[0] = jobs, out[1] = jobs searched whole (the head; == jobs: no tail plan),
+ * out[2] = workgroups (segments) of the tail, out[3] = 1 if head and tail are one launch */
+int hmme_test_tail_plan(int width, int height, int search_range, int n_pairs, int slots, int* out);
+
 /* which job the k-th workgroup of a refinement launch over `n_pairs` whole pictures of width x height takes (me_frac_deal, me_kernels.hpp:
  * edge CTUs of every pair first, then the interiors); host code, needs no device.  -1 for k outside the launch */
 int hmme_test_frac_deal(int k, int n_pairs, int width, int height);

@@ -301,3 +301,33 @@ def test_bench_counts_the_candidates_actually_searched():
         total += (min(64, w - cx) // 4) * (min(64, h - cy) // 4) * (rb_x - lt_x + 1) * (rb_y - lt_y + 1)
     assert bench.work_4x4_sads(api, w, h, sr, pred) == total
     assert bench.work_4x4_sads(api, w, h, sr) >= total * 0.95 and bench.work_4x4_sads(api, w, h, sr) != total
+
+
+def test_tail_plan_of_whole_picture_searches():
+    """hmme.hip prep_jobs, 8-bit: which jobs of a launch run whole and how the rest -- the jobs beyond the last full round of the chip's 512 workgroup
+    slots -- are cut into equal segments (hmme_test_tail_plan: host arithmetic).  2160p's 504 and 1080p's 510 left-over jobs stay whole (measured
+    slower as segments); 720p is all tail on exactly one round of segments; 1440p's 408 tail jobs share one launch with the 512 head jobs, 1200p's
+    58 get a launch of their own; tiny windows never get more workgroups than they have units of four tasks"""
+    import ctypes as C
+    from hmme import api
+    L = api.load()
+    L.hmme_test_tail_plan.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_int)]
+
+    def plan(w, h, sr=64, pairs=1, slots=512):
+        out = (C.c_int * 4)()
+        assert L.hmme_test_tail_plan(w, h, sr, pairs, slots, out) == 0
+        return tuple(out)
+    assert plan(3840, 2160) == (2040, 2040, 0, 0)
+    assert plan(1920, 1080) == (510, 510, 0, 0)
+    assert plan(3840, 2160, pairs=4) == (8160, 8160, 0, 0)            # 8 160 = 15 rounds + 480: whole
+    assert plan(1280, 720) == (240, 0, 512, 1)                        # all tail: 240 x 17 units on one round of 512 segments
+    assert plan(2560, 1440) == (920, 512, 512, 1)                     # 408 x 17 = 6 936 units on 512 segments behind 512 whole jobs, one launch
+    assert plan(1920, 1200) == (570, 512, 512, 0)                     # 58 tail jobs: a launch of their own
+    assert plan(64, 64, sr=8) == (1, 1, 0, 0)                         # one job of 17 x 17 candidates is 3 tasks = one unit: nothing to cut
+    assert plan(64, 64, sr=64) == (1, 0, 17, 1)                       # one job of 129 x 129: 17 units, a workgroup each
+    jobs, head, wgs, one = plan(832, 480, sr=16)                      # 104 jobs of 33 x 33 candidates
+    assert jobs == 104 and head == 0 and 1 <= wgs <= 512
+    for w, h, sr, pairs in ((1280, 720, 64, 3), (3840, 2160, 32, 1), (640, 360, 64, 16), (4096, 2304, 64, 1)):
+        jobs, head, wgs, one = plan(w, h, sr, pairs)
+        assert head in (jobs, jobs - jobs % 512) and (wgs > 0) == (head < jobs) and (not one or wgs > 0)
+    assert L.hmme_test_tail_plan(1280, 720, 65, 1, 512, (C.c_int * 4)()) != 0      # windows beyond 129 x 129 are tiled, not planned here
