@@ -28,8 +28,9 @@ counts, the same job on rank 0 alone (strong scaling) and a pair of the last ran
 
 At N = 1 the line also times and verifies, after the headline and never inside `value`, the other
 single-GPU BASELINE configurations (`configs`: 1080p SR 64; 2160p 10-bit SR 128; the 64-picture
-random-access sequence streamed through one GPU) and the refinement kernel on coherent, mixed and
-unrelated content (`refine`).
+random-access sequence streamed through one GPU; 720p and 1440p, pictures that do not fill whole rounds
+of the chip's workgroup slots) and the refinement kernel on coherent, mixed and unrelated content
+(`refine`).
 """
 import argparse
 import json
@@ -1135,6 +1136,11 @@ def main():
                 "with_random_predictors": time_search_config(torch, api, synth, eng, dev, 3840, 2160, 8, 64, 10, 1234,
                                                              "3840x2160 8-bit, SearchRange=64, per-CTU random predictors <= +-16 pel (SURVEY 8d)",
                                                              pred=synth.random_predictors(n_ctu, seed=4242, max_pel=16)),
+                # pictures that do not fill whole rounds of the chip's 512 search workgroups, one pair per launch: 720p is 240 jobs (all "tail": equal
+                # segments of the jobs' task list), 1440p 512 whole jobs + 408 as segments in the same launch (DESIGN.md 4.1 "Tails")
+                "small_pictures_one_pair_per_launch": {
+                    "1280x720": time_search_config(torch, api, synth, eng, dev, 1280, 720, 8, 64, 20, 1234, "1280x720 8-bit, SearchRange=64, one pair per launch (240 CTU searches on 512 workgroup slots)"),
+                    "2560x1440": time_search_config(torch, api, synth, eng, dev, 2560, 1440, 8, 64, 20, 1234, "2560x1440 8-bit, SearchRange=64, one pair per launch (920 CTU searches = 512 + 408)")},
                 "config4_2160p_randomaccess_64_pictures_one_gpu": time_sequence_config(torch, api, synth, eng, dev),
                 "config4_with_refinement": time_sequence_config(torch, api, synth, eng, dev, refine=True),
             })
